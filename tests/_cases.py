@@ -1,0 +1,62 @@
+"""Shared helpers: regenerate the inputs of the golden cases (tests/golden/make_golden.py)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from skdownscale_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def month_gid(index):
+    return np.asarray(index.month, dtype=np.int32) - 1
+
+
+def tas_inputs(g, start="1980-01-01"):
+    C, T, Tp, seed, c_full = (int(g[k]) for k in ("C", "T", "Tp", "seed", "c_full"))
+    index = synth.daily_calendar(T, start)
+    index_p = synth.daily_calendar(Tp, start)
+    cells = np.arange(C)
+    X = synth.tas_field("X_hist", seed, index, cells, c_full)
+    y = synth.tas_field("y_obs", seed, index, cells, c_full)
+    Xp = synth.tas_field("X_fut", seed, index_p, cells, c_full)
+    return index, index_p, X, y, Xp
+
+
+def pr_inputs(g):
+    C, T, Tp, seed, c_full = (int(g[k]) for k in ("C", "T", "Tp", "seed", "c_full"))
+    cells = np.arange(C)
+    X = synth.pr_field("X_hist", seed, T, cells, c_full)
+    y = synth.pr_field("y_obs", seed, T, cells, c_full)
+    Xp = synth.pr_field("X_fut", seed, Tp, cells, c_full)
+    return synth.daily_calendar(T), synth.daily_calendar(Tp), X, y, Xp
+
+
+def analog_inputs(g):
+    T, Tq, C, F, seed, c_full = (int(g[k]) for k in ("T", "Tq", "C", "F", "seed", "c_full"))
+    return synth.analog_fields(seed, T, np.arange(C), c_full, n_query=Tq, n_features=F)
+
+
+def assert_close(actual, expected, rtol=1e-6, scale=None, what=""):
+    """north_star tolerance: 1e-6 relative (float64) with an absolute floor tied to the data scale
+    (anomalies are differences of near-equal numbers)."""
+    actual = np.asarray(actual)
+    expected = np.asarray(expected)
+    assert actual.shape == expected.shape, (what, actual.shape, expected.shape)
+    nan_a, nan_e = np.isnan(actual), np.isnan(expected)
+    assert np.array_equal(nan_a, nan_e), f"{what}: NaN pattern differs"
+    fin = ~nan_e
+    if scale is None:
+        scale = float(np.std(expected[fin])) if fin.any() else 1.0
+    atol = rtol * max(scale, 1e-300)
+    err = np.abs(actual[fin] - expected[fin])
+    tol = atol + rtol * np.abs(expected[fin])
+    bad = err > tol
+    assert not bad.any(), f"{what}: {bad.sum()} mismatches, max err {err.max():.3e} (tol {tol[bad].min():.3e})"
+    return float(err.max()) if err.size else 0.0

@@ -1,0 +1,126 @@
+"""CPU: the NumPy oracle reproduces the golden vectors generated from the real reference."""
+import numpy as np
+import pytest
+
+import analog_oracle as ao
+import bcsd_oracle as bo
+from _cases import analog_inputs, assert_close, load, month_gid, pr_inputs, tas_inputs
+
+
+@pytest.mark.parametrize("name", ["g1_tas_same", "g2_tas_long", "g2_tas_short", "g1_tas_small"])
+def test_bcsd_temperature(name):
+    g = load(name)
+    index, index_p, X, y, Xp = tas_inputs(g)
+    for key, ra in (("out_anoms", True), ("out_abs", False)):
+        out, st = bo.pointwise_fit_predict(bo.TAS, X, y, Xp, month_gid(index), month_gid(index_p), return_anoms=ra)
+        assert_close(out, g[key], what=f"{name}/{key}")
+        assert np.array_equal(st, g["status"])
+
+
+def test_bcsd_temperature_ties():
+    g = load("g_tas_ties")
+    index, index_p, X, y, Xp = tas_inputs(g)
+    X, y, Xp = np.round(X * 2) / 2, np.round(y * 2) / 2, np.round(Xp * 2) / 2
+    out, _ = bo.pointwise_fit_predict(bo.TAS, X, y, Xp, month_gid(index), month_gid(index_p))
+    assert_close(out, g["out_anoms"], what="ties")
+
+
+@pytest.mark.parametrize("name", ["g3_pr_same", "g3_pr_long", "g3_pr_small"])
+def test_bcsd_precipitation(name):
+    g = load(name)
+    index, index_p, X, y, Xp = pr_inputs(g)
+    for key, ra in (("out_anoms", True), ("out_abs", False)):
+        out, st = bo.pointwise_fit_predict(bo.PR, X, y, Xp, month_gid(index), month_gid(index_p), return_anoms=ra)
+        assert_close(out, g[key], what=f"{name}/{key}")
+        assert np.array_equal(st, g["status"])
+
+
+def test_bcsd_precipitation_bad_climatology():
+    g = load("g3_pr_badclimo")
+    index, _, X, y, Xp = pr_inputs(g)
+    y[np.asarray(index.month) == 7, 1] = 0.0
+    out, st = bo.pointwise_fit_predict(bo.PR, X, y, Xp, month_gid(index), month_gid(index), return_anoms=True)
+    assert np.array_equal(st, g["status"]) and st[1] == bo.STATUS_BAD_CLIMO
+    assert "Invalid value in target climatology" in str(g["errors"][1])
+    assert_close(out, g["out_anoms"], what="badclimo/anoms")
+    out, st = bo.pointwise_fit_predict(bo.PR, X, y, Xp, month_gid(index), month_gid(index), return_anoms=False)
+    assert np.array_equal(st, g["status_abs"])
+    assert_close(out, g["out_abs"], what="badclimo/abs")
+
+
+def test_ndarray_input_fabricated_index():
+    g = load("g4_ndarray")
+    gid, gid_p = bo.fabricated_group_id(100), bo.fabricated_group_id(150)
+    out, _ = bo.pointwise_fit_predict(bo.TAS, g["X"], g["y"], g["Xp"], gid, gid_p)
+    assert_close(out[:, 0], g["out_tas"], what="ndarray tas")
+    out, _ = bo.pointwise_fit_predict(bo.TAS, g["X"], g["y"], g["X"], gid, gid)
+    assert_close(out[:, 0], g["out_tas_same"], what="ndarray tas same")
+    out, _ = bo.pointwise_fit_predict(bo.PR, g["P"], g["yP"], g["PP"], gid, gid_p)
+    assert_close(out[:, 0], g["out_pr"], what="ndarray pr")
+    assert any("making one up" in str(m) for m in g["warn_msgs"])
+
+
+def test_masked_and_nan_cells():
+    g = load("g7_masked")
+    index, index_p, X, y, Xp = tas_inputs(g)
+    X[0, 1] = np.nan
+    X[0, 4] = np.nan
+    y[0, 1] = np.nan
+    out, st = bo.pointwise_fit_predict(bo.TAS, X, y, Xp, month_gid(index), month_gid(index_p))
+    assert np.array_equal(st, g["status"])
+    assert_close(out, g["out_anoms"], what="masked")
+    X[100, 2] = np.nan
+    _, st = bo.pointwise_fit_predict(bo.TAS, X, y, Xp, month_gid(index), month_gid(index_p))
+    assert np.array_equal(st, g["status_nan_inside"]) and st[2] == bo.STATUS_NONFINITE
+    assert "NaN" in str(g["errors_nan_inside"][2])
+
+
+def test_reference_own_tests():
+    """test_pointwise_models.py:81-90 (QuantileMapper identity) and the 365-day smoke inputs."""
+    g = load("g8_reference_tests")
+    exp = g["qm_expected"][:, 0]
+    q = bo.qm_segment(exp + 2, np.sort(exp))
+    np.testing.assert_almost_equal(q, exp)  # the reference's own assertion
+    np.testing.assert_almost_equal(q, g["qm_actual"][:, 0])
+    import pandas as pd
+
+    index = pd.date_range("2019-01-01", periods=365)
+    x = g["sine365"]
+    out, _ = bo.pointwise_fit_predict(bo.TAS, x[:, None], x[:, None] + 2, x[:, None], month_gid(index), month_gid(index))
+    assert_close(out[:, 0], g["bcsd_tas_sine365"], what="sine365")
+    x = g["pr_random365"]
+    out, _ = bo.pointwise_fit_predict(bo.PR, x[:, None], x[:, None] + 2, x[:, None], month_gid(index), month_gid(index))
+    assert_close(out[:, 0], g["bcsd_pr_random365"], what="pr365")
+
+
+@pytest.mark.parametrize("F", [1, 3])
+def test_analog_knn_bit_exact(F):
+    g = load(f"g5_analog_F{F}")
+    X, y, Xq = analog_inputs(g)
+    for k in (1, 30):
+        for c in range(X.shape[2]):
+            d, i = ao.knn(X[:, :, c], Xq[:, :, c], k)
+            assert np.array_equal(i, g[f"inds_k{k}"][:, :, c])  # bit-exact index selection
+            assert np.array_equal(d, g[f"dist_k{k}"][:, :, c])  # and bit-exact distances
+
+
+@pytest.mark.parametrize("F", [1, 3])
+@pytest.mark.parametrize("kind", ["best_analog", "sample_analogs", "weight_analogs", "mean_analogs"])
+def test_pure_analog(F, kind):
+    g = load(f"g5_analog_F{F}")
+    X, y, Xq = analog_inputs(g)
+    for k in (1, 30):
+        for thresh, tt in ((None, "none"), (0.0, "t0")):
+            tag = f"{kind}_k{k}_{tt}"
+            samp = g["samp_" + tag] if kind == "sample_analogs" else None
+            out = ao.pointwise_analog(X, y, Xq, k, ao.KIND_NAMES[kind], thresh, samp)
+            assert_close(out, g["out_" + tag], what=tag)
+
+
+@pytest.mark.parametrize("F", [1, 3])
+def test_analog_regression(F):
+    g = load(f"g5_analog_F{F}")
+    X, y, Xq = analog_inputs(g)
+    Tr = int(g["Tr"])
+    out = ao.pointwise_analog(X, y, Xq[:Tr], 30, None, regression=True)
+    assert_close(out, g["out_analogreg_k30"], what="analogreg")
