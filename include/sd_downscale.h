@@ -1,0 +1,156 @@
+/* sd_downscale.h -- C ABI of the MI355X-native pointwise-downscaling engine.
+ *
+ * Drop-in boundary for scikit-downscale's per-grid-cell statistical hot path.  Every entry point
+ * replaces a *batch over the cell axis* of one reference call (citations are file:line under
+ * /root/reference/skdownscale/pointwise_models/):
+ *
+ *   sd_bcsd_fit*            <- core.py:86-96 looping BcsdTemperature.fit (bcsd.py:197-228) or
+ *                              BcsdPrecipitation.fit (bcsd.py:115-147) over all cells
+ *   sd_bcsd_predict*        <- core.py:137-141 looping BcsdTemperature.predict (bcsd.py:230-269) or
+ *                              BcsdPrecipitation.predict (bcsd.py:149-185)
+ *   sd_bcsd_fit_predict_dev <- both of the above fused (no persisted quantile state)
+ *   sd_analog_fit*          <- AnalogBase.fit (gard.py:58-87)
+ *   sd_analog_predict*      <- PureAnalog.predict (gard.py:273-364)
+ *   sd_analogreg_predict*   <- AnalogRegression.predict, thresh=None (gard.py:152-224)
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  All fields are float64, time-major with the cell axis
+ *     fastest: X[t*ld + c] (the layout core.py:427-440 `_to_feature_x` produces), feature arrays
+ *     X[(t*F + f)*ld + c].  `ld` >= C is the row stride in elements (host variants: ld == C).
+ *   - `group_id[t]` in [0,G) is the time group (calendar month - 1, groupers.py:11-12); it is the
+ *     same for every cell and always lives in HOST memory.
+ *   - Host variants (`sd_xxx`) take host pointers and copy in/out; `_dev` variants take device
+ *     pointers (HBM-resident fields) and never touch PCIe.  No pointer is retained after a call
+ *     returns; persistent state lives behind opaque handles owned by the library.
+ *   - Every function returns SD_OK (0) or an SD_ERR_* code; sd_last_error() gives the
+ *     thread-local message.  Per-cell conditions (masked / non-finite / bad climatology) are not
+ *     errors of the call: they are reported in `cell_status[C]` and the host raises like the
+ *     reference does (base.py:18-20, bcsd.py:140-141, core.py:35-37).
+ *   - A context is bound to one GPU and one HIP stream; calls on one context are serialised.
+ */
+#ifndef SD_DOWNSCALE_H
+#define SD_DOWNSCALE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SD_VERSION 100
+
+/* return codes */
+#define SD_OK 0
+#define SD_ERR_INVALID 1     /* bad argument (NULL, size <= 0, group id out of range ...) */
+#define SD_ERR_HIP 2         /* HIP runtime failure; message carries hipGetErrorString */
+#define SD_ERR_UNSUPPORTED 3 /* valid request outside the engine's limits (e.g. segment too long) */
+#define SD_ERR_NOMEM 4
+
+/* BCSD variants */
+#define SD_BCSD_TAS 0 /* BcsdTemperature */
+#define SD_BCSD_PR 1  /* BcsdPrecipitation */
+
+/* per-cell status */
+#define SD_CELL_OK 0
+#define SD_CELL_MASKED 1    /* core.py:35-37: first sample of X is NaN -> cell skipped, output NaN */
+#define SD_CELL_NONFINITE 2 /* base.py:18-20: NaN/inf inside an active cell -> ValueError on host */
+#define SD_CELL_BAD_CLIMO 3 /* bcsd.py:140-141: y climatology <= 0 with return_anoms */
+
+/* PureAnalog kinds (gard.py:258-262) */
+#define SD_ANALOG_BEST 0
+#define SD_ANALOG_SAMPLE 1
+#define SD_ANALOG_WEIGHT 2
+#define SD_ANALOG_MEAN 3
+
+/* synthetic field kinds (sd_synth_fill) */
+#define SD_SYNTH_GAUSS 0
+#define SD_SYNTH_PRECIP 1
+
+typedef struct sd_ctx sd_ctx;
+typedef struct sd_bcsd_state sd_bcsd_state;
+typedef struct sd_analog_state sd_analog_state;
+
+/* ---- library / context ---------------------------------------------------------------------- */
+int sd_version(void);
+const char* sd_last_error(void);
+int sd_device_count(int* count);
+int sd_ctx_create(int device, sd_ctx** out);
+int sd_ctx_destroy(sd_ctx* ctx);
+int sd_ctx_synchronize(sd_ctx* ctx);
+int sd_ctx_device_info(sd_ctx* ctx, char* name, size_t name_len, int* compute_units, int64_t* hbm_bytes);
+
+/* ---- device memory (so a non-torch host can keep fields resident in HBM) --------------------- */
+int sd_dev_alloc(sd_ctx* ctx, size_t bytes, void** dptr);
+int sd_dev_free(sd_ctx* ctx, void* dptr);
+int sd_memcpy_h2d(sd_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int sd_memcpy_d2h(sd_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int sd_memcpy_d2d(sd_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+
+/* ---- timing: HIP events on the context's stream ---------------------------------------------- */
+int sd_timer_start(sd_ctx* ctx);
+int sd_timer_stop(sd_ctx* ctx, float* elapsed_ms); /* synchronises the stream */
+/* per-kernel profile: when enabled every launch is bracketed by events (serialising). */
+int sd_prof_enable(sd_ctx* ctx, int on);
+int sd_prof_reset(sd_ctx* ctx);
+int sd_prof_query(sd_ctx* ctx, const char* kernel_name, double* total_ms, int64_t* launches);
+int sd_prof_names(sd_ctx* ctx, char* buf, size_t buf_len); /* ';'-separated kernel names */
+
+/* ---- deterministic synthetic fields generated in HBM (mirror: skdownscale_amd/synth.py) ------- */
+int sd_synth_fill(sd_ctx* ctx, double* out_dev, int64_t T, int64_t C, int64_t ld, int64_t c_offset, int64_t c_full,
+                  int kind, uint64_t seed, uint32_t stream, const double* base_host /* [T] or NULL */, double amp,
+                  double cell_scale, double p_dry, int32_t stream2 /* <0: none */, double amp2);
+
+/* ---- BCSD quantile mapping --------------------------------------------------------------------
+ * X: [T,C] model-historical field (TAS: used for x_climo; PR: only validated, may be NULL ->
+ * mask/validation then use y).  y: [T,C] observations.  group_id: host int32[T]. */
+int sd_bcsd_fit(sd_ctx* ctx, int kind, const double* X, const double* y, const int32_t* group_id, int G, int64_t T,
+                int64_t C, int return_anoms, sd_bcsd_state** out);
+int sd_bcsd_fit_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_dev, int64_t ld,
+                    const int32_t* group_id, int G, int64_t T, int64_t C, int return_anoms, sd_bcsd_state** out);
+/* out: [Tp,C]; cell_status: host int32[C] (may be NULL).  Cells whose fit status != OK get NaN. */
+int sd_bcsd_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, const int32_t* group_id_p, int64_t Tp,
+                    double* out, int32_t* cell_status);
+int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_dev, int64_t ld,
+                        const int32_t* group_id_p, int64_t Tp, double* out_dev, int64_t ld_out, int32_t* cell_status);
+/* fused fit+predict for resident fields: one pass, no persisted state. */
+int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_dev, int64_t ld,
+                            const int32_t* group_id, int G, int64_t T, int64_t C, int return_anoms,
+                            const double* Xp_dev, int64_t ld_p, const int32_t* group_id_p, int64_t Tp,
+                            double* out_dev, int64_t ld_out, int32_t* cell_status);
+int sd_bcsd_state_info(const sd_bcsd_state* st, int* kind, int* G, int64_t* T, int64_t* C, int* return_anoms);
+int sd_bcsd_state_status(const sd_bcsd_state* st, int32_t* cell_status /* host [C] */);
+/* Plain-array view of the fitted state (pickling / get_attr): y_sorted is CELL-major [C][T] with the
+ * G group segments of a cell stored back to back at group_offsets[g]; climatologies are [C][G]. */
+int sd_bcsd_state_export(const sd_bcsd_state* st, double* y_sorted, double* x_climo, double* y_climo,
+                         int32_t* cell_status, int64_t* group_offsets /* [G+1] */);
+int sd_bcsd_state_import(sd_ctx* ctx, int kind, int G, int64_t T, int64_t C, int return_anoms, const double* y_sorted,
+                         const double* x_climo, const double* y_climo, const int32_t* cell_status,
+                         const int64_t* group_offsets, sd_bcsd_state** out);
+int sd_bcsd_state_destroy(sd_bcsd_state* st);
+
+/* ---- GARD analogs ----------------------------------------------------------------------------
+ * X: [T,F,C], y: [T,C], Xq: [Tq,F,C]; out: [Tq,3,C] columns pred / exceedance_prob /
+ * prediction_error (gard.py:254-255).  inds: int64 [Tq,k,C] training indices, ascending distance
+ * (may be NULL); dist: float64 [Tq,k,C] (may be NULL).  sample_inds: int32 [Tq,C], required for
+ * SD_ANALOG_SAMPLE (the host draws them with np.random.randint like gard.py:315). */
+int sd_analog_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int F, int64_t C, sd_analog_state** out);
+int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t ld, int64_t T, int F, int64_t C,
+                      sd_analog_state** out);
+int sd_analog_predict(sd_ctx* ctx, const sd_analog_state* st, const double* Xq, int64_t Tq, int k, int kind,
+                      int has_thresh, double thresh, const int32_t* sample_inds, double* out, int64_t* inds,
+                      double* dist, int32_t* cell_status);
+int sd_analog_predict_dev(sd_ctx* ctx, const sd_analog_state* st, const double* Xq_dev, int64_t ld, int64_t Tq, int k,
+                          int kind, int has_thresh, double thresh, const int32_t* sample_inds_dev, double* out_dev,
+                          int64_t ld_out, int64_t* inds_dev, double* dist_dev, int32_t* cell_status);
+int sd_analogreg_predict(sd_ctx* ctx, const sd_analog_state* st, const double* Xq, int64_t Tq, int k, double* out,
+                         int32_t* cell_status);
+int sd_analogreg_predict_dev(sd_ctx* ctx, const sd_analog_state* st, const double* Xq_dev, int64_t ld, int64_t Tq,
+                             int k, double* out_dev, int64_t ld_out, int32_t* cell_status);
+int sd_analog_state_info(const sd_analog_state* st, int64_t* T, int* F, int64_t* C);
+int sd_analog_state_destroy(sd_analog_state* st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SD_DOWNSCALE_H */

@@ -1,0 +1,216 @@
+/* TEST INFRASTRUCTURE ONLY -- plain-C restatement of the reference's BCSD hot path.
+ *
+ * Checker and CPU baseline ("port") for the HIP engine: only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this.  It follows, step by step and per cell, what
+ * skdownscale/pointwise_models does (citations file:line under /root/reference/skdownscale/
+ * pointwise_models), with NumPy's np.sort / np.interp spelled out in C.  Pinned: checked against
+ * the golden vectors generated from the real reference (tests/test_oracle_c.py) and against the
+ * NumPy restatement oracle/bcsd_oracle.py.
+ *
+ * Build: make -C oracle   (gcc -O2 -fopenmp -ffp-contract=off)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define KIND_TAS 0
+#define KIND_PR 1
+#define ST_OK 0
+#define ST_MASKED 1
+#define ST_NONFINITE 2
+#define ST_BAD_CLIMO 3
+#define ALPHA 0.4 /* quantile.py:423 */
+#define BETA 0.4  /* quantile.py:424 */
+#define N_ENDPOINTS 10 /* quantile.py:426 */
+
+static int cmp_double(const void* a, const void* b) {
+    const double x = *(const double*)a, y = *(const double*)b;
+    return (x > y) - (x < y);
+}
+
+/* quantile.py:23-43 plotting_positions, same operation order */
+static inline double pp_denom(int n) { return ((double)n + 1.0 - ALPHA) - BETA; }
+static inline double pp_at(int i, double denom) { return ((double)(i + 1) - ALPHA) / denom; }
+
+/* number of elements <= v in sorted s[0..n) (np.interp's exact-hit rule: last xp <= x) */
+static int upper_bound(const double* s, int n, double v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (s[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+/* sklearn LinearRegression on one feature = centred least squares (quantile.py:535-543) */
+static void ols_line(const double* ys, int first, int e, double denom, double* slope, double* icpt) {
+    double xm = 0.0, ym = 0.0, sxx = 0.0, sxy = 0.0;
+    for (int i = 0; i < e; ++i) { xm += pp_at(first + i, denom); ym += ys[first + i]; }
+    xm /= e; ym /= e;
+    for (int i = 0; i < e; ++i) {
+        const double dx = pp_at(first + i, denom) - xm;
+        sxx += dx * dx;
+        sxy += dx * (ys[first + i] - ym);
+    }
+    *slope = sxx > 0.0 ? sxy / sxx : 0.0;
+    *icpt = ym - *slope * xm;
+}
+
+/* CunnaneTransformer.inverse_transform (quantile.py:523-545): np.interp(p, pp, ys, -inf, inf) + OLS tails */
+static double inverse_cdf(double p, const double* ys, int n, double denom, const double* tails) {
+    if (p < pp_at(0, denom)) return p * tails[0] + tails[1];
+    if (p > pp_at(n - 1, denom)) return p * tails[2] + tails[3];
+    /* binary search for the last i with pp[i] <= p (numpy compiled_base.c arr_interp) */
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pp_at(mid, denom) <= p) lo = mid + 1; else hi = mid;
+    }
+    const int i = lo - 1;
+    const double pi = pp_at(i, denom);
+    if (i == n - 1 || pi == p) return ys[i];
+    const double slope = (ys[i + 1] - ys[i]) / (pp_at(i + 1, denom) - pi);
+    return slope * (p - pi) + ys[i];
+}
+
+/* QuantileMapper.transform for one segment (quantile.py:109-147): u[m] -> q[m]; work: m doubles */
+static void qm_segment(const double* u, int m, const double* ys, int n, double* q, double* work) {
+    memcpy(work, u, sizeof(double) * m);
+    qsort(work, m, sizeof(double), cmp_double); /* quantile.py:462 via fit_transform 505-521 */
+    const double dm = pp_denom(m), dn = pp_denom(n);
+    double tails[4] = {0, 0, 0, 0};
+    const int e = n < N_ENDPOINTS ? n : N_ENDPOINTS;
+    if (m > n) {
+        ols_line(ys, 0, e, dn, &tails[0], &tails[1]);
+        ols_line(ys, n - e, e, dn, &tails[2], &tails[3]);
+    }
+    for (int j = 0; j < m; ++j) {
+        const int r = upper_bound(work, m, u[j]) - 1; /* quantile.py:488 np.interp on own sorted data */
+        q[j] = inverse_cdf(pp_at(r, dm), ys, n, dn, tails);
+    }
+}
+
+/* One cell: fit (bcsd.py:197-228 / 115-147) + predict (bcsd.py:230-269 / 149-185).
+ * x, y: [T] strided by ld; xp: [Tp] strided by ldp; out: [Tp] strided by ldo. */
+static int bcsd_cell(int kind, const double* x, const double* y, int64_t ld, const double* xp, int64_t ldp,
+                     const int32_t* ord, const int64_t* off, const int32_t* ordp, const int64_t* offp, int G,
+                     int return_anoms, double* out, int64_t ldo, double* buf /* 6*nmax */, int nmax) {
+    double* ys = buf;            /* sorted y segment */
+    double* xg = buf + nmax;     /* predict segment  */
+    double* u = buf + 2 * nmax;
+    double* q = buf + 3 * nmax;
+    double* work = buf + 4 * nmax;
+    double* shiftv = buf + 5 * nmax;
+    const double first = x ? x[0] : y[0];
+    if (first != first) return ST_MASKED; /* core.py:35-37 */
+    int status = ST_OK;
+    /* base.py:18-20: validation happens before any arithmetic */
+    const int64_t T = off[G], Tp = offp[G];
+    for (int64_t t = 0; t < T; ++t)
+        if (!isfinite(y[t * ld]) || (x && !isfinite(x[t * ld]))) return ST_NONFINITE;
+    for (int g = 0; g < G && status == ST_OK; ++g) { /* climatology check precedes the mapper fit (bcsd.py:138-141) */
+        const int n = (int)(off[g + 1] - off[g]);
+        if (kind == KIND_PR && return_anoms && n > 0) {
+            double s = 0.0;
+            for (int i = 0; i < n; ++i) s += y[(int64_t)ord[off[g] + i] * ld];
+            if (s / n <= 0.0) status = ST_BAD_CLIMO;
+        }
+    }
+    if (status != ST_OK) return status;
+    for (int64_t t = 0; t < Tp; ++t)
+        if (!isfinite(xp[t * ldp])) return ST_NONFINITE;
+    for (int g = 0; g < G; ++g) {
+        const int n = (int)(off[g + 1] - off[g]), m = (int)(offp[g + 1] - offp[g]);
+        if (n == 0 || m == 0) continue;
+        double xc = 0.0, yc = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const int64_t t = ord[off[g] + i];
+            ys[i] = y[t * ld];
+            yc += ys[i];
+            if (kind == KIND_TAS) xc += x[t * ld];
+        }
+        xc /= n; /* bcsd.py:222 */
+        yc /= n; /* bcsd.py:223 / 138 */
+        qsort(ys, n, sizeof(double), cmp_double); /* quantile.py:462 np.sort */
+        for (int j = 0; j < m; ++j) xg[j] = xp[(int64_t)ordp[offp[g] + j] * ldp];
+        if (kind == KIND_TAS) {
+            for (int j = 0; j < m; ++j) { /* bcsd.py:247-256 */
+                const int lo = j - 4 < 0 ? 0 : j - 4, hi = j + 5 > m ? m : j + 5;
+                double s = 0.0;
+                for (int i = lo; i < hi; ++i) s += xg[i];
+                const double shift = s / (hi - lo) - xc;
+                u[j] = xg[j] - shift;
+                shiftv[j] = shift;
+            }
+            qm_segment(u, m, ys, n, q, work); /* bcsd.py:260 */
+            for (int j = 0; j < m; ++j) {
+                double r = shiftv[j] + q[j];      /* bcsd.py:263 */
+                if (return_anoms) r = r - yc;     /* bcsd.py:266-267 */
+                out[(int64_t)ordp[offp[g] + j] * ldo] = r;
+            }
+        } else {
+            qm_segment(xg, m, ys, n, q, work); /* bcsd.py:167 */
+            for (int j = 0; j < m; ++j) out[(int64_t)ordp[offp[g] + j] * ldo] = return_anoms ? q[j] / yc : q[j]; /* bcsd.py:170-185 */
+        }
+    }
+    return ST_OK;
+}
+
+static int build_table(const int32_t* gid, int64_t T, int G, int32_t* ord, int64_t* off) {
+    int nmax = 0;
+    memset(off, 0, sizeof(int64_t) * (G + 1));
+    for (int64_t t = 0; t < T; ++t) off[gid[t] + 1]++;
+    for (int g = 0; g < G; ++g) {
+        if (off[g + 1] > nmax) nmax = (int)off[g + 1];
+        off[g + 1] += off[g];
+    }
+    int64_t* cur = (int64_t*)malloc(sizeof(int64_t) * G);
+    memcpy(cur, off, sizeof(int64_t) * G);
+    for (int64_t t = 0; t < T; ++t) ord[cur[gid[t]]++] = (int32_t)t;
+    free(cur);
+    return nmax;
+}
+
+/* Grid driver (core.py:86-96,137-141): loops the per-cell model over the cell axis.
+ * X may be NULL for PR.  Fields [T,C] / [Tp,C], cells contiguous (ld = C).  Returns 0. */
+int sdo_bcsd_fit_predict(int kind, const double* X, const double* y, const double* Xp, const int32_t* gid,
+                         const int32_t* gid_p, int G, int64_t T, int64_t Tp, int64_t C, int return_anoms, double* out,
+                         int32_t* status, int nthreads) {
+    int32_t* ord = (int32_t*)malloc(sizeof(int32_t) * T);
+    int32_t* ordp = (int32_t*)malloc(sizeof(int32_t) * Tp);
+    int64_t* off = (int64_t*)malloc(sizeof(int64_t) * (G + 1));
+    int64_t* offp = (int64_t*)malloc(sizeof(int64_t) * (G + 1));
+    int nmax = build_table(gid, T, G, ord, off);
+    const int nmaxp = build_table(gid_p, Tp, G, ordp, offp);
+    if (nmaxp > nmax) nmax = nmaxp;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+    {
+        double* buf = (double*)malloc(sizeof(double) * 6 * (size_t)nmax);
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t c = 0; c < C; ++c) {
+            const int st = bcsd_cell(kind, X ? X + c : NULL, y + c, C, Xp + c, C, ord, off, ordp, offp, G, return_anoms,
+                                     out + c, C, buf, nmax);
+            status[c] = st;
+            if (st != ST_OK)
+                for (int64_t t = 0; t < Tp; ++t) out[t * C + c] = NAN; /* core.py:119 */
+        }
+        free(buf);
+    }
+    free(ord); free(ordp); free(off); free(offp);
+    return 0;
+}
+
+int sdo_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

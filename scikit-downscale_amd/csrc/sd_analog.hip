@@ -1,0 +1,685 @@
+// GARD analog models (PureAnalog / AnalogRegression), batched over the cell axis.
+//
+// Reference (file:line under skdownscale/pointwise_models/gard.py): AnalogBase.fit 58-87 (KDTree),
+// PureAnalog.predict 273-364, AnalogRegression.predict/_predict_one_step 152-224 (thresh=None).
+// KDTree.query is restated as: k training rows with the smallest reduced distance
+// rdist = sum_f (q_f - x_f)^2 (accumulated f = 0..F-1, no FMA), ascending by (rdist, index).
+//
+// fit   : mask / finite check, cell-major copies Xc[C][F][T], yc[C][T] (tiled LDS transpose); for
+//         F == 1 additionally a per-cell sort of (x, index) -> xs[C][T], xi[C][T], yx[C][T].
+// predict: one persistent workgroup per cell.
+//   F == 1 : the cell's sorted training values live in LDS; each thread answers queries by a binary
+//            search + two-pointer walk that emits neighbours in (rdist, index) order.
+//   F  > 1 : tiled brute force over the training set staged through LDS, per-thread top-k list.
+// Neighbour lists go to an L2-resident scratch [k][threads] per workgroup, then the statistics
+// epilogue (gard.py:303-346) or the per-query OLS (gard.py:194-224) runs on them.
+#include <algorithm>
+
+#include "sd_internal.h"
+
+namespace {
+
+constexpr int kMaxF = 8;
+
+__device__ __forceinline__ bool sd_finite(double v) { return (__double_as_longlong(v) & 0x7ff0000000000000ll) != 0x7ff0000000000000ll; }
+
+// XCD-aware persistent mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of
+// cells and let its workgroups take adjacent cells at the same time, so 8-byte column reads of
+// neighbouring cells merge into full lines in that XCD's L2.
+__device__ __forceinline__ int64_t first_cell(int64_t C, int64_t* step, int64_t* end) {
+    const int nb = gridDim.x, b = blockIdx.x;
+    if (nb % 8 != 0) {
+        *step = nb;
+        *end = C;
+        return b;
+    }
+    const int64_t cx = (C + 7) / 8;
+    const int x = b % 8, j = b / 8;
+    *step = nb / 8;
+    *end = (x + 1) * cx < C ? (x + 1) * cx : C;
+    return x * cx + j;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fit kernels
+// ------------------------------------------------------------------------------------------------
+
+// [R, C] (ld) -> [C][R] transpose through a 32x33 LDS tile, with mask / finite bookkeeping.
+// plane f of X: rows are t*F + f.
+__global__ void __launch_bounds__(256) analog_transpose_kernel(const double* __restrict__ src, int64_t ld, int64_t T, int F,
+                                                               int f, int64_t C, double* __restrict__ dst /* [C][F][T] */,
+                                                               int32_t* status, int set_mask) {
+    __shared__ double tile[32][33];
+    const int64_t t0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+    const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t t = t0 + r, c = c0 + tx;
+        double v = 0.0;
+        if (t < T && c < C) {
+            v = src[(t * F + f) * ld + c];
+            if (set_mask && t == 0 && f == 0 && v != v) atomicOr(&status[c], SDI_MASKED);
+            if (!sd_finite(v)) atomicOr(&status[c], SDI_NONFINITE);
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t c = c0 + r, t = t0 + tx;
+        if (t < T && c < C) dst[(c * F + f) * T + t] = tile[tx][r];
+    }
+}
+
+// F == 1: per-cell sort of (x, index) ascending, lexicographic.  One workgroup per cell, keys and
+// 16-bit indices in LDS, truncated standard-form bitonic network (see sd_bcsd.hip).
+__global__ void __launch_bounds__(1024) analog_sort_kernel(const double* __restrict__ Xc, const double* __restrict__ yc,
+                                                           int64_t T, int64_t C, double* __restrict__ xs,
+                                                           int32_t* __restrict__ xi, double* __restrict__ yx) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* key = reinterpret_cast<double*>(smem_raw);
+    uint16_t* idx = reinterpret_cast<uint16_t*>(key + T);
+    const int n = (int)T;
+    int N = 1;
+    while (N < n) N <<= 1;
+    const int half = N >> 1;
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const double* x = Xc + c * T;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            key[i] = x[i];
+            idx[i] = (uint16_t)i;
+        }
+        __syncthreads();
+        for (int size = 2; size <= N; size <<= 1) {
+            const int hs = size >> 1;
+            for (int stride = hs, first = 1; stride >= 1; stride >>= 1, first = 0) {
+                for (int i = threadIdx.x; i < half; i += blockDim.x) {
+                    int lo, hi;
+                    if (first) {
+                        const int blk = i / hs, off = i - blk * hs;
+                        lo = blk * size + off;
+                        hi = blk * size + size - 1 - off;
+                    } else {
+                        const int blk = i / stride, off = i - blk * stride;
+                        lo = blk * 2 * stride + off;
+                        hi = lo + stride;
+                    }
+                    if (hi < n) {
+                        const double a = key[lo], b = key[hi];
+                        const uint16_t ia = idx[lo], ib = idx[hi];
+                        if (b < a || (b == a && ib < ia)) {
+                            key[lo] = b; key[hi] = a;
+                            idx[lo] = ib; idx[hi] = ia;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        const double* yy = yc + c * T;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            xs[c * T + i] = key[i];
+            xi[c * T + i] = idx[i];
+            if (yx) yx[c * T + i] = yy[idx[i]];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// epilogues (run by the thread that owns the query; lists are [k][nthr] in scratch)
+// ------------------------------------------------------------------------------------------------
+struct PredictArgs {
+    int k, kind, has_thresh;
+    double thresh;
+    const int32_t* sample;  // device [Tq, ld_s] or null
+    int64_t ld_s;
+    double* out;            // [Tq,3,ld_out]
+    int64_t ld_out;
+    int64_t* inds;          // [Tq,k,ld_out] or null
+    double* dist;           // [Tq,k,ld_out] or null
+};
+
+__device__ __forceinline__ double nan_to_num(double v) {
+    if (v != v) return 0.0;
+    if (v == __longlong_as_double(0x7ff0000000000000ll)) return 1.7976931348623157e308;
+    if (v == __longlong_as_double(0xfff0000000000000ll)) return -1.7976931348623157e308;
+    return v;
+}
+
+// PureAnalog statistics for one query (gard.py:301-346).  a[i] = analog values in neighbour order,
+// read through `av(i)`; rd(i) = reduced distance.
+template <typename AV, typename RD>
+__device__ void pure_analog_stats(const PredictArgs& pa, int k, int kind, int sample_i, AV av, RD rd, double* pred,
+                                  double* prob, double* err) {
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    double sum = 0.0, wsum = 0.0, awsum = 0.0;
+    int nexc = 0;
+    bool any_masked = false;
+    for (int i = 0; i < k; ++i) {
+        const double a = av(i);
+        const bool exc = !pa.has_thresh || a > pa.thresh;  // gard.py:307
+        nexc += exc ? 1 : 0;
+        any_masked |= !exc;
+        sum += a;
+        if (kind == SD_ANALOG_WEIGHT) {
+            const double d = sqrt(rd(i));
+            const double w = 1.0 / (d == 0.0 ? 1e-20 : d);  // gard.py:322-323
+            wsum += w;
+            awsum += a * w;
+        }
+    }
+    double p;
+    if (kind == SD_ANALOG_BEST) p = av(0);                               // gard.py:311
+    else if (kind == SD_ANALOG_SAMPLE) p = av(sample_i);                 // gard.py:313-317
+    else if (kind == SD_ANALOG_WEIGHT) p = any_masked ? nan : awsum / wsum;  // gard.py:319-327 (NaN-masked average)
+    else p = any_masked ? nan : sum / (double)k;                         // gard.py:329-333
+    if (pa.has_thresh) {
+        p = nan_to_num(p);  // gard.py:341
+        *prob = (double)nexc / (double)k;  // gard.py:343
+    } else {
+        *prob = 1.0;  // gard.py:346
+    }
+    if (any_masked) {
+        *err = nan;  // gard.py:342 plain .std() of a NaN-masked row
+    } else {
+        const double mean = sum / (double)k;
+        double ss = 0.0;
+        for (int i = 0; i < k; ++i) {
+            const double d = av(i) - mean;
+            ss += d * d;
+        }
+        *err = sqrt(ss / (double)k);  // ddof = 0 (gard.py:342,345)
+    }
+    *pred = p;
+}
+
+// AnalogRegression for one query (gard.py:194-224, thresh=None): centred normal equations.
+template <typename XV, typename YV>
+__device__ void analog_regression(int k, int F, XV xv /* (i,f) */, YV yv /* (i) */, const double* q, double* pred,
+                                  double* err) {
+    double xm[kMaxF], A[kMaxF][kMaxF + 1], coef[kMaxF];
+    double ym = 0.0;
+    for (int f = 0; f < F; ++f) xm[f] = 0.0;
+    for (int i = 0; i < k; ++i) {
+        ym += yv(i);
+        for (int f = 0; f < F; ++f) xm[f] += xv(i, f);
+    }
+    ym /= (double)k;
+    for (int f = 0; f < F; ++f) xm[f] /= (double)k;
+    for (int f = 0; f < F; ++f)
+        for (int g = 0; g <= F; ++g) A[f][g] = 0.0;
+    for (int i = 0; i < k; ++i) {
+        const double dy = yv(i) - ym;
+        for (int f = 0; f < F; ++f) {
+            const double df = xv(i, f) - xm[f];
+            for (int g = f; g < F; ++g) A[f][g] += df * (xv(i, g) - xm[g]);
+            A[f][F] += df * dy;
+        }
+    }
+    for (int f = 0; f < F; ++f)
+        for (int g = 0; g < f; ++g) A[f][g] = A[g][f];
+    // Gaussian elimination with partial pivoting; a vanishing pivot drops that direction (coef 0)
+    double scale = 0.0;
+    for (int f = 0; f < F; ++f) scale = fmax(scale, fabs(A[f][f]));
+    const double tiny = scale * 1e-13;
+    bool dead[kMaxF];
+    for (int f = 0; f < F; ++f) dead[f] = false;
+    for (int col = 0; col < F; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < F; ++r)
+            if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
+        if (fabs(A[piv][col]) <= tiny) {
+            dead[col] = true;
+            continue;
+        }
+        if (piv != col)
+            for (int g = 0; g <= F; ++g) {
+                const double tmp = A[col][g];
+                A[col][g] = A[piv][g];
+                A[piv][g] = tmp;
+            }
+        for (int r = col + 1; r < F; ++r) {
+            const double m = A[r][col] / A[col][col];
+            for (int g = col; g <= F; ++g) A[r][g] -= m * A[col][g];
+        }
+    }
+    for (int col = F - 1; col >= 0; --col) {
+        if (dead[col]) {
+            coef[col] = 0.0;
+            continue;
+        }
+        double s = A[col][F];
+        for (int g = col + 1; g < F; ++g) s -= A[col][g] * coef[g];
+        coef[col] = s / A[col][col];
+    }
+    double icpt = ym;
+    for (int f = 0; f < F; ++f) icpt -= xm[f] * coef[f];
+    double p = icpt;
+    for (int f = 0; f < F; ++f) p += q[f] * coef[f];
+    double ss = 0.0;
+    for (int i = 0; i < k; ++i) {
+        double yh = icpt;
+        for (int f = 0; f < F; ++f) yh += xv(i, f) * coef[f];
+        const double d = yv(i) - yh;
+        ss += d * d;
+    }
+    *pred = p;
+    *err = sqrt(ss / (double)k);  // root_mean_squared_error (gard.py:218-219)
+}
+
+// mode 0 = PureAnalog, 1 = AnalogRegression.  Lists in scratch: sd[i*nthr + tid], si[...].
+__device__ void finish_query(int mode, const PredictArgs& pa, int F, int64_t T, int64_t c, int64_t tq, const double* q,
+                             const double* __restrict__ Xc_cell, const double* __restrict__ yc_cell,
+                             const double* sd, const int32_t* si, int nthr, bool cell_active) {
+    const int tid = threadIdx.x;
+    const int k = pa.k;
+    double pred, prob = 1.0, err;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    if (!cell_active) {
+        pred = prob = err = nan;
+    } else if (mode == 0) {
+        const int s = (pa.kind == SD_ANALOG_SAMPLE && pa.sample) ? pa.sample[tq * pa.ld_s + c] : 0;
+        pure_analog_stats(
+            pa, k, pa.kind, s < 0 ? 0 : (s >= k ? k - 1 : s), [&](int i) { return yc_cell[si[(int64_t)i * nthr + tid]]; },
+            [&](int i) { return sd[(int64_t)i * nthr + tid]; }, &pred, &prob, &err);
+    } else {
+        analog_regression(
+            k, F, [&](int i, int f) { return Xc_cell[(int64_t)f * T + si[(int64_t)i * nthr + tid]]; },
+            [&](int i) { return yc_cell[si[(int64_t)i * nthr + tid]]; }, q, &pred, &err);
+    }
+    pa.out[(tq * 3 + 0) * pa.ld_out + c] = pred;
+    pa.out[(tq * 3 + 1) * pa.ld_out + c] = prob;
+    pa.out[(tq * 3 + 2) * pa.ld_out + c] = err;
+    if (cell_active && pa.inds)
+        for (int i = 0; i < k; ++i) pa.inds[(tq * k + i) * pa.ld_out + c] = si[(int64_t)i * nthr + tid];
+    if (cell_active && pa.dist)
+        for (int i = 0; i < k; ++i) pa.dist[(tq * k + i) * pa.ld_out + c] = sqrt(sd[(int64_t)i * nthr + tid]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// F == 1 predict: sorted training values in LDS, binary search + two-pointer walk
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) analog_f1_predict_kernel(int mode, const double* __restrict__ Xq, int64_t ld,
+                                                                 int64_t Tq, int64_t T, int64_t C,
+                                                                 const double* __restrict__ xs_all,
+                                                                 const int32_t* __restrict__ xi_all,
+                                                                 const double* __restrict__ Xc,
+                                                                 const double* __restrict__ yc,
+                                                                 const int32_t* __restrict__ fit_status, int32_t* status,
+                                                                 double* scratch_d, int32_t* scratch_i, PredictArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* xs = reinterpret_cast<double*>(smem_raw);
+    const int nthr = blockDim.x, tid = threadIdx.x;
+    const int n = (int)T, k = pa.k;
+    double* sd = scratch_d + (int64_t)blockIdx.x * k * nthr;
+    int32_t* si = scratch_i + (int64_t)blockIdx.x * k * nthr;
+    int64_t step, end;
+    for (int64_t c = first_cell(C, &step, &end); c < end; c += step) {
+        const bool active = fit_status[c] == 0;
+        const int32_t* xi = xi_all + c * T;
+        __syncthreads();
+        if (active)
+            for (int i = tid; i < n; i += nthr) xs[i] = xs_all[c * T + i];
+        __syncthreads();
+        for (int64_t tq = tid; tq < Tq; tq += nthr) {
+            const double q = Xq[tq * ld + c];
+            bool ok = active;
+            if (active && !sd_finite(q)) {
+                atomicOr(&status[c], SDI_NONFINITE);
+                ok = false;
+            }
+            if (ok) {
+                // r = first sorted position with x > q ; left part ends at r - 1
+                int lo = 0, hi = n;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (xs[mid] <= q) lo = mid + 1; else hi = mid;
+                }
+                int r = lo;          // next right candidate
+                int le = lo - 1;     // last element of the current left run (-1: exhausted)
+                int rs = 0, cur = 0; // current left run [rs, le], next to take = cur (ascending index order)
+                if (le >= 0) {
+                    rs = le;
+                    while (rs > 0 && xs[rs - 1] == xs[le]) --rs;
+                    cur = rs;
+                }
+                for (int i = 0; i < k; ++i) {
+                    double dl = 0.0, dr = 0.0;
+                    const bool hl = le >= 0, hr = r < n;
+                    if (hl) { const double d = q - xs[le]; dl = d * d; }
+                    if (hr) { const double d = q - xs[r]; dr = d * d; }
+                    bool take_left;
+                    if (hl && hr) take_left = dl < dr || (dl == dr && xi[cur] < xi[r]);
+                    else take_left = hl;
+                    if (take_left) {
+                        sd[(int64_t)i * nthr + tid] = dl;
+                        si[(int64_t)i * nthr + tid] = xi[cur];
+                        if (++cur > le) {
+                            le = rs - 1;
+                            if (le >= 0) {
+                                rs = le;
+                                while (rs > 0 && xs[rs - 1] == xs[le]) --rs;
+                                cur = rs;
+                            }
+                        }
+                    } else {
+                        sd[(int64_t)i * nthr + tid] = dr;
+                        si[(int64_t)i * nthr + tid] = xi[r];
+                        ++r;
+                    }
+                }
+            }
+            finish_query(mode, pa, 1, T, c, tq, &q, Xc + c * T, yc + c * T, sd, si, nthr, ok);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// general F predict: brute force, training rows staged through LDS, per-thread top-k in scratch
+// ------------------------------------------------------------------------------------------------
+constexpr int kBfThreads = 256;
+constexpr int kBfChunk = 1024;
+
+__global__ void __launch_bounds__(kBfThreads) analog_bf_predict_kernel(int mode, const double* __restrict__ Xq, int64_t ld,
+                                                                      int64_t Tq, int64_t T, int F, int64_t C,
+                                                                      const double* __restrict__ Xc,
+                                                                      const double* __restrict__ yc,
+                                                                      const int32_t* __restrict__ fit_status,
+                                                                      int32_t* status, double* scratch_d,
+                                                                      int32_t* scratch_i, PredictArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* xt = reinterpret_cast<double*>(smem_raw);  // [F][kBfChunk]
+    const int nthr = blockDim.x, tid = threadIdx.x;
+    const int k = pa.k;
+    double* sd = scratch_d + (int64_t)blockIdx.x * k * nthr;
+    int32_t* si = scratch_i + (int64_t)blockIdx.x * k * nthr;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    int64_t step, end;
+    for (int64_t c = first_cell(C, &step, &end); c < end; c += step) {
+        const bool active = fit_status[c] == 0;
+        const double* Xcell = Xc + c * F * T;
+        for (int64_t tq0 = 0; tq0 < Tq; tq0 += nthr) {
+            const int64_t tq = tq0 + tid;
+            const bool has_q = tq < Tq;
+            double q[kMaxF];
+            bool ok = active && has_q;
+            for (int f = 0; f < F; ++f) {
+                q[f] = has_q ? Xq[(tq * F + f) * ld + c] : 0.0;
+                if (active && has_q && !sd_finite(q[f])) {
+                    atomicOr(&status[c], SDI_NONFINITE);
+                    ok = false;
+                }
+            }
+            // unsorted top-k with tracked worst element
+            for (int i = 0; i < k; ++i) {
+                sd[(int64_t)i * nthr + tid] = inf;
+                si[(int64_t)i * nthr + tid] = 0x7fffffff;
+            }
+            double worst_d = inf;
+            int worst_i = 0x7fffffff, worst_slot = 0;
+            for (int64_t j0 = 0; j0 < T; j0 += kBfChunk) {
+                const int nj = (int)((T - j0) < kBfChunk ? (T - j0) : kBfChunk);
+                __syncthreads();
+                if (active)
+                    for (int i = tid; i < nj * F; i += nthr) {
+                        const int f = i / nj, j = i - f * nj;
+                        xt[f * kBfChunk + j] = Xcell[(int64_t)f * T + j0 + j];
+                    }
+                __syncthreads();
+                if (!ok) continue;
+                for (int j = 0; j < nj; ++j) {
+                    double d = 0.0;
+                    for (int f = 0; f < F; ++f) {
+                        const double df = q[f] - xt[f * kBfChunk + j];
+                        d += df * df;
+                    }
+                    // ascending j: an equal distance with a larger index never displaces
+                    if (d < worst_d) {
+                        sd[(int64_t)worst_slot * nthr + tid] = d;
+                        si[(int64_t)worst_slot * nthr + tid] = (int32_t)(j0 + j);
+                        worst_d = -1.0;
+                        worst_i = -1;
+                        for (int i = 0; i < k; ++i) {
+                            const double di = sd[(int64_t)i * nthr + tid];
+                            const int ii = si[(int64_t)i * nthr + tid];
+                            if (di > worst_d || (di == worst_d && ii > worst_i)) {
+                                worst_d = di;
+                                worst_i = ii;
+                                worst_slot = i;
+                            }
+                        }
+                    }
+                }
+            }
+            if (ok) {
+                // selection sort into ascending (rdist, index)
+                for (int i = 0; i < k - 1; ++i) {
+                    int best = i;
+                    double bd = sd[(int64_t)i * nthr + tid];
+                    int bi = si[(int64_t)i * nthr + tid];
+                    for (int j = i + 1; j < k; ++j) {
+                        const double dj = sd[(int64_t)j * nthr + tid];
+                        const int ij = si[(int64_t)j * nthr + tid];
+                        if (dj < bd || (dj == bd && ij < bi)) {
+                            best = j;
+                            bd = dj;
+                            bi = ij;
+                        }
+                    }
+                    if (best != i) {
+                        sd[(int64_t)best * nthr + tid] = sd[(int64_t)i * nthr + tid];
+                        si[(int64_t)best * nthr + tid] = si[(int64_t)i * nthr + tid];
+                        sd[(int64_t)i * nthr + tid] = bd;
+                        si[(int64_t)i * nthr + tid] = bi;
+                    }
+                }
+            }
+            if (has_q) finish_query(mode, pa, F, T, c, tq, q, Xcell, yc + c * T, sd, si, nthr, ok);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) analog_status_public_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                                                                   int64_t C, int32_t* __restrict__ outp) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const int32_t bits = a[c] | (b ? b[c] : 0);
+        outp[c] = (bits & SDI_MASKED) ? SD_CELL_MASKED : (bits & SDI_NONFINITE) ? SD_CELL_NONFINITE : SD_CELL_OK;
+    }
+}
+
+int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const double* Xq, int64_t ld, int64_t Tq, int k,
+                   int kind, int has_thresh, double thresh, const int32_t* sample_dev, int64_t ld_s, double* out,
+                   int64_t ld_out, int64_t* inds, double* dist, int32_t* cell_status) {
+    SD_CHECK_ARG(ctx && st && Xq && out, "sd_analog_predict: NULL argument");
+    SD_CHECK_ARG(Tq > 0 && ld >= st->C && ld_out >= st->C, "sd_analog_predict: bad sizes");
+    SD_CHECK_ARG(k >= 1 && k <= st->T, "sd_analog_predict: k=%d must be in [1, T=%lld]", k, (long long)st->T);
+    SD_CHECK_ARG(mode == 1 || (kind >= SD_ANALOG_BEST && kind <= SD_ANALOG_MEAN), "sd_analog_predict: unknown kind %d", kind);
+    SD_CHECK_ARG(!(mode == 0 && kind == SD_ANALOG_SAMPLE) || sample_dev, "sd_analog_predict: sample_analogs needs sample_inds");
+    SD_HIP(hipSetDevice(ctx->device));
+    const int64_t C = st->C, T = st->T;
+    const int F = st->F;
+    PredictArgs pa;
+    pa.k = k;
+    pa.kind = kind;
+    pa.has_thresh = has_thresh;
+    pa.thresh = thresh;
+    pa.sample = sample_dev;
+    pa.ld_s = ld_s;
+    pa.out = out;
+    pa.ld_out = ld_out;
+    pa.inds = inds;
+    pa.dist = dist;
+    sd_scratch status_p, sc_d, sc_i, status_pub;
+    SD_HIP(hipMalloc(&status_p.p, sizeof(int32_t) * C));
+    SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
+    const bool f1 = st->xs != nullptr;
+    const int nthr = f1 ? 1024 : kBfThreads;
+    int nb = ctx->cu_count * (f1 ? 1 : 4);
+    nb = (nb / 8) * 8;
+    if (nb < 8) nb = 8;
+    if ((int64_t)nb > ((C + 7) / 8) * 8) nb = (int)(((C + 7) / 8) * 8);
+    SD_HIP(hipMalloc(&sc_d.p, sizeof(double) * (size_t)nb * k * nthr));
+    SD_HIP(hipMalloc(&sc_i.p, sizeof(int32_t) * (size_t)nb * k * nthr));
+    if (f1) {
+        const size_t lds = sizeof(double) * T;
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_predict_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SD_LAUNCH(ctx, "analog_f1_predict_kernel", analog_f1_predict_kernel, dim3(nb), dim3(nthr), lds, mode, Xq, ld, Tq,
+                  T, C, (const double*)st->xs, (const int32_t*)st->xi, (const double*)st->X, (const double*)st->y,
+                  (const int32_t*)st->status, status_p.as<int32_t>(), sc_d.as<double>(), sc_i.as<int32_t>(), pa);
+    } else {
+        const size_t lds = sizeof(double) * F * kBfChunk;
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_bf_predict_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SD_LAUNCH(ctx, "analog_bf_predict_kernel", analog_bf_predict_kernel, dim3(nb), dim3(nthr), lds, mode, Xq, ld, Tq,
+                  T, F, C, (const double*)st->X, (const double*)st->y, (const int32_t*)st->status,
+                  status_p.as<int32_t>(), sc_d.as<double>(), sc_i.as<int32_t>(), pa);
+    }
+    if (cell_status) {
+        SD_HIP(hipMalloc(&status_pub.p, sizeof(int32_t) * C));
+        SD_LAUNCH(ctx, "analog_status_public_kernel", analog_status_public_kernel, dim3((unsigned)((C + 255) / 256)),
+                  dim3(256), 0, (const int32_t*)st->status, (const int32_t*)status_p.p, C, status_pub.as<int32_t>());
+        SD_HIP(hipMemcpyAsync(cell_status, status_pub.p, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int predict_host(int mode, sd_ctx* ctx, const sd_analog_state* st, const double* Xq, int64_t Tq, int k, int kind,
+                 int has_thresh, double thresh, const int32_t* sample, double* out, int64_t* inds, double* dist,
+                 int32_t* cell_status) {
+    SD_CHECK_ARG(ctx && st && Xq && out, "sd_analog_predict: NULL argument");
+    SD_CHECK_ARG(Tq > 0 && k >= 1, "sd_analog_predict: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    const int64_t C = st->C;
+    sd_scratch dq, dout, dinds, ddist, dsamp;
+    const size_t qb = sizeof(double) * (size_t)Tq * st->F * C, ob = sizeof(double) * (size_t)Tq * 3 * C;
+    SD_HIP(hipMalloc(&dq.p, qb));
+    SD_HIP(hipMalloc(&dout.p, ob));
+    SD_HIP(hipMemcpyAsync(dq.p, Xq, qb, hipMemcpyHostToDevice, ctx->stream));
+    if (inds) SD_HIP(hipMalloc(&dinds.p, sizeof(int64_t) * (size_t)Tq * k * C));
+    if (dist) SD_HIP(hipMalloc(&ddist.p, sizeof(double) * (size_t)Tq * k * C));
+    if (sample) {
+        SD_HIP(hipMalloc(&dsamp.p, sizeof(int32_t) * (size_t)Tq * C));
+        SD_HIP(hipMemcpyAsync(dsamp.p, sample, sizeof(int32_t) * (size_t)Tq * C, hipMemcpyHostToDevice, ctx->stream));
+    }
+    SD_TRY(predict_common(mode, ctx, st, dq.as<double>(), C, Tq, k, kind, has_thresh, thresh, dsamp.as<int32_t>(), C,
+                          dout.as<double>(), C, dinds.as<int64_t>(), ddist.as<double>(), cell_status));
+    SD_HIP(hipMemcpyAsync(out, dout.p, ob, hipMemcpyDeviceToHost, ctx->stream));
+    if (inds) SD_HIP(hipMemcpyAsync(inds, dinds.p, sizeof(int64_t) * (size_t)Tq * k * C, hipMemcpyDeviceToHost, ctx->stream));
+    if (dist) SD_HIP(hipMemcpyAsync(dist, ddist.p, sizeof(double) * (size_t)Tq * k * C, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sd_analog_state_destroy(sd_analog_state* st) {
+    if (!st) return SD_OK;
+    if (st->ctx) {
+        (void)hipSetDevice(st->ctx->device);
+        (void)hipStreamSynchronize(st->ctx->stream);
+    }
+    (void)hipFree(st->X);
+    (void)hipFree(st->y);
+    (void)hipFree(st->status);
+    (void)hipFree(st->xs);
+    (void)hipFree(st->xi);
+    delete st;
+    return SD_OK;
+}
+
+int sd_analog_state_info(const sd_analog_state* st, int64_t* T, int* F, int64_t* C) {
+    SD_CHECK_ARG(st, "state is NULL");
+    if (T) *T = st->T;
+    if (F) *F = st->F;
+    if (C) *C = st->C;
+    return SD_OK;
+}
+
+int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t ld, int64_t T, int F, int64_t C,
+                      sd_analog_state** out) {
+    SD_CHECK_ARG(ctx && X_dev && y_dev && out, "sd_analog_fit: NULL argument");
+    SD_CHECK_ARG(T > 0 && C > 0 && ld >= C, "sd_analog_fit: bad sizes");
+    SD_CHECK_ARG(F >= 1 && F <= kMaxF, "sd_analog_fit: F=%d outside [1,%d]", F, kMaxF);
+    *out = nullptr;
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_analog_state* st = new sd_analog_state();
+    st->ctx = ctx;
+    st->T = T;
+    st->F = F;
+    st->C = C;
+    auto body = [&]() -> int {
+        SD_HIP(hipMalloc((void**)&st->X, sizeof(double) * (size_t)T * F * C));
+        SD_HIP(hipMalloc((void**)&st->y, sizeof(double) * (size_t)T * C));
+        SD_HIP(hipMalloc((void**)&st->status, sizeof(int32_t) * C));
+        SD_HIP(hipMemsetAsync(st->status, 0, sizeof(int32_t) * C, ctx->stream));
+        dim3 grid((unsigned)((C + 31) / 32), (unsigned)((T + 31) / 32));
+        for (int f = 0; f < F; ++f)
+            SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, grid, dim3(256), 0, X_dev, ld, T, F, f, C,
+                      st->X, st->status, 1);
+        SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, grid, dim3(256), 0, y_dev, ld, T, 1, 0, C,
+                  st->y, st->status, 0);
+        const size_t lds = (size_t)T * (sizeof(double) + sizeof(uint16_t));
+        if (F == 1 && T <= 65535 && lds <= ctx->lds_max) {
+            // sorted view for the 1-D fast path; yx is not kept (y gathered by index, L2-resident)
+            SD_HIP(hipMalloc((void**)&st->xs, sizeof(double) * (size_t)T * C));
+            SD_HIP(hipMalloc((void**)&st->xi, sizeof(int32_t) * (size_t)T * C));
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            int nb = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 4);
+            SD_LAUNCH(ctx, "analog_sort_kernel", analog_sort_kernel, dim3(nb), dim3(1024), lds, (const double*)st->X,
+                      (const double*)st->y, T, C, st->xs, st->xi, (double*)nullptr);
+            SD_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        return SD_OK;
+    };
+    int rc = body();
+    if (rc != SD_OK) {
+        sd_analog_state_destroy(st);
+        return rc;
+    }
+    *out = st;
+    return SD_OK;
+}
+
+int sd_analog_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int F, int64_t C, sd_analog_state** out) {
+    SD_CHECK_ARG(ctx && X && y && out, "sd_analog_fit: NULL argument");
+    SD_CHECK_ARG(T > 0 && C > 0 && F >= 1, "sd_analog_fit: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_scratch dX, dy;
+    SD_HIP(hipMalloc(&dX.p, sizeof(double) * (size_t)T * F * C));
+    SD_HIP(hipMalloc(&dy.p, sizeof(double) * (size_t)T * C));
+    SD_HIP(hipMemcpyAsync(dX.p, X, sizeof(double) * (size_t)T * F * C, hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(hipMemcpyAsync(dy.p, y, sizeof(double) * (size_t)T * C, hipMemcpyHostToDevice, ctx->stream));
+    return sd_analog_fit_dev(ctx, dX.as<double>(), dy.as<double>(), C, T, F, C, out);
+}
+
+int sd_analog_predict_dev(sd_ctx* ctx, const sd_analog_state* st, const double* Xq_dev, int64_t ld, int64_t Tq, int k,
+                          int kind, int has_thresh, double thresh, const int32_t* sample_inds_dev, double* out_dev,
+                          int64_t ld_out, int64_t* inds_dev, double* dist_dev, int32_t* cell_status) {
+    return predict_common(0, ctx, st, Xq_dev, ld, Tq, k, kind, has_thresh, thresh, sample_inds_dev, ld, out_dev, ld_out,
+                          inds_dev, dist_dev, cell_status);
+}
+
+int sd_analog_predict(sd_ctx* ctx, const sd_analog_state* st, const double* Xq, int64_t Tq, int k, int kind,
+                      int has_thresh, double thresh, const int32_t* sample_inds, double* out, int64_t* inds,
+                      double* dist, int32_t* cell_status) {
+    return predict_host(0, ctx, st, Xq, Tq, k, kind, has_thresh, thresh, sample_inds, out, inds, dist, cell_status);
+}
+
+int sd_analogreg_predict_dev(sd_ctx* ctx, const sd_analog_state* st, const double* Xq_dev, int64_t ld, int64_t Tq,
+                             int k, double* out_dev, int64_t ld_out, int32_t* cell_status) {
+    return predict_common(1, ctx, st, Xq_dev, ld, Tq, k, SD_ANALOG_MEAN, 0, 0.0, nullptr, ld, out_dev, ld_out, nullptr,
+                          nullptr, cell_status);
+}
+
+int sd_analogreg_predict(sd_ctx* ctx, const sd_analog_state* st, const double* Xq, int64_t Tq, int k, double* out,
+                         int32_t* cell_status) {
+    return predict_host(1, ctx, st, Xq, Tq, k, SD_ANALOG_MEAN, 0, 0.0, nullptr, out, nullptr, nullptr, cell_status);
+}
+
+}  // extern "C"

@@ -1,0 +1,605 @@
+// BCSD empirical quantile mapping, batched over the cell axis.
+//
+// One workgroup = W adjacent cells x one time group (calendar month); one 64-lane wave per cell.
+// A *segment* is the chronologically ordered samples of one (cell, group): n ~ 1240 doubles for a
+// 40-year daily series.  Reference semantics (file:line under skdownscale/pointwise_models):
+//   fit      bcsd.py:197-228 / 115-147 -> quantile.py:81-107 -> 438-463 (np.sort) + 23-43 (Cunnane pp)
+//   predict  bcsd.py:230-269 / 149-185 -> quantile.py:109-147 -> 505-521,488 (self ECDF, np.interp
+//            exact-hit rule = last xp <= x) -> 523-545 (inverse through fitted CDF + 10-point OLS tails)
+//
+// Data layout: fields are [T, ld] with cells contiguous, so a workgroup reads W*8-byte row
+// fragments (coalesced over the cell axis) and transposes them through LDS into cell-major
+// segments; sorted state is stored cell-major [C][T] so each wave streams contiguous segments.
+#include "sd_internal.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kEndpoints = 10;  // quantile.py:426
+constexpr double kAlpha = 0.4;  // quantile.py:423
+constexpr double kBeta = 0.4;   // quantile.py:424
+
+__device__ __forceinline__ bool sd_finite(double v) { return (__double_as_longlong(v) & 0x7ff0000000000000ll) != 0x7ff0000000000000ll; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// Cunnane plotting position of 0-based rank i among n (quantile.py:43, same operation order).
+__device__ __forceinline__ double pp_denom(int n) { return ((double)n + 1.0 - kAlpha) - kBeta; }
+__device__ __forceinline__ double pp_at(int i, double denom) { return ((double)(i + 1) - kAlpha) / denom; }
+
+// ---- wave-cooperative bitonic sort of a[0..n) in LDS, ascending --------------------------------
+// Standard-form network (every comparator puts the min at the lower index) for the next power of
+// two, with comparators that touch an index >= n dropped: the dropped slots behave as +inf
+// padding that never moves, so the truncated network still sorts any n.
+// All waves of the block call this with the same n (block-level barriers).
+__device__ void block_bitonic_sort_rows(double* row, int n, int lane) {
+    int N = 1;
+    while (N < n) N <<= 1;
+    const int half = N >> 1;
+    for (int size = 2; size <= N; size <<= 1) {
+        const int hs = size >> 1;
+        for (int i = lane; i < half; i += kWave) {
+            const int blk = i / hs, off = i - blk * hs;
+            const int lo = blk * size + off, hi = blk * size + size - 1 - off;
+            if (hi < n) {
+                const double a = row[lo], b = row[hi];
+                if (b < a) { row[lo] = b; row[hi] = a; }
+            }
+        }
+        __syncthreads();
+        for (int stride = size >> 2; stride >= 1; stride >>= 1) {
+            for (int i = lane; i < half; i += kWave) {
+                const int blk = i / stride, off = i - blk * stride;
+                const int lo = blk * 2 * stride + off, hi = lo + stride;
+                if (hi < n) {
+                    const double a = row[lo], b = row[hi];
+                    if (b < a) { row[lo] = b; row[hi] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Load the rows of one group for W adjacent cells into a cell-major LDS tile (transpose), flagging
+// non-finite samples.  tile[cell * stride + r]; out-of-range cells are filled with 0.
+template <int W>
+__device__ void load_group_tile(const double* __restrict__ src, int64_t ld, const int32_t* __restrict__ order, int n,
+                                int64_t c0, int64_t C, double* tile, int stride, int32_t* status_bits) {
+    const int total = n * W;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int r = i / W, cl = i - r * W;
+        const int64_t c = c0 + cl;
+        double v = 0.0;
+        if (c < C) {
+            v = src[(int64_t)order[r] * ld + c];
+            if (!sd_finite(v)) atomicOr(&status_bits[c], SDI_NONFINITE);
+        }
+        tile[cl * stride + r] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mask: core.py:35-37  active iff first sample of the first feature is not NaN
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bcsd_mask_kernel(const double* __restrict__ X0, int64_t C, int32_t* status) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const double v = X0[c];
+        status[c] = (v != v) ? SDI_MASKED : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fit: per (cell tile, group): x_climo, y_climo, sorted y segment
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(64 * W) bcsd_fit_kernel(int kind, const double* __restrict__ X,
+                                                          const double* __restrict__ y, int64_t ld,
+                                                          const int32_t* __restrict__ order,
+                                                          const int32_t* __restrict__ goff, int G, int64_t T, int64_t C,
+                                                          int stride, int return_anoms, double* __restrict__ ys,
+                                                          double* __restrict__ x_climo, double* __restrict__ y_climo,
+                                                          int32_t* status) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* tile = reinterpret_cast<double*>(smem_raw);
+    const int g = blockIdx.y;
+    const int64_t c0 = (int64_t)blockIdx.x * W;
+    const int beg = goff[g], n = goff[g + 1] - beg;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int64_t c = c0 + wave;
+    double* row = tile + wave * stride;
+    if (n == 0) return;
+
+    // x climatology (bcsd.py:222) -- X only needs its group mean; PR validates X only.
+    if (X != nullptr) {
+        load_group_tile<W>(X, ld, order + beg, n, c0, C, tile, stride, status);
+        __syncthreads();
+        if (kind == SD_BCSD_TAS) {
+            double s = 0.0;
+            for (int i = lane; i < n; i += kWave) s += row[i];
+            s = wave_sum(s);
+            if (lane == 0 && c < C) x_climo[c * G + g] = s / (double)n;
+        }
+        __syncthreads();
+    }
+    load_group_tile<W>(y, ld, order + beg, n, c0, C, tile, stride, status);
+    __syncthreads();
+    {
+        double s = 0.0;
+        for (int i = lane; i < n; i += kWave) s += row[i];
+        s = wave_sum(s);
+        const double m = s / (double)n;
+        if (lane == 0 && c < C) {
+            y_climo[c * G + g] = m;  // bcsd.py:223 / 138
+            if (kind == SD_BCSD_PR && return_anoms && m <= 0.0) atomicOr(&status[c], SDI_BAD_CLIMO);  // bcsd.py:140-141
+        }
+    }
+    block_bitonic_sort_rows(row, n, lane);  // quantile.py:462 np.sort
+    if (c < C) {
+        double* dst = ys + c * T + beg;
+        for (int i = lane; i < n; i += kWave) dst[i] = row[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// predict
+// ------------------------------------------------------------------------------------------------
+struct TailFit {
+    double slope_lo, icpt_lo, slope_hi, icpt_hi;
+};
+
+// 10-endpoint OLS lines for the CDF tails (quantile.py:532-543; sklearn LinearRegression = centred LS)
+__device__ void ols_line(const double* __restrict__ ysg, int first, int e, double denom, double* slope, double* icpt) {
+    double xm = 0.0, ym = 0.0;
+    for (int i = 0; i < e; ++i) {
+        xm += pp_at(first + i, denom);
+        ym += ysg[first + i];
+    }
+    xm /= (double)e;
+    ym /= (double)e;
+    double sxx = 0.0, sxy = 0.0;
+    for (int i = 0; i < e; ++i) {
+        const double dx = pp_at(first + i, denom) - xm;
+        sxx += dx * dx;
+        sxy += dx * (ysg[first + i] - ym);
+    }
+    const double s = sxx > 0.0 ? sxy / sxx : 0.0;
+    *slope = s;
+    *icpt = ym - s * xm;
+}
+
+// value of the fitted inverse CDF at probability p (np.interp semantics + OLS tails)
+__device__ __forceinline__ double inverse_cdf(double p, const double* __restrict__ ysg, int n, double denom,
+                                              const TailFit& tf) {
+    const double pp0 = pp_at(0, denom), ppl = pp_at(n - 1, denom);
+    if (p < pp0) return p * tf.slope_lo + tf.icpt_lo;
+    if (p > ppl) return p * tf.slope_hi + tf.icpt_hi;
+    // pp is an affine grid: analytic guess, then guard against rounding of the guess
+    int i = (int)floor(p * denom + kAlpha) - 1;
+    i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    while (i + 1 < n && pp_at(i + 1, denom) <= p) ++i;
+    while (i > 0 && pp_at(i, denom) > p) --i;
+    const double pi = pp_at(i, denom);
+    const double yi = ysg[i];
+    if (i == n - 1 || pi == p) return yi;
+    const double slope = (ysg[i + 1] - yi) / (pp_at(i + 1, denom) - pi);
+    return slope * (p - pi) + yi;
+}
+
+// rolling(9, center=True, min_periods=1).mean() at position j of a segment (bcsd.py:247-250)
+__device__ __forceinline__ double rolling9(const double* __restrict__ x, int m, int j) {
+    const int lo = j - 4 < 0 ? 0 : j - 4;
+    const int hi = j + 5 > m ? m : j + 5;
+    double s = 0.0;
+    for (int i = lo; i < hi; ++i) s += x[i];
+    return s / (double)(hi - lo);
+}
+
+template <int W>
+__global__ void __launch_bounds__(64 * W) bcsd_predict_kernel(
+    int kind, const double* __restrict__ Xp, int64_t ld, const int32_t* __restrict__ order_p,
+    const int32_t* __restrict__ goff_p, const int32_t* __restrict__ goff_f, int G, int64_t Tf, int64_t C, int stride,
+    int return_anoms, const double* __restrict__ ys, const double* __restrict__ x_climo,
+    const double* __restrict__ y_climo, const int32_t* __restrict__ fit_status, int32_t* status,
+    double* __restrict__ out, int64_t ld_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* tile_x = reinterpret_cast<double*>(smem_raw);
+    double* tile_s = tile_x + W * stride;
+    double* stage = tile_s + W * stride;  // [W][64]
+    const int g = blockIdx.y;
+    const int64_t c0 = (int64_t)blockIdx.x * W;
+    const int begp = goff_p[g], m = goff_p[g + 1] - begp;
+    const int begf = goff_f[g], n = goff_f[g + 1] - begf;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int64_t c = c0 + wave;
+    const bool cell_ok = c < C;
+    if (m == 0) return;
+    const int32_t* ord = order_p + begp;
+
+    load_group_tile<W>(Xp, ld, ord, m, c0, C, tile_x, stride, status);
+    __syncthreads();
+
+    const double* xr = tile_x + wave * stride;
+    double* sr = tile_s + wave * stride;
+    const double xc = (kind == SD_BCSD_TAS && cell_ok) ? x_climo[c * G + g] : 0.0;
+    const double yc = cell_ok ? y_climo[c * G + g] : 1.0;
+    // u = X - (rolling mean - x_climo)   (bcsd.py:247-256); PR maps raw X (bcsd.py:167)
+    for (int j = lane; j < m; j += kWave) {
+        double u = xr[j];
+        if (kind == SD_BCSD_TAS) u = u - (rolling9(xr, m, j) - xc);
+        sr[j] = u;
+    }
+    __syncthreads();
+    block_bitonic_sort_rows(sr, m, lane);  // self ECDF: np.sort(u)  (quantile.py:462 via 505-521)
+
+    const double* ysg = ys + (cell_ok ? c : 0) * Tf + begf;
+    const double dn = pp_denom(n), dm = pp_denom(m);
+    TailFit tf = {0.0, 0.0, 0.0, 0.0};
+    const bool active = cell_ok && n > 0 && fit_status[c] == 0;
+    if (active && m > n) {  // p can leave [pp_0, pp_{n-1}] only when the predict segment is longer
+        const int e = n < kEndpoints ? n : kEndpoints;
+        ols_line(ysg, 0, e, dn, &tf.slope_lo, &tf.icpt_lo);
+        ols_line(ysg, n - e, e, dn, &tf.slope_hi, &tf.icpt_hi);
+    }
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+
+    for (int k0 = 0; k0 < m; k0 += kWave) {
+        const int j = k0 + lane;
+        double res = nan;
+        if (j < m && active) {
+            const double x = xr[j];
+            double shift = 0.0, u = x;
+            if (kind == SD_BCSD_TAS) {
+                shift = rolling9(xr, m, j) - xc;
+                u = x - shift;
+            }
+            // rank = (number of sorted values <= u) - 1  == np.interp exact-hit index (max rank among ties)
+            int lo = 0, hi = m;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (sr[mid] <= u) lo = mid + 1; else hi = mid;
+            }
+            const int r = lo > 0 ? lo - 1 : 0;
+            const double p = pp_at(r, dm);
+            const double q = inverse_cdf(p, ysg, n, dn, tf);
+            if (kind == SD_BCSD_TAS) {
+                res = shift + q;                      // bcsd.py:263
+                if (return_anoms) res = res - yc;     // bcsd.py:266-267
+            } else {
+                res = return_anoms ? q / yc : q;      // bcsd.py:170-185
+            }
+        }
+        stage[wave * kWave + lane] = res;
+        __syncthreads();
+        {   // transposed, coalesced store of 64 rows x W cells
+            const int rr = threadIdx.x / W, cl = threadIdx.x - rr * W;
+            const int j2 = k0 + rr;
+            if (j2 < m && c0 + cl < C) out[(int64_t)ord[j2] * ld_out + c0 + cl] = stage[cl * kWave + rr];
+        }
+        __syncthreads();
+    }
+}
+
+// fold internal status bits into public codes, in place
+__global__ void __launch_bounds__(256) status_public_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                                                            int64_t C, int32_t* __restrict__ outp) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const int32_t bits = a[c] | (b ? b[c] : 0);
+        int32_t code = SD_CELL_OK;
+        if (bits & SDI_MASKED) code = SD_CELL_MASKED;
+        else if (bits & SDI_NONFINITE) code = SD_CELL_NONFINITE;
+        else if (bits & SDI_BAD_CLIMO) code = SD_CELL_BAD_CLIMO;
+        outp[c] = code;
+    }
+}
+
+// fill rows of cells whose status != 0 with NaN (masked / failed cells; core.py:119)
+__global__ void __launch_bounds__(256) nan_fill_kernel(double* __restrict__ out, int64_t ld, int64_t Tp, int64_t C,
+                                                       const int32_t* __restrict__ st_a, const int32_t* __restrict__ st_b) {
+    const int64_t total = Tp * C;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / C, c = i - t * C;
+        if ((st_a[c] | (st_b ? st_b[c] : 0)) != 0) out[t * ld + c] = nan;
+    }
+}
+
+int pick_tile_width(size_t lds_max, int nmax, int tiles, int* W, int* stride) {
+    // LDS need: tiles * W * stride * 8 (+ W*64*8 staging when tiles == 2)
+    const int st = nmax | 1;  // odd stride: rows of different cells start on different banks
+    for (int w = 8; w >= 1; w >>= 1) {
+        size_t need = (size_t)tiles * w * st * sizeof(double) + (tiles == 2 ? (size_t)w * 64 * sizeof(double) : 0);
+        if (need <= lds_max) {
+            *W = w;
+            *stride = st;
+            return SD_OK;
+        }
+    }
+    return sd_set_error(SD_ERR_UNSUPPORTED, "BCSD segment of %d samples does not fit the %zu-byte LDS", nmax, lds_max);
+}
+
+struct DevGroupTable {
+    sd_scratch order, off;
+    int nmax = 0;
+    std::vector<int64_t> host_off;
+};
+
+int upload_group_table(sd_ctx* ctx, const int32_t* gid, int64_t T, int G, DevGroupTable* d) {
+    sd_group_table gt;
+    SD_TRY(sd_build_group_table(gid, T, G, &gt));
+    SD_CHECK_ARG(T < (int64_t)1 << 31, "T too large");
+    std::vector<int32_t> off32(gt.off.begin(), gt.off.end());
+    SD_HIP(hipMalloc(&d->order.p, sizeof(int32_t) * T));
+    SD_HIP(hipMalloc(&d->off.p, sizeof(int32_t) * (G + 1)));
+    SD_HIP(hipMemcpyAsync(d->order.p, gt.order.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(hipMemcpyAsync(d->off.p, off32.data(), sizeof(int32_t) * (G + 1), hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+    d->nmax = gt.nmax;
+    d->host_off = gt.off;
+    return SD_OK;
+}
+
+template <int W>
+int launch_fit(sd_ctx* ctx, int kind, const double* X, const double* y, int64_t ld, const DevGroupTable& gt, int G,
+               int64_t T, int64_t C, int stride, int return_anoms, sd_bcsd_state* st) {
+    const size_t lds = (size_t)W * stride * sizeof(double);
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fit_kernel<W>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)((C + W - 1) / W), (unsigned)G);
+    SD_LAUNCH(ctx, "bcsd_fit_kernel", bcsd_fit_kernel<W>, grid, dim3(64 * W), lds, kind, X, y, ld,
+              (const int32_t*)gt.order.p, (const int32_t*)gt.off.p, G, T, C, stride, return_anoms, st->ys, st->x_climo,
+              st->y_climo, st->status);
+    return SD_OK;
+}
+
+template <int W>
+int launch_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, int64_t ld, const DevGroupTable& gt,
+                   int stride, int32_t* status_p, double* out, int64_t ld_out) {
+    const size_t lds = (size_t)2 * W * stride * sizeof(double) + (size_t)W * 64 * sizeof(double);
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_predict_kernel<W>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)((st->C + W - 1) / W), (unsigned)st->G);
+    SD_LAUNCH(ctx, "bcsd_predict_kernel", bcsd_predict_kernel<W>, grid, dim3(64 * W), lds, st->kind, Xp, ld,
+              (const int32_t*)gt.order.p, (const int32_t*)gt.off.p, (const int32_t*)st->goff_dev, st->G, st->T, st->C,
+              stride, st->return_anoms, (const double*)st->ys, (const double*)st->x_climo, (const double*)st->y_climo,
+              (const int32_t*)st->status, status_p, out, ld_out);
+    return SD_OK;
+}
+
+int alloc_state(sd_ctx* ctx, int kind, int G, int64_t T, int64_t C, int return_anoms, sd_bcsd_state** out) {
+    sd_bcsd_state* st = new sd_bcsd_state();
+    st->ctx = ctx;
+    st->kind = kind;
+    st->G = G;
+    st->T = T;
+    st->C = C;
+    st->return_anoms = return_anoms;
+    *out = st;
+    SD_HIP(hipMalloc((void**)&st->ys, sizeof(double) * T * C));
+    SD_HIP(hipMalloc((void**)&st->x_climo, sizeof(double) * G * C));
+    SD_HIP(hipMalloc((void**)&st->y_climo, sizeof(double) * G * C));
+    SD_HIP(hipMalloc((void**)&st->status, sizeof(int32_t) * C));
+    SD_HIP(hipMalloc((void**)&st->goff_dev, sizeof(int32_t) * (G + 1)));
+    SD_HIP(hipMemsetAsync(st->x_climo, 0, sizeof(double) * G * C, ctx->stream));
+    SD_HIP(hipMemsetAsync(st->y_climo, 0, sizeof(double) * G * C, ctx->stream));
+    return SD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sd_bcsd_state_destroy(sd_bcsd_state* st) {
+    if (!st) return SD_OK;
+    if (st->ctx) {
+        (void)hipSetDevice(st->ctx->device);
+        (void)hipStreamSynchronize(st->ctx->stream);
+    }
+    (void)hipFree(st->ys);
+    (void)hipFree(st->x_climo);
+    (void)hipFree(st->y_climo);
+    (void)hipFree(st->status);
+    (void)hipFree(st->goff_dev);
+    delete st;
+    return SD_OK;
+}
+
+int sd_bcsd_fit_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_dev, int64_t ld,
+                    const int32_t* group_id, int G, int64_t T, int64_t C, int return_anoms, sd_bcsd_state** out) {
+    SD_CHECK_ARG(ctx && y_dev && group_id && out, "sd_bcsd_fit: NULL argument");
+    SD_CHECK_ARG(kind == SD_BCSD_TAS || kind == SD_BCSD_PR, "sd_bcsd_fit: unknown kind %d", kind);
+    SD_CHECK_ARG(kind == SD_BCSD_PR || X_dev, "sd_bcsd_fit: BcsdTemperature needs X");
+    SD_CHECK_ARG(T > 0 && C > 0 && G > 0 && ld >= C, "sd_bcsd_fit: bad sizes T=%lld C=%lld G=%d ld=%lld", (long long)T,
+                 (long long)C, G, (long long)ld);
+    *out = nullptr;
+    SD_HIP(hipSetDevice(ctx->device));
+    DevGroupTable gt;
+    SD_TRY(upload_group_table(ctx, group_id, T, G, &gt));
+    int W = 0, stride = 0;
+    SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 1, &W, &stride));
+    sd_bcsd_state* st = nullptr;
+    int rc = alloc_state(ctx, kind, G, T, C, return_anoms, &st);
+    if (rc != SD_OK) {
+        sd_bcsd_state_destroy(st);
+        return rc;
+    }
+    st->goff = gt.host_off;
+    st->nmax = gt.nmax;
+    auto body = [&]() -> int {
+        SD_HIP(hipMemcpyAsync(st->goff_dev, gt.off.p, sizeof(int32_t) * (G + 1), hipMemcpyDeviceToDevice, ctx->stream));
+        const double* first = X_dev ? X_dev : y_dev;
+        SD_LAUNCH(ctx, "bcsd_mask_kernel", bcsd_mask_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, first, C,
+                  st->status);
+        switch (W) {
+            case 8: SD_TRY(launch_fit<8>(ctx, kind, X_dev, y_dev, ld, gt, G, T, C, stride, return_anoms, st)); break;
+            case 4: SD_TRY(launch_fit<4>(ctx, kind, X_dev, y_dev, ld, gt, G, T, C, stride, return_anoms, st)); break;
+            case 2: SD_TRY(launch_fit<2>(ctx, kind, X_dev, y_dev, ld, gt, G, T, C, stride, return_anoms, st)); break;
+            default: SD_TRY(launch_fit<1>(ctx, kind, X_dev, y_dev, ld, gt, G, T, C, stride, return_anoms, st)); break;
+        }
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        return SD_OK;
+    };
+    rc = body();
+    if (rc != SD_OK) {
+        sd_bcsd_state_destroy(st);
+        return rc;
+    }
+    *out = st;
+    return SD_OK;
+}
+
+int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_dev, int64_t ld,
+                        const int32_t* group_id_p, int64_t Tp, double* out_dev, int64_t ld_out, int32_t* cell_status) {
+    SD_CHECK_ARG(ctx && st && Xp_dev && group_id_p && out_dev, "sd_bcsd_predict: NULL argument");
+    SD_CHECK_ARG(Tp > 0 && ld >= st->C && ld_out >= st->C, "sd_bcsd_predict: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    const int64_t C = st->C;
+    DevGroupTable gt;
+    SD_TRY(upload_group_table(ctx, group_id_p, Tp, st->G, &gt));
+    int W = 0, stride = 0;
+    SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 2, &W, &stride));
+    sd_scratch status_p, status_pub;
+    SD_HIP(hipMalloc(&status_p.p, sizeof(int32_t) * C));
+    SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
+    switch (W) {
+        case 8: SD_TRY(launch_predict<8>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;
+        case 4: SD_TRY(launch_predict<4>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;
+        case 2: SD_TRY(launch_predict<2>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;
+        default: SD_TRY(launch_predict<1>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;
+    }
+    // cells that are masked / failed in fit or non-finite in predict -> NaN rows
+    SD_LAUNCH(ctx, "nan_fill_kernel", nan_fill_kernel, dim3(2048), dim3(256), 0, out_dev, ld_out, Tp, C,
+              (const int32_t*)st->status, (const int32_t*)status_p.p);
+    if (cell_status) {
+        SD_HIP(hipMalloc(&status_pub.p, sizeof(int32_t) * C));
+        SD_LAUNCH(ctx, "status_public_kernel", status_public_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
+                  (const int32_t*)st->status, (const int32_t*)status_p.p, C, status_pub.as<int32_t>());
+        SD_HIP(hipMemcpyAsync(cell_status, status_pub.p, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_dev, int64_t ld,
+                            const int32_t* group_id, int G, int64_t T, int64_t C, int return_anoms,
+                            const double* Xp_dev, int64_t ld_p, const int32_t* group_id_p, int64_t Tp,
+                            double* out_dev, int64_t ld_out, int32_t* cell_status) {
+    // v1: fit then predict through a transient state (fused kernel lands with the register-resident path)
+    sd_bcsd_state* st = nullptr;
+    SD_TRY(sd_bcsd_fit_dev(ctx, kind, X_dev, y_dev, ld, group_id, G, T, C, return_anoms, &st));
+    int rc = sd_bcsd_predict_dev(ctx, st, Xp_dev, ld_p, group_id_p, Tp, out_dev, ld_out, cell_status);
+    sd_bcsd_state_destroy(st);
+    return rc;
+}
+
+int sd_bcsd_fit(sd_ctx* ctx, int kind, const double* X, const double* y, const int32_t* group_id, int G, int64_t T,
+                int64_t C, int return_anoms, sd_bcsd_state** out) {
+    SD_CHECK_ARG(ctx && y && group_id && out, "sd_bcsd_fit: NULL argument");
+    SD_CHECK_ARG(T > 0 && C > 0, "sd_bcsd_fit: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_scratch dX, dy;
+    const size_t bytes = sizeof(double) * (size_t)T * (size_t)C;
+    if (X) {
+        SD_HIP(hipMalloc(&dX.p, bytes));
+        SD_HIP(hipMemcpyAsync(dX.p, X, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    SD_HIP(hipMalloc(&dy.p, bytes));
+    SD_HIP(hipMemcpyAsync(dy.p, y, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return sd_bcsd_fit_dev(ctx, kind, dX.as<double>(), dy.as<double>(), C, group_id, G, T, C, return_anoms, out);
+}
+
+int sd_bcsd_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, const int32_t* group_id_p, int64_t Tp,
+                    double* out, int32_t* cell_status) {
+    SD_CHECK_ARG(ctx && st && Xp && group_id_p && out, "sd_bcsd_predict: NULL argument");
+    SD_CHECK_ARG(Tp > 0, "sd_bcsd_predict: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_scratch dX, dout;
+    const size_t bytes = sizeof(double) * (size_t)Tp * (size_t)st->C;
+    SD_HIP(hipMalloc(&dX.p, bytes));
+    SD_HIP(hipMalloc(&dout.p, bytes));
+    SD_HIP(hipMemcpyAsync(dX.p, Xp, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_bcsd_predict_dev(ctx, st, dX.as<double>(), st->C, group_id_p, Tp, dout.as<double>(), st->C, cell_status));
+    SD_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_bcsd_state_info(const sd_bcsd_state* st, int* kind, int* G, int64_t* T, int64_t* C, int* return_anoms) {
+    SD_CHECK_ARG(st, "state is NULL");
+    if (kind) *kind = st->kind;
+    if (G) *G = st->G;
+    if (T) *T = st->T;
+    if (C) *C = st->C;
+    if (return_anoms) *return_anoms = st->return_anoms;
+    return SD_OK;
+}
+
+int sd_bcsd_state_status(const sd_bcsd_state* st, int32_t* cell_status) {
+    SD_CHECK_ARG(st && cell_status, "sd_bcsd_state_status: NULL argument");
+    SD_HIP(hipSetDevice(st->ctx->device));
+    SD_HIP(hipMemcpyAsync(cell_status, st->status, sizeof(int32_t) * st->C, hipMemcpyDeviceToHost, st->ctx->stream));
+    SD_HIP(hipStreamSynchronize(st->ctx->stream));
+    for (int64_t c = 0; c < st->C; ++c) cell_status[c] = sd_public_status(cell_status[c]);
+    return SD_OK;
+}
+
+int sd_bcsd_state_export(const sd_bcsd_state* st, double* y_sorted, double* x_climo, double* y_climo,
+                         int32_t* cell_status, int64_t* group_offsets) {
+    SD_CHECK_ARG(st, "state is NULL");
+    sd_ctx* ctx = st->ctx;
+    SD_HIP(hipSetDevice(ctx->device));
+    if (y_sorted) SD_HIP(hipMemcpyAsync(y_sorted, st->ys, sizeof(double) * st->T * st->C, hipMemcpyDeviceToHost, ctx->stream));
+    if (x_climo) SD_HIP(hipMemcpyAsync(x_climo, st->x_climo, sizeof(double) * st->G * st->C, hipMemcpyDeviceToHost, ctx->stream));
+    if (y_climo) SD_HIP(hipMemcpyAsync(y_climo, st->y_climo, sizeof(double) * st->G * st->C, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    if (cell_status) SD_TRY(sd_bcsd_state_status(st, cell_status));
+    if (group_offsets)
+        for (int g = 0; g <= st->G; ++g) group_offsets[g] = st->goff[g];
+    return SD_OK;
+}
+
+int sd_bcsd_state_import(sd_ctx* ctx, int kind, int G, int64_t T, int64_t C, int return_anoms, const double* y_sorted,
+                         const double* x_climo, const double* y_climo, const int32_t* cell_status,
+                         const int64_t* group_offsets, sd_bcsd_state** out) {
+    SD_CHECK_ARG(ctx && y_sorted && y_climo && group_offsets && out, "sd_bcsd_state_import: NULL argument");
+    SD_CHECK_ARG(kind == SD_BCSD_PR || x_climo, "sd_bcsd_state_import: BcsdTemperature needs x_climo");
+    SD_CHECK_ARG(T > 0 && C > 0 && G > 0 && group_offsets[0] == 0 && group_offsets[G] == T, "sd_bcsd_state_import: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_bcsd_state* st = nullptr;
+    int rc = alloc_state(ctx, kind, G, T, C, return_anoms, &st);
+    if (rc != SD_OK) {
+        sd_bcsd_state_destroy(st);
+        return rc;
+    }
+    st->goff.assign(group_offsets, group_offsets + G + 1);
+    std::vector<int32_t> off32(G + 1), bits(C, 0);
+    st->nmax = 0;
+    for (int g = 0; g <= G; ++g) off32[g] = (int32_t)group_offsets[g];
+    for (int g = 0; g < G; ++g) st->nmax = std::max(st->nmax, off32[g + 1] - off32[g]);
+    if (cell_status)
+        for (int64_t c = 0; c < C; ++c) bits[c] = sd_internal_status(cell_status[c]);
+    auto body = [&]() -> int {
+        SD_HIP(hipMemcpyAsync(st->ys, y_sorted, sizeof(double) * T * C, hipMemcpyHostToDevice, ctx->stream));
+        if (x_climo) SD_HIP(hipMemcpyAsync(st->x_climo, x_climo, sizeof(double) * G * C, hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(hipMemcpyAsync(st->y_climo, y_climo, sizeof(double) * G * C, hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(hipMemcpyAsync(st->status, bits.data(), sizeof(int32_t) * C, hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(hipMemcpyAsync(st->goff_dev, off32.data(), sizeof(int32_t) * (G + 1), hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        return SD_OK;
+    };
+    rc = body();
+    if (rc != SD_OK) {
+        sd_bcsd_state_destroy(st);
+        return rc;
+    }
+    *out = st;
+    return SD_OK;
+}
+
+}  // extern "C"

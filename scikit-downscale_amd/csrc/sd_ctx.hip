@@ -1,0 +1,290 @@
+// Context, device memory, timers, per-kernel profile and the on-device synthetic field generator.
+#include <cstring>
+
+#include "sd_internal.h"
+
+static thread_local std::string g_last_error;
+
+int sd_set_error(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+extern "C" {
+
+int sd_version(void) { return SD_VERSION; }
+
+const char* sd_last_error(void) { return g_last_error.c_str(); }
+
+int sd_device_count(int* count) {
+    SD_CHECK_ARG(count, "sd_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return sd_set_error(SD_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return SD_OK;
+}
+
+int sd_ctx_create(int device, sd_ctx** out) {
+    SD_CHECK_ARG(out, "sd_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    SD_HIP(hipGetDeviceCount(&n));
+    SD_CHECK_ARG(device >= 0 && device < n, "sd_ctx_create: device %d out of range (have %d)", device, n);
+    SD_HIP(hipSetDevice(device));
+    sd_ctx* ctx = new sd_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    SD_HIP(hipGetDeviceProperties(&prop, device));
+    ctx->cu_count = prop.multiProcessorCount;
+    ctx->lds_max = prop.sharedMemPerBlock;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) ctx->lds_max = 160 * 1024;  // CDNA4: 160 KiB LDS per CU
+    SD_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    SD_HIP(hipEventCreate(&ctx->t0));
+    SD_HIP(hipEventCreate(&ctx->t1));
+    SD_HIP(hipEventCreate(&ctx->p0));
+    SD_HIP(hipEventCreate(&ctx->p1));
+    *out = ctx;
+    return SD_OK;
+}
+
+int sd_ctx_destroy(sd_ctx* ctx) {
+    if (!ctx) return SD_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipEventDestroy(ctx->t0);
+    (void)hipEventDestroy(ctx->t1);
+    (void)hipEventDestroy(ctx->p0);
+    (void)hipEventDestroy(ctx->p1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SD_OK;
+}
+
+int sd_ctx_synchronize(sd_ctx* ctx) {
+    SD_CHECK_ARG(ctx, "ctx is NULL");
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_ctx_device_info(sd_ctx* ctx, char* name, size_t name_len, int* compute_units, int64_t* hbm_bytes) {
+    SD_CHECK_ARG(ctx, "ctx is NULL");
+    hipDeviceProp_t prop;
+    SD_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len) {
+        snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return SD_OK;
+}
+
+int sd_dev_alloc(sd_ctx* ctx, size_t bytes, void** dptr) {
+    SD_CHECK_ARG(ctx && dptr, "sd_dev_alloc: NULL argument");
+    *dptr = nullptr;
+    SD_HIP(hipSetDevice(ctx->device));
+    if (bytes == 0) bytes = 8;
+    SD_HIP(hipMalloc(dptr, bytes));
+    return SD_OK;
+}
+
+int sd_dev_free(sd_ctx* ctx, void* dptr) {
+    SD_CHECK_ARG(ctx, "ctx is NULL");
+    if (!dptr) return SD_OK;
+    SD_HIP(hipSetDevice(ctx->device));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    SD_HIP(hipFree(dptr));
+    return SD_OK;
+}
+
+int sd_memcpy_h2d(sd_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    SD_CHECK_ARG(ctx && dst && src, "sd_memcpy_h2d: NULL argument");
+    SD_HIP(hipSetDevice(ctx->device));
+    SD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_memcpy_d2h(sd_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    SD_CHECK_ARG(ctx && dst && src, "sd_memcpy_d2h: NULL argument");
+    SD_HIP(hipSetDevice(ctx->device));
+    SD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_memcpy_d2d(sd_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    SD_CHECK_ARG(ctx && dst && src, "sd_memcpy_d2d: NULL argument");
+    SD_HIP(hipSetDevice(ctx->device));
+    SD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SD_OK;
+}
+
+int sd_timer_start(sd_ctx* ctx) {
+    SD_CHECK_ARG(ctx, "ctx is NULL");
+    SD_HIP(hipEventRecord(ctx->t0, ctx->stream));
+    return SD_OK;
+}
+
+int sd_timer_stop(sd_ctx* ctx, float* elapsed_ms) {
+    SD_CHECK_ARG(ctx && elapsed_ms, "sd_timer_stop: NULL argument");
+    SD_HIP(hipEventRecord(ctx->t1, ctx->stream));
+    SD_HIP(hipEventSynchronize(ctx->t1));
+    SD_HIP(hipEventElapsedTime(elapsed_ms, ctx->t0, ctx->t1));
+    return SD_OK;
+}
+
+int sd_prof_enable(sd_ctx* ctx, int on) {
+    SD_CHECK_ARG(ctx, "ctx is NULL");
+    ctx->prof_on = on != 0;
+    return SD_OK;
+}
+
+int sd_prof_reset(sd_ctx* ctx) {
+    SD_CHECK_ARG(ctx, "ctx is NULL");
+    ctx->prof.clear();
+    return SD_OK;
+}
+
+int sd_prof_query(sd_ctx* ctx, const char* kernel_name, double* total_ms, int64_t* launches) {
+    SD_CHECK_ARG(ctx && kernel_name, "sd_prof_query: NULL argument");
+    auto it = ctx->prof.find(kernel_name);
+    if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
+    return SD_OK;
+}
+
+int sd_prof_names(sd_ctx* ctx, char* buf, size_t buf_len) {
+    SD_CHECK_ARG(ctx && buf && buf_len, "sd_prof_names: NULL argument");
+    std::string s;
+    for (auto& kv : ctx->prof) {
+        if (!s.empty()) s += ";";
+        s += kv.first;
+    }
+    snprintf(buf, buf_len, "%s", s.c_str());
+    return SD_OK;
+}
+
+}  // extern "C"
+
+int sd_prof_begin(sd_ctx* ctx) {
+    if (ctx->prof_on) SD_HIP(hipEventRecord(ctx->p0, ctx->stream));
+    return SD_OK;
+}
+
+int sd_prof_end(sd_ctx* ctx, const char* name) {
+    if (ctx->prof_on) {
+        SD_HIP(hipEventRecord(ctx->p1, ctx->stream));
+        SD_HIP(hipEventSynchronize(ctx->p1));
+        float ms = 0.f;
+        SD_HIP(hipEventElapsedTime(&ms, ctx->p0, ctx->p1));
+        auto& e = ctx->prof[name];
+        e.ms += ms;
+        e.launches += 1;
+    }
+    return SD_OK;
+}
+
+int sd_build_group_table(const int32_t* gid, int64_t T, int G, sd_group_table* out) {
+    SD_CHECK_ARG(gid && out && G > 0 && T > 0, "group table: bad arguments");
+    out->off.assign(G + 1, 0);
+    for (int64_t t = 0; t < T; ++t) {
+        SD_CHECK_ARG(gid[t] >= 0 && gid[t] < G, "group_id[%lld] = %d outside [0,%d)", (long long)t, gid[t], G);
+        out->off[gid[t] + 1]++;
+    }
+    out->nmax = 0;
+    for (int g = 0; g < G; ++g) {
+        if (out->off[g + 1] > out->nmax) out->nmax = (int)out->off[g + 1];
+        out->off[g + 1] += out->off[g];
+    }
+    out->order.resize(T);
+    std::vector<int64_t> cur(out->off.begin(), out->off.end() - 1);
+    for (int64_t t = 0; t < T; ++t) out->order[cur[gid[t]]++] = (int32_t)t;
+    return SD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Synthetic fields (bit-identical mirror of skdownscale_amd/synth.py; compiled -ffp-contract=off)
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint64_t sd_splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ double sd_u01(uint64_t h0, uint64_t ctr4, int j) {
+    const uint64_t x = sd_splitmix64(h0 ^ (ctr4 + (uint64_t)j));
+    return (double)(x >> 11) * 0x1.0p-53;
+}
+
+__device__ __forceinline__ double sd_gauss(uint64_t h0, uint64_t ctr4) {
+    const double u0 = sd_u01(h0, ctr4, 0), u1 = sd_u01(h0, ctr4, 1), u2 = sd_u01(h0, ctr4, 2), u3 = sd_u01(h0, ctr4, 3);
+    return (((u0 + u1) + (u2 + u3)) - 2.0) * 1.7320508075688772;
+}
+
+__global__ void __launch_bounds__(256) sd_synth_kernel(double* __restrict__ out, int64_t T, int64_t C, int64_t ld,
+                                                       int64_t c_offset, int64_t c_full, int kind, uint64_t h0,
+                                                       uint64_t h0b, int has2, const double* __restrict__ base,
+                                                       double amp, double cell_scale, double p_dry, double amp2) {
+    const int64_t total = T * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / C;
+        const int64_t cl = i - t * C;
+        const uint64_t c = (uint64_t)(cl + c_offset);
+        const uint64_t ctr4 = ((uint64_t)t * (uint64_t)c_full + c) * 4ull;
+        double v;
+        if (kind == SD_SYNTH_GAUSS) {
+            const double g = sd_gauss(h0, ctr4);
+            const double b = base ? base[t] : 0.0;
+            const double off = cell_scale * (double)(c % 101ull);
+            v = (b + off) + amp * g;
+            if (has2) v = v + amp2 * sd_gauss(h0b, ctr4);
+        } else {
+            const double u0 = sd_u01(h0, ctr4, 0), u1 = sd_u01(h0, ctr4, 1), u2 = sd_u01(h0, ctr4, 2),
+                         u3 = sd_u01(h0, ctr4, 3);
+            const double wet = ((amp * u1) * u2) * u3;
+            v = (u0 < p_dry) ? 0.0 : wet;
+        }
+        out[t * ld + cl] = v;
+    }
+}
+
+static uint64_t host_splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+extern "C" int sd_synth_fill(sd_ctx* ctx, double* out_dev, int64_t T, int64_t C, int64_t ld, int64_t c_offset,
+                             int64_t c_full, int kind, uint64_t seed, uint32_t stream, const double* base_host,
+                             double amp, double cell_scale, double p_dry, int32_t stream2, double amp2) {
+    SD_CHECK_ARG(ctx && out_dev, "sd_synth_fill: NULL argument");
+    SD_CHECK_ARG(T > 0 && C > 0 && ld >= C && c_full >= c_offset + C, "sd_synth_fill: bad sizes");
+    SD_CHECK_ARG(kind == SD_SYNTH_GAUSS || kind == SD_SYNTH_PRECIP, "sd_synth_fill: unknown kind %d", kind);
+    SD_HIP(hipSetDevice(ctx->device));
+    const uint64_t h0 = host_splitmix64(seed ^ host_splitmix64((uint64_t)stream));
+    const uint64_t h0b = stream2 >= 0 ? host_splitmix64(seed ^ host_splitmix64((uint64_t)stream2)) : 0;
+    sd_scratch base;
+    if (base_host) {
+        SD_HIP(hipMalloc(&base.p, sizeof(double) * T));
+        SD_HIP(hipMemcpyAsync(base.p, base_host, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const int64_t total = T * C;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    SD_LAUNCH(ctx, "sd_synth_kernel", sd_synth_kernel, dim3((unsigned)blocks), dim3(256), 0, out_dev, T, C, ld, c_offset,
+              c_full, kind, h0, h0b, stream2 >= 0 ? 1 : 0, base.as<double>(), amp, cell_scale, p_dry, amp2);
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}

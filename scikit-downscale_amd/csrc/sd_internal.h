@@ -1,0 +1,127 @@
+// Internal definitions shared by the HIP translation units (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sd_downscale.h"
+
+// Internal per-cell status is a bitmask (atomicOr from many workgroups, order independent); it is
+// folded into the public SD_CELL_* code with the reference's precedence on the way out.
+#define SDI_MASKED 1
+#define SDI_NONFINITE 2
+#define SDI_BAD_CLIMO 4
+
+struct sd_prof_entry {
+    double ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct sd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;  // sd_timer_*
+    hipEvent_t p0 = nullptr, p1 = nullptr;  // per-kernel profile
+    bool prof_on = false;
+    std::map<std::string, sd_prof_entry> prof;
+    int cu_count = 0;
+    size_t lds_max = 0;
+};
+
+struct sd_bcsd_state {
+    sd_ctx* ctx = nullptr;
+    int kind = 0, G = 0, return_anoms = 1;
+    int64_t T = 0, C = 0;
+    std::vector<int64_t> goff;  // host copy, [G+1]
+    int nmax = 0;
+    double* ys = nullptr;        // device [C][T] cell-major, group segments back to back
+    double* x_climo = nullptr;   // device [C][G]
+    double* y_climo = nullptr;   // device [C][G]
+    int32_t* status = nullptr;   // device [C] internal bitmask
+    int32_t* goff_dev = nullptr; // device [G+1]
+};
+
+struct sd_analog_state {
+    sd_ctx* ctx = nullptr;
+    int64_t T = 0, C = 0;
+    int F = 0;
+    double* X = nullptr;       // device [T,F,C]
+    double* y = nullptr;       // device [T,C]
+    int32_t* status = nullptr; // device [C] internal bitmask
+    // F == 1 fast path: per cell training values sorted ascending + original indices
+    double* xs = nullptr;   // device [C][T]
+    int32_t* xi = nullptr;  // device [C][T]
+};
+
+int sd_set_error(int code, const char* fmt, ...);
+
+#define SD_CHECK_ARG(cond, ...)                                  \
+    do {                                                         \
+        if (!(cond)) return sd_set_error(SD_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define SD_HIP(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return sd_set_error(_e == hipErrorOutOfMemory ? SD_ERR_NOMEM : SD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                                hipGetErrorString(_e), __FILE__, __LINE__);                               \
+    } while (0)
+
+#define SD_TRY(expr)              \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != SD_OK) return _rc; \
+    } while (0)
+
+// Launch helper: optional per-kernel event timing (sd_prof_enable).
+int sd_prof_begin(sd_ctx* ctx);
+int sd_prof_end(sd_ctx* ctx, const char* name);
+
+#define SD_LAUNCH(ctx, name, kernel, grid, block, lds, ...)                                  \
+    do {                                                                                     \
+        SD_TRY(sd_prof_begin(ctx));                                                          \
+        hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);            \
+        SD_HIP(hipGetLastError());                                                           \
+        SD_TRY(sd_prof_end(ctx, name));                                                      \
+    } while (0)
+
+// RAII device scratch buffer (freed asynchronously on the context stream order by hipFree sync).
+struct sd_scratch {
+    void* p = nullptr;
+    ~sd_scratch() {
+        if (p) (void)hipFree(p);
+    }
+    template <typename T>
+    T* as() { return static_cast<T*>(p); }
+};
+
+// Host-side group table: time indices ordered by (group, time) + offsets.
+struct sd_group_table {
+    std::vector<int32_t> order;
+    std::vector<int64_t> off;  // [G+1]
+    int nmax = 0;
+};
+int sd_build_group_table(const int32_t* gid, int64_t T, int G, sd_group_table* out);
+
+// public status from internal bitmask
+static inline int32_t sd_public_status(int32_t bits) {
+    if (bits & SDI_MASKED) return SD_CELL_MASKED;
+    if (bits & SDI_NONFINITE) return SD_CELL_NONFINITE;
+    if (bits & SDI_BAD_CLIMO) return SD_CELL_BAD_CLIMO;
+    return SD_CELL_OK;
+}
+static inline int32_t sd_internal_status(int32_t code) {
+    switch (code) {
+        case SD_CELL_MASKED: return SDI_MASKED;
+        case SD_CELL_NONFINITE: return SDI_NONFINITE;
+        case SD_CELL_BAD_CLIMO: return SDI_BAD_CLIMO;
+        default: return 0;
+    }
+}

@@ -1,0 +1,24 @@
+"""skdownscale_amd -- MI355X-native engine for scikit-downscale's per-grid-cell hot path.
+
+Public names mirror ``skdownscale.pointwise_models`` for the hot path only
+(``skdownscale/pointwise_models/__init__.py:17-36`` of the reference).
+"""
+from .bcsd import BcsdGridModel, BcsdPrecipitation, BcsdTemperature
+from .core import GridArray, GridDataset, PointWiseDownscaler
+from .gard import AnalogGridModel, AnalogRegression, PureAnalog
+from .groupers import DAY_GROUPER, MONTH_GROUPER
+
+__all__ = [
+    "AnalogRegression",
+    "BcsdPrecipitation",
+    "BcsdTemperature",
+    "PointWiseDownscaler",
+    "PureAnalog",
+    "MONTH_GROUPER",
+    "DAY_GROUPER",
+    "GridArray",
+    "GridDataset",
+    "BcsdGridModel",
+    "AnalogGridModel",
+]
+__version__ = "0.1.0"

@@ -1,0 +1,121 @@
+"""ctypes binding of ``libsd_downscale.so`` (the C ABI declared in ``include/sd_downscale.h``).
+
+There is deliberately **no CPU fallback**: if the shared library is missing or a call fails the
+error is raised to the caller.  Build the library with ``python __graft_entry__.py`` (or
+``make -C scikit-downscale_amd``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("SD_DOWNSCALE_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libsd_downscale.so"))
+
+SD_OK = 0
+BCSD_TAS, BCSD_PR = 0, 1
+CELL_OK, CELL_MASKED, CELL_NONFINITE, CELL_BAD_CLIMO = 0, 1, 2, 3
+ANALOG_BEST, ANALOG_SAMPLE, ANALOG_WEIGHT, ANALOG_MEAN = 0, 1, 2, 3
+SYNTH_GAUSS, SYNTH_PRECIP = 0, 1
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+_dbl = C.c_double
+
+# name -> (argtypes); every function returns int unless noted
+SIGNATURES = {
+    "sd_version": [],
+    "sd_device_count": [C.POINTER(_int)],
+    "sd_ctx_create": [_int, C.POINTER(_p)],
+    "sd_ctx_destroy": [_p],
+    "sd_ctx_synchronize": [_p],
+    "sd_ctx_device_info": [_p, C.c_char_p, C.c_size_t, C.POINTER(_int), C.POINTER(_i64)],
+    "sd_dev_alloc": [_p, C.c_size_t, C.POINTER(_p)],
+    "sd_dev_free": [_p, _p],
+    "sd_memcpy_h2d": [_p, _p, _p, C.c_size_t],
+    "sd_memcpy_d2h": [_p, _p, _p, C.c_size_t],
+    "sd_memcpy_d2d": [_p, _p, _p, C.c_size_t],
+    "sd_timer_start": [_p],
+    "sd_timer_stop": [_p, C.POINTER(C.c_float)],
+    "sd_prof_enable": [_p, _int],
+    "sd_prof_reset": [_p],
+    "sd_prof_query": [_p, C.c_char_p, C.POINTER(_dbl), C.POINTER(_i64)],
+    "sd_prof_names": [_p, C.c_char_p, C.c_size_t],
+    "sd_synth_fill": [_p, _p, _i64, _i64, _i64, _i64, _i64, _int, C.c_uint64, C.c_uint32, _p, _dbl, _dbl, _dbl,
+                      C.c_int32, _dbl],
+    "sd_bcsd_fit": [_p, _int, _p, _p, _p, _int, _i64, _i64, _int, C.POINTER(_p)],
+    "sd_bcsd_fit_dev": [_p, _int, _p, _p, _i64, _p, _int, _i64, _i64, _int, C.POINTER(_p)],
+    "sd_bcsd_predict": [_p, _p, _p, _p, _i64, _p, _p],
+    "sd_bcsd_predict_dev": [_p, _p, _p, _i64, _p, _i64, _p, _i64, _p],
+    "sd_bcsd_fit_predict_dev": [_p, _int, _p, _p, _i64, _p, _int, _i64, _i64, _int, _p, _i64, _p, _i64, _p, _i64, _p],
+    "sd_bcsd_state_info": [_p, C.POINTER(_int), C.POINTER(_int), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int)],
+    "sd_bcsd_state_status": [_p, _p],
+    "sd_bcsd_state_export": [_p, _p, _p, _p, _p, _p],
+    "sd_bcsd_state_import": [_p, _int, _int, _i64, _i64, _int, _p, _p, _p, _p, _p, C.POINTER(_p)],
+    "sd_bcsd_state_destroy": [_p],
+    "sd_analog_fit": [_p, _p, _p, _i64, _int, _i64, C.POINTER(_p)],
+    "sd_analog_fit_dev": [_p, _p, _p, _i64, _i64, _int, _i64, C.POINTER(_p)],
+    "sd_analog_predict": [_p, _p, _p, _i64, _int, _int, _int, _dbl, _p, _p, _p, _p, _p],
+    "sd_analog_predict_dev": [_p, _p, _p, _i64, _i64, _int, _int, _int, _dbl, _p, _p, _i64, _p, _p, _p],
+    "sd_analogreg_predict": [_p, _p, _p, _i64, _int, _p, _p],
+    "sd_analogreg_predict_dev": [_p, _p, _p, _i64, _i64, _int, _p, _i64, _p],
+    "sd_analog_state_info": [_p, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_i64)],
+    "sd_analog_state_destroy": [_p],
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    """A call into the HIP engine failed (carries sd_last_error())."""
+
+
+def load():
+    """Load (once) and return the ctypes library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f"HIP engine library not found at {LIB_PATH}: build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _int
+    lib.sd_last_error.argtypes = []
+    lib.sd_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != SD_OK:
+        msg = load().sd_last_error().decode("utf-8", "replace")
+        if rc == 1:
+            raise ValueError(f"sd_downscale: {msg}")
+        if rc == 3:
+            raise NotImplementedError(f"sd_downscale: {msg}")
+        if rc == 4:
+            raise MemoryError(f"sd_downscale: {msg}")
+        raise EngineError(f"sd_downscale (code {rc}): {msg}")
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def as_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)

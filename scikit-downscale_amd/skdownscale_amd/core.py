@@ -1,0 +1,331 @@
+"""Grid driver: ``PointWiseDownscaler`` with the reference's surface (core.py:200-448).
+
+The reference loops over cells in Python (core.py:86-96 and 137-141), deep-copying the estimator
+and building a pandas DataFrame per cell.  Here BCSD / analog estimators are fitted and applied to
+*all cells in one batched launch* of the HIP engine; any other estimator (sklearn Pipelines ...)
+takes the reference's per-cell loop unchanged in behaviour.
+
+Inputs may be ``xarray.DataArray`` / ``xarray.Dataset`` (lazy import; xarray is optional) or the
+tiny labelled-array stand-in ``GridArray`` (numpy values + dims + coords) used where xarray is
+not installed.  Output type follows the input type.
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import pandas as pd
+
+from . import _lib
+from .bcsd import BcsdBase, BcsdGridModel, check_supported
+from .gard import AnalogBase, AnalogGridModel, AnalogRegression, PureAnalog
+
+DEFAULT_FEATURE_DIM = "variable"
+
+
+class GridArray:
+    """Minimal labelled array: ``values`` (ndarray), ``dims`` (tuple of names), ``coords`` (dict)."""
+
+    def __init__(self, values, dims, coords=None, name=None):
+        self.values = np.asarray(values)
+        self.dims = tuple(dims)
+        if self.values.ndim != len(self.dims):
+            raise ValueError(f"values has {self.values.ndim} dims but dims={self.dims}")
+        self.coords = dict(coords or {})
+        self.name = name
+
+    @property
+    def shape(self):
+        return self.values.shape
+
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+    @property
+    def sizes(self):
+        return dict(zip(self.dims, self.values.shape))
+
+    def transpose(self, *dims):
+        if Ellipsis in dims:
+            i = dims.index(Ellipsis)
+            rest = [d for d in self.dims if d not in dims]
+            dims = tuple(dims[:i]) + tuple(rest) + tuple(dims[i + 1:])
+        perm = [self.dims.index(d) for d in dims]
+        return GridArray(self.values.transpose(perm), dims, self.coords, self.name)
+
+    def __repr__(self):
+        return f"<GridArray {self.sizes}>"
+
+
+class GridDataset(dict):
+    """Ordered mapping name -> GridArray (stand-in for xarray.Dataset)."""
+
+
+def _is_xarray(obj):
+    mod = type(obj).__module__
+    return mod.startswith("xarray")
+
+
+def _to_grid(obj, feature_dim):
+    """-> (GridArray, was_xarray)"""
+    if isinstance(obj, GridArray):
+        return obj, False
+    if isinstance(obj, GridDataset):
+        names = list(obj)
+        first = obj[names[0]]
+        vals = np.stack([obj[n].values for n in names], axis=0)
+        coords = dict(first.coords)
+        coords[feature_dim] = np.array(names)
+        return GridArray(vals, (feature_dim,) + first.dims, coords), False
+    if _is_xarray(obj):
+        import xarray as xr
+
+        if isinstance(obj, xr.Dataset):
+            obj = obj.to_array(feature_dim)  # core.py:429-430
+        coords = {k: np.asarray(v.values) for k, v in obj.coords.items() if v.ndim <= 1}
+        return GridArray(np.asarray(obj.values), obj.dims, coords, obj.name), True
+    raise TypeError(f"unsupported input type {type(obj)}; expected xarray.DataArray/Dataset or GridArray")
+
+
+def _from_grid(g, as_xarray):
+    if not as_xarray:
+        return g
+    import xarray as xr
+
+    coords = {k: ((k,), v) if np.ndim(v) == 1 and k in g.dims else v for k, v in g.coords.items()
+              if (k in g.dims) or np.ndim(v) == 0}
+    return xr.DataArray(g.values, dims=g.dims, coords=coords)
+
+
+def _time_index(g, dim):
+    """core.py:52-64: pandas index of the time coordinate (RangeIndex when absent)."""
+    if dim in g.coords:
+        v = g.coords[dim]
+        return v if isinstance(v, pd.Index) else pd.Index(np.asarray(v))
+    return pd.RangeIndex(g.sizes[dim])
+
+
+def _da_to_df(values_2d, index, columns):
+    return pd.DataFrame(values_2d, columns=columns, index=index)
+
+
+class _BatchedModels:
+    """Fitted state of a whole grid held by the engine (replaces the object array of estimators)."""
+
+    def __init__(self, kind, grid_model, mask, spatial_dims, spatial_shape, coords):
+        self.kind = kind  # 'bcsd' | 'analog'
+        self.grid_model = grid_model
+        self.mask = mask
+        self.spatial_dims = spatial_dims
+        self.spatial_shape = spatial_shape
+        self.coords = coords
+
+
+class PointWiseDownscaler:
+    """Pointwise downscaling model wrapper (core.py:200-448).
+
+    Parameters
+    ----------
+    model : estimator implementing fit/predict
+    dim : str, dimension to apply the model along (default ``time``)
+    """
+
+    def __init__(self, model, dim="time"):
+        self._dim = dim
+        self._model = model
+        self._models = None
+        if not hasattr(model, "fit"):
+            raise TypeError(f"Type {type(model)} does not have the fit method required by PointWiseDownscaler")
+
+    # ------------------------------------------------------------------------------------------
+    def _to_feature_x(self, X, feature_dim=DEFAULT_FEATURE_DIM):
+        """core.py:427-440 -> GridArray with dims (time, feature, *spatial)."""
+        g, was_x = _to_grid(X, feature_dim)
+        if feature_dim not in g.dims:
+            vals = np.expand_dims(g.values, 1)
+            dims = (g.dims[0], feature_dim) + g.dims[1:] if g.dims[0] == self._dim else None
+            if dims is None:  # time is not leading: move it first, then insert the feature axis
+                g = g.transpose(self._dim, ...)
+                vals = np.expand_dims(g.values, 1)
+                dims = (self._dim, feature_dim) + g.dims[1:]
+            coords = dict(g.coords)
+            coords[feature_dim] = np.array([f"{feature_dim}_0"])
+            g = GridArray(vals, dims, coords, g.name)
+        return g.transpose(self._dim, feature_dim, ...), was_x
+
+    def _batched(self):
+        m = self._model
+        if isinstance(m, BcsdBase):
+            check_supported(m)
+            return "bcsd"
+        if isinstance(m, (PureAnalog, AnalogRegression)):
+            if isinstance(m, AnalogRegression) and (m.thresh is not None or m.lr_kwargs):
+                raise NotImplementedError("AnalogRegression(thresh=... / lr_kwargs) is not supported on the HIP engine")
+            return "analog"
+        return None
+
+    # ------------------------------------------------------------------------------------------
+    def fit(self, X, *args, **kwargs):
+        """Fit the model for every cell (core.py:225-264)."""
+        kws = {"along_dim": self._dim, "feature_dim": DEFAULT_FEATURE_DIM} | kwargs
+        if len(args) > 1:
+            raise ValueError(f"Expected at most 1 positional argument, got {len(args)}")
+        feature_dim = kws["feature_dim"]
+        Xg, _ = self._to_feature_x(X, feature_dim)
+        yg = None
+        if args:
+            yg, _ = _to_grid(args[0], feature_dim)
+            yg = yg.transpose(self._dim, ...)
+        T, F = Xg.shape[:2]
+        spatial_dims, spatial_shape = Xg.dims[2:], Xg.shape[2:]
+        C = int(np.prod(spatial_shape, dtype=np.int64)) if spatial_shape else 1
+        Xv = np.ascontiguousarray(Xg.values, dtype=np.float64).reshape(T, F, C)
+        mask = ~np.isnan(Xv[0, 0, :])  # core.py:35-37
+        index = _time_index(Xg, self._dim)
+        kind = self._batched()
+        coords = {k: v for k, v in Xg.coords.items() if k in spatial_dims}
+        if kind is None:
+            self._models = self._fit_loop(Xg, yg, Xv, mask, index, feature_dim, spatial_dims, spatial_shape, coords,
+                                          {k: v for k, v in kws.items() if k not in ("along_dim", "feature_dim")})
+            return
+        if yg is None:
+            raise TypeError(f"{type(self._model).__name__}.fit() missing 1 required positional argument: 'y'")
+        yv = np.ascontiguousarray(yg.values, dtype=np.float64).reshape(T, C)
+        m = self._model
+        if kind == "bcsd":
+            if F != 1:
+                msg = "BCSD only supports up to 4 features, found {}" if m._kind == _lib.BCSD_TAS else "BCSD only supports 1 feature, found {}"
+                raise ValueError(msg.format(F))
+            gm = BcsdGridModel(m._kind, m.return_anoms, m.time_grouper)
+            gm.fit(Xv[:, 0, :], yv, index)
+            self._raise_for_status(gm.status_, Xv[:, 0, :], yv)
+        else:
+            gm = AnalogGridModel(m.n_analogs)
+            gm.fit(Xv, yv)
+            gm.status_ = np.where(mask, 0, _lib.CELL_MASKED).astype(np.int32)
+            bad = mask & ~(np.isfinite(Xv).all(axis=(0, 1)) & np.isfinite(yv).all(axis=0))
+            if bad.any():
+                c = int(np.flatnonzero(bad)[0])
+                self._raise_for_status(np.where(bad, _lib.CELL_NONFINITE, 0), Xv[:, :, c:c + 1].reshape(T, -1), yv[:, c:c + 1], cell=c)
+        self._models = _BatchedModels(kind, gm, mask, spatial_dims, spatial_shape, coords)
+
+    @staticmethod
+    def _raise_for_status(status, Xv, yv, cell=None):
+        """Raise like the reference would for the first offending cell (base.py:18-20, bcsd.py:140-141)."""
+        bad = np.flatnonzero((status == _lib.CELL_NONFINITE) | (status == _lib.CELL_BAD_CLIMO))
+        if not len(bad):
+            return
+        c = int(bad[0])
+        if status[c] == _lib.CELL_BAD_CLIMO:
+            raise ValueError("Invalid value in target climatology")
+        xc = Xv if cell is not None else Xv[:, c]
+        yc = yv if cell is not None else yv[:, c]
+        for name, a in (("X", xc), ("y", yc)):
+            if np.isnan(a).any():
+                raise ValueError(f"Input {name} contains NaN.")
+            if not np.isfinite(a).all():
+                raise ValueError(f"Input {name} contains infinity or a value too large for dtype('float64').")
+        raise ValueError("Input contains NaN.")
+
+    def _fit_loop(self, Xg, yg, Xv, mask, index, feature_dim, spatial_dims, spatial_shape, coords, fit_kwargs):
+        """The reference's per-cell loop (core.py:69-97) for estimators the engine does not batch."""
+        T, F, C = Xv.shape
+        columns = list(Xg.coords.get(feature_dim, [f"feature{i}" for i in range(F)]))
+        yv = None if yg is None else np.asarray(yg.values).reshape(T, C)
+        models = np.full(C, None, dtype=object)
+        for c in range(C):
+            mod = copy.deepcopy(self._model)
+            if not mask[c]:
+                continue
+            xdf = _da_to_df(Xv[:, :, c], index, columns)
+            if yv is not None:
+                ydf = _da_to_df(yv[:, c:c + 1], index, [f"{feature_dim}_0"])
+                models[c] = mod.fit(xdf, ydf, **fit_kwargs)
+            else:
+                models[c] = mod.fit(xdf, **fit_kwargs)
+        return _BatchedModels("loop", models, mask, spatial_dims, spatial_shape, coords)
+
+    # ------------------------------------------------------------------------------------------
+    def predict(self, X, **kwargs):
+        """Predict for every fitted cell (core.py:266-338); masked cells stay NaN."""
+        if self._models is None:
+            raise ValueError("PointWiseDownscaler is not fitted: call fit() first")
+        kws = {"along_dim": self._dim, "feature_dim": DEFAULT_FEATURE_DIM} | kwargs
+        feature_dim = kws["feature_dim"]
+        Xg, was_x = self._to_feature_x(X, feature_dim)
+        T, F = Xg.shape[:2]
+        spatial_dims, spatial_shape = Xg.dims[2:], Xg.shape[2:]
+        C = int(np.prod(spatial_shape, dtype=np.int64)) if spatial_shape else 1
+        if tuple(spatial_shape) != tuple(self._models.spatial_shape):
+            raise ValueError(f"spatial shape {spatial_shape} does not match the fitted grid {self._models.spatial_shape}")
+        Xv = np.ascontiguousarray(Xg.values, dtype=np.float64).reshape(T, F, C)
+        index = _time_index(Xg, self._dim)
+        n_outputs = getattr(self._model, "n_outputs", 1)  # core.py:294-298
+        output_names = getattr(self._model, "output_names", None)
+        mdl = self._models
+        coords = {k: v for k, v in Xg.coords.items() if k != feature_dim}
+        if mdl.kind == "bcsd":
+            out, status = mdl.grid_model.predict(Xv[:, 0, :], index)
+            self._raise_for_status(status, Xv[:, 0, :], Xv[:, 0, :])
+            vals = out.reshape((T,) + tuple(spatial_shape)).astype(Xg.dtype, copy=False)
+            res = GridArray(vals, (self._dim,) + spatial_dims, coords)
+        elif mdl.kind == "analog":
+            m = self._model
+            if isinstance(m, AnalogRegression):
+                out, status = mdl.grid_model.predict_regression(Xv)
+            else:
+                out, status = mdl.grid_model.predict_pure(Xv, m.kind, m.thresh)
+            if (status == _lib.CELL_NONFINITE).any():
+                raise ValueError("Input X contains NaN.")
+            vals = out.reshape((T, 3) + tuple(spatial_shape)).astype(Xg.dtype, copy=False)
+            coords[feature_dim] = np.array(output_names)
+            res = GridArray(vals, (self._dim, feature_dim) + spatial_dims, coords)
+        else:
+            res = self._predict_loop(Xg, Xv, index, feature_dim, n_outputs, output_names, spatial_dims, spatial_shape,
+                                     coords, {k: v for k, v in kws.items() if k not in ("along_dim", "feature_dim")})
+        return _from_grid(res, was_x)
+
+    def _predict_loop(self, Xg, Xv, index, feature_dim, n_outputs, output_names, spatial_dims, spatial_shape, coords, kw):
+        """core.py:100-143 for estimators the engine does not batch."""
+        T, F, C = Xv.shape
+        columns = list(Xg.coords.get(feature_dim, [f"feature{i}" for i in range(F)]))
+        shape = (T, C) if n_outputs == 1 else (T, n_outputs, C)
+        y = np.full(shape, np.nan, dtype=Xg.dtype)
+        for c in range(C):
+            model = self._models.grid_model[c]
+            if model is None:
+                continue
+            ydf = model.predict(_da_to_df(Xv[:, :, c], index, columns), **kw)
+            y[..., c] = np.asarray(ydf).squeeze()
+        if n_outputs == 1:
+            return GridArray(y.reshape((T,) + tuple(spatial_shape)), (self._dim,) + spatial_dims, coords)
+        coords[feature_dim] = np.array(output_names)
+        return GridArray(y.reshape((T, n_outputs) + tuple(spatial_shape)), (self._dim, feature_dim) + spatial_dims, coords)
+
+    # ------------------------------------------------------------------------------------------
+    def get_attr(self, key, dtype=np.float64, template_output=None):
+        """Fitted attribute of every cell (core.py:405-425).  Batched BCSD grids serve ``y_climo_`` /
+        ``_x_climo`` as [group, *spatial] fields straight from the engine state."""
+        mdl = self._models
+        if mdl is None:
+            raise ValueError("PointWiseDownscaler is not fitted: call fit() first")
+        if mdl.kind == "bcsd" and key in ("y_climo_", "_x_climo"):
+            e = mdl.grid_model.export()
+            a = e["y_climo" if key == "y_climo_" else "x_climo"].T.astype(dtype)  # [G, C]
+            a = np.where(mdl.mask[None, :], a, np.nan)
+            coords = dict(mdl.coords)
+            coords["group"] = e["keys"]
+            return GridArray(a.reshape((a.shape[0],) + tuple(mdl.spatial_shape)), ("group",) + tuple(mdl.spatial_dims), coords)
+        if mdl.kind == "loop":
+            vals = np.full(len(mdl.grid_model), np.nan, dtype=dtype)
+            for c, m in enumerate(mdl.grid_model):
+                if m is not None:
+                    vals[c] = getattr(m, key)
+            return GridArray(vals.reshape(tuple(mdl.spatial_shape)), tuple(mdl.spatial_dims), dict(mdl.coords))
+        raise NotImplementedError(f"get_attr({key!r}) is not available for engine-batched {mdl.kind} grids")
+
+    def __repr__(self):
+        summary = [f"<skdownscale.{self.__class__.__name__}>", f"  Fit Status: {self._models is not None}",
+                   f"  Model:\n    {self._model}"]
+        return "\n".join(summary)

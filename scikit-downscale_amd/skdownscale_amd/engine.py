@@ -1,0 +1,298 @@
+"""Thin object layer over the C ABI: contexts, HBM-resident fields and fitted-state handles."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, ptr
+
+
+class DeviceArray:
+    """A float64/int field resident in HBM (owned by the library's allocator, not torch)."""
+
+    def __init__(self, ctx, shape, dtype=np.float64, dptr=None, owner=True):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self._owner = owner
+        if dptr is None:
+            p = C.c_void_p()
+            check(ctx.lib.sd_dev_alloc(ctx.handle, self.nbytes, C.byref(p)))
+            dptr = p.value
+        self.ptr = dptr
+        if owner:
+            self._fin = weakref.finalize(self, DeviceArray._free, ctx, dptr)
+
+    @staticmethod
+    def _free(ctx, dptr):
+        if ctx.handle is not None:
+            ctx.lib.sd_dev_free(ctx.handle, C.c_void_p(dptr))
+
+    def free(self):
+        if self._owner and self._fin.alive:
+            self._fin()
+
+    @property
+    def vptr(self):
+        return C.c_void_p(self.ptr)
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(self.ctx.lib.sd_memcpy_d2h(self.ctx.handle, ptr(out), self.vptr, self.nbytes))
+        return out
+
+    def copy_from_host(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.shape == self.shape, (a.shape, self.shape)
+        check(self.ctx.lib.sd_memcpy_h2d(self.ctx.handle, self.vptr, ptr(a), self.nbytes))
+        return self
+
+
+class _State:
+    def __init__(self, ctx, handle, destroy):
+        self.ctx = ctx
+        self.handle = handle
+        self._fin = weakref.finalize(self, _State._destroy, ctx, handle, destroy)
+
+    @staticmethod
+    def _destroy(ctx, handle, destroy):
+        if ctx.handle is not None and handle:
+            destroy(C.c_void_p(handle))
+
+    def close(self):
+        if self._fin.alive:
+            self._fin()
+        self.handle = None
+
+    @property
+    def vptr(self):
+        if self.handle is None:
+            raise ValueError("state has been destroyed")
+        return C.c_void_p(self.handle)
+
+
+class BcsdState(_State):
+    def info(self):
+        kind, G, ra = C.c_int(), C.c_int(), C.c_int()
+        T, Cc = C.c_int64(), C.c_int64()
+        check(self.ctx.lib.sd_bcsd_state_info(self.vptr, C.byref(kind), C.byref(G), C.byref(T), C.byref(Cc), C.byref(ra)))
+        return dict(kind=kind.value, G=G.value, T=T.value, C=Cc.value, return_anoms=bool(ra.value))
+
+    def status(self):
+        st = np.empty(self.info()["C"], dtype=np.int32)
+        check(self.ctx.lib.sd_bcsd_state_status(self.vptr, ptr(st)))
+        return st
+
+    def export(self):
+        i = self.info()
+        ys = np.empty((i["C"], i["T"]))
+        xc = np.empty((i["C"], i["G"]))
+        yc = np.empty((i["C"], i["G"]))
+        st = np.empty(i["C"], dtype=np.int32)
+        off = np.empty(i["G"] + 1, dtype=np.int64)
+        check(self.ctx.lib.sd_bcsd_state_export(self.vptr, ptr(ys), ptr(xc), ptr(yc), ptr(st), ptr(off)))
+        return dict(info=i, y_sorted=ys, x_climo=xc, y_climo=yc, status=st, group_offsets=off)
+
+
+class AnalogState(_State):
+    def info(self):
+        T, Cc, F = C.c_int64(), C.c_int64(), C.c_int()
+        check(self.ctx.lib.sd_analog_state_info(self.vptr, C.byref(T), C.byref(F), C.byref(Cc)))
+        return dict(T=T.value, F=F.value, C=Cc.value)
+
+
+class Context:
+    """One GPU + one HIP stream.  Calls on a context are serialised."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.sd_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.sd_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ---- info / timing ----
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu, mem = C.c_int(), C.c_int64()
+        check(self.lib.sd_ctx_device_info(self.handle, name, 256, C.byref(cu), C.byref(mem)))
+        return dict(name=name.value.decode(), compute_units=cu.value, hbm_bytes=mem.value)
+
+    def synchronize(self):
+        check(self.lib.sd_ctx_synchronize(self.handle))
+
+    def timer_start(self):
+        check(self.lib.sd_timer_start(self.handle))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(self.lib.sd_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    def prof_enable(self, on=True):
+        check(self.lib.sd_prof_enable(self.handle, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self.lib.sd_prof_reset(self.handle))
+
+    def prof(self):
+        buf = C.create_string_buffer(4096)
+        check(self.lib.sd_prof_names(self.handle, buf, 4096))
+        out = {}
+        for name in filter(None, buf.value.decode().split(";")):
+            ms, n = C.c_double(), C.c_int64()
+            check(self.lib.sd_prof_query(self.handle, name.encode(), C.byref(ms), C.byref(n)))
+            out[name] = dict(ms=ms.value, launches=n.value)
+        return out
+
+    # ---- memory ----
+    def empty(self, shape, dtype=np.float64):
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, a, dtype=np.float64):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        return DeviceArray(self, a.shape, dtype).copy_from_host(a)
+
+    def wrap(self, dptr, shape, dtype=np.float64):
+        """View foreign device memory (e.g. a torch tensor's data_ptr()) without owning it."""
+        return DeviceArray(self, shape, dtype, dptr=int(dptr), owner=False)
+
+    def synth_fill(self, out, kind, seed, stream, c_offset=0, c_full=None, base=None, amp=1.0, cell_scale=0.0,
+                   p_dry=0.0, stream2=None, amp2=0.0):
+        T, Cc = out.shape
+        c_full = Cc if c_full is None else c_full
+        b = None if base is None else np.ascontiguousarray(base, dtype=np.float64)
+        check(self.lib.sd_synth_fill(self.handle, out.vptr, T, Cc, Cc, c_offset, c_full, kind, seed, stream, ptr(b), amp,
+                                     cell_scale, p_dry, -1 if stream2 is None else stream2, amp2))
+        return out
+
+    # ---- BCSD ----
+    def bcsd_fit(self, kind, X, y, gid, G, return_anoms=True):
+        """X, y: numpy [T,C] (host path) or DeviceArray [T,C] (resident path); X may be None for PR."""
+        gid = _lib.as_i32(gid)
+        h = C.c_void_p()
+        if isinstance(y, DeviceArray):
+            T, Cc = y.shape
+            check(self.lib.sd_bcsd_fit_dev(self.handle, kind, None if X is None else X.vptr, y.vptr, Cc, ptr(gid), G, T, Cc,
+                                           int(return_anoms), C.byref(h)))
+        else:
+            y = _lib.as_f64(y)
+            X = None if X is None else _lib.as_f64(X)
+            T, Cc = y.shape
+            check(self.lib.sd_bcsd_fit(self.handle, kind, ptr(X), ptr(y), ptr(gid), G, T, Cc, int(return_anoms), C.byref(h)))
+        return BcsdState(self, h.value, self.lib.sd_bcsd_state_destroy)
+
+    def bcsd_predict(self, state, Xp, gid_p, out=None):
+        gid_p = _lib.as_i32(gid_p)
+        Cc = state.info()["C"]
+        status = np.empty(Cc, dtype=np.int32)
+        if isinstance(Xp, DeviceArray):
+            Tp = Xp.shape[0]
+            out = self.empty((Tp, Cc)) if out is None else out
+            check(self.lib.sd_bcsd_predict_dev(self.handle, state.vptr, Xp.vptr, Cc, ptr(gid_p), Tp, out.vptr, Cc, ptr(status)))
+        else:
+            Xp = _lib.as_f64(Xp)
+            Tp = Xp.shape[0]
+            out = np.empty((Tp, Cc))
+            check(self.lib.sd_bcsd_predict(self.handle, state.vptr, ptr(Xp), ptr(gid_p), Tp, ptr(out), ptr(status)))
+        return out, status
+
+    def bcsd_fit_predict(self, kind, X, y, gid, G, Xp, gid_p, return_anoms=True, out=None):
+        """Fused resident path (DeviceArrays only)."""
+        gid, gid_p = _lib.as_i32(gid), _lib.as_i32(gid_p)
+        T, Cc = y.shape
+        Tp = Xp.shape[0]
+        out = self.empty((Tp, Cc)) if out is None else out
+        status = np.empty(Cc, dtype=np.int32)
+        check(self.lib.sd_bcsd_fit_predict_dev(self.handle, kind, None if X is None else X.vptr, y.vptr, Cc, ptr(gid), G, T,
+                                               Cc, int(return_anoms), Xp.vptr, Cc, ptr(gid_p), Tp, out.vptr, Cc, ptr(status)))
+        return out, status
+
+    def bcsd_import(self, exported):
+        i = exported["info"]
+        h = C.c_void_p()
+        check(self.lib.sd_bcsd_state_import(
+            self.handle, i["kind"], i["G"], i["T"], i["C"], int(i["return_anoms"]), ptr(_lib.as_f64(exported["y_sorted"])),
+            ptr(_lib.as_f64(exported["x_climo"])), ptr(_lib.as_f64(exported["y_climo"])), ptr(_lib.as_i32(exported["status"])),
+            ptr(np.ascontiguousarray(exported["group_offsets"], dtype=np.int64)), C.byref(h)))
+        return BcsdState(self, h.value, self.lib.sd_bcsd_state_destroy)
+
+    # ---- analogs ----
+    def analog_fit(self, X, y):
+        """X [T,F,C], y [T,C] numpy or DeviceArray."""
+        h = C.c_void_p()
+        if isinstance(X, DeviceArray):
+            T, F, Cc = X.shape
+            check(self.lib.sd_analog_fit_dev(self.handle, X.vptr, y.vptr, Cc, T, F, Cc, C.byref(h)))
+        else:
+            X, y = _lib.as_f64(X), _lib.as_f64(y)
+            T, F, Cc = X.shape
+            check(self.lib.sd_analog_fit(self.handle, ptr(X), ptr(y), T, F, Cc, C.byref(h)))
+        return AnalogState(self, h.value, self.lib.sd_analog_state_destroy)
+
+    def analog_predict(self, state, Xq, k, kind, thresh=None, sample_inds=None, want_neighbors=False, out=None):
+        info = state.info()
+        Cc = info["C"]
+        status = np.empty(Cc, dtype=np.int32)
+        has_t, tv = (0, 0.0) if thresh is None else (1, float(thresh))
+        if isinstance(Xq, DeviceArray):
+            Tq = Xq.shape[0]
+            out = self.empty((Tq, 3, Cc)) if out is None else out
+            samp = None if sample_inds is None else (sample_inds if isinstance(sample_inds, DeviceArray) else self.to_device(sample_inds, np.int32))
+            inds = self.empty((Tq, k, Cc), np.int64) if want_neighbors else None
+            dist = self.empty((Tq, k, Cc)) if want_neighbors else None
+            check(self.lib.sd_analog_predict_dev(self.handle, state.vptr, Xq.vptr, Cc, Tq, k, kind, has_t, tv,
+                                                 None if samp is None else samp.vptr, out.vptr, Cc,
+                                                 None if inds is None else inds.vptr, None if dist is None else dist.vptr, ptr(status)))
+        else:
+            Xq = _lib.as_f64(Xq)
+            Tq = Xq.shape[0]
+            out = np.empty((Tq, 3, Cc))
+            samp = None if sample_inds is None else _lib.as_i32(sample_inds)
+            inds = np.empty((Tq, k, Cc), dtype=np.int64) if want_neighbors else None
+            dist = np.empty((Tq, k, Cc)) if want_neighbors else None
+            check(self.lib.sd_analog_predict(self.handle, state.vptr, ptr(Xq), Tq, k, kind, has_t, tv, ptr(samp), ptr(out),
+                                             ptr(inds), ptr(dist), ptr(status)))
+        return (out, status, inds, dist) if want_neighbors else (out, status)
+
+    def analogreg_predict(self, state, Xq, k, out=None):
+        Cc = state.info()["C"]
+        status = np.empty(Cc, dtype=np.int32)
+        if isinstance(Xq, DeviceArray):
+            Tq = Xq.shape[0]
+            out = self.empty((Tq, 3, Cc)) if out is None else out
+            check(self.lib.sd_analogreg_predict_dev(self.handle, state.vptr, Xq.vptr, Cc, Tq, k, out.vptr, Cc, ptr(status)))
+        else:
+            Xq = _lib.as_f64(Xq)
+            Tq = Xq.shape[0]
+            out = np.empty((Tq, 3, Cc))
+            check(self.lib.sd_analogreg_predict(self.handle, state.vptr, ptr(Xq), Tq, k, ptr(out), ptr(status)))
+        return out, status
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on ``$SD_DEVICE`` / ``$LOCAL_RANK`` / device 0."""
+    global _default_ctx
+    if _default_ctx is None or _default_ctx.handle is None:
+        dev = int(os.environ.get("SD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _default_ctx = Context(dev)
+    return _default_ctx

@@ -1,0 +1,171 @@
+"""GARD analog estimators with the reference's surface, computed by the HIP engine.
+
+Mirrors ``skdownscale/pointwise_models/gard.py``: ``AnalogBase`` (55-98), ``AnalogRegression``
+(101-224, ``thresh=None`` only) and ``PureAnalog`` (227-364).  The KD-tree of the reference is
+replaced by batched exact nearest-neighbour search in ``csrc/sd_analog.hip`` (neighbours ordered by
+(squared distance, training index); identical to ``KDTree.query`` on tie-free data).
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import pandas as pd
+from sklearn.base import BaseEstimator, RegressorMixin
+from sklearn.exceptions import NotFittedError
+
+from . import _lib
+from .base import _finite_error
+from .engine import default_context
+
+KIND_CODES = {"best_analog": _lib.ANALOG_BEST, "sample_analogs": _lib.ANALOG_SAMPLE,
+              "weight_analogs": _lib.ANALOG_WEIGHT, "mean_analogs": _lib.ANALOG_MEAN}
+OUTPUT_NAMES = ["pred", "exceedance_prob", "prediction_error"]
+
+
+class AnalogGridModel:
+    """Batched analog model over the cell axis: X [T,F,C], y [T,C], Xq [Tq,F,C] (numpy or DeviceArray)."""
+
+    def __init__(self, n_analogs, ctx=None):
+        self.n_analogs = int(n_analogs)
+        self.ctx = ctx or default_context()
+        self.state = None
+
+    def fit(self, X, y):
+        T = X.shape[0]
+        if T >= self.n_analogs:  # gard.py:75-79
+            self.k_ = self.n_analogs
+        else:
+            warnings.warn("length of X is less than n_analogs, setting n_analogs = len(X)")
+            self.k_ = T
+        self.state = self.ctx.analog_fit(X, y)
+        return self
+
+    def predict_pure(self, Xq, kind, thresh=None, sample_inds=None, want_neighbors=False, out=None):
+        if kind == "best_analog" or self.n_analogs == 1:  # gard.py:291-296
+            k, kind = 1, "best_analog"
+        else:
+            k = self.k_
+        if kind not in KIND_CODES:
+            raise ValueError(f"got unexpected kind {kind}")  # gard.py:336
+        Tq, C = Xq.shape[0], Xq.shape[-1]
+        if kind == "sample_analogs" and sample_inds is None:
+            # gard.py:315 draws from the global NumPy RNG; one draw per cell, in cell order
+            sample_inds = np.stack([np.random.randint(low=0, high=k, size=Tq) for _ in range(C)], axis=1)
+        return self.ctx.analog_predict(self.state, Xq, k, KIND_CODES[kind], thresh, sample_inds, want_neighbors, out=out)
+
+    def predict_regression(self, Xq, out=None):
+        return self.ctx.analogreg_predict(self.state, Xq, self.k_, out=out)
+
+
+def _as_2d(X, name="X"):
+    a = np.asarray(X.values if isinstance(X, (pd.DataFrame, pd.Series)) else X, dtype=np.float64)
+    if a.ndim == 1 and name == "X":
+        raise ValueError(
+            f"Expected 2D array, got 1D array instead:\narray={a}.\nReshape your data either using array.reshape(-1, 1) "
+            "if your data has a single feature or array.reshape(1, -1) if it contains a single sample.")
+    if not np.isfinite(a).all():
+        raise _finite_error(name, a)
+    return a
+
+
+class AnalogBase(RegressorMixin, BaseEstimator):
+    _fit_attributes = ["kdtree_", "X_", "y_", "k_"]
+    n_outputs = 3
+    output_names = OUTPUT_NAMES
+
+    def fit(self, X, y):
+        """Fit the analog model (gard.py:58-87): stores the training set on the device."""
+        X2 = _as_2d(X, "X")
+        y1 = _as_2d(y, "y")
+        if y1.ndim == 2:
+            if y1.shape[1] != 1:
+                raise ValueError(f"y should be a 1d array, got an array of shape {y1.shape} instead.")
+            y1 = y1[:, 0]
+        if len(X2) != len(y1):
+            raise ValueError(f"Found input variables with inconsistent numbers of samples: [{len(X2)}, {len(y1)}]")
+        self.n_features_in_ = X2.shape[1]
+        grid = AnalogGridModel(self.n_analogs)
+        grid.fit(X2[:, :, None], y1[:, None])
+        self._grid = grid
+        self.k_ = grid.k_
+        self.X_ = pd.DataFrame(X2, columns=X.columns) if isinstance(X, pd.DataFrame) else X2  # gard.py:49-50,84
+        self.y_ = y1
+        self.kdtree_ = grid.state  # opaque device handle standing in for the KDTree
+        return self
+
+    def _query(self, X):
+        if not hasattr(self, "k_"):
+            raise NotFittedError(
+                f"This {type(self).__name__} instance is not fitted yet. Call 'fit' with appropriate arguments before "
+                "using this estimator.")
+        X2 = _as_2d(X, "X")
+        if X2.shape[1] != self.n_features_in_:
+            raise ValueError(f"X has {X2.shape[1]} features, but {type(self).__name__} is expecting "
+                             f"{self.n_features_in_} features as input.")
+        if not hasattr(self, "_grid"):
+            self._grid = AnalogGridModel(self.n_analogs).fit(np.asarray(self.X_, dtype=np.float64)[:, :, None], self.y_[:, None])
+        return X2
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_grid", None)
+        d.pop("kdtree_", None)
+        return d
+
+    def __sklearn_tags__(self):
+        from dataclasses import replace
+
+        tags = super().__sklearn_tags__()
+        return replace(tags, _skip_test="GARD models output 3 columns pandas dataframe instead of one during predict")
+
+
+class AnalogRegression(AnalogBase):
+    """AnalogRegression (gard.py:101-224).  ``thresh`` (per-step logistic regression) is outside the
+    engine's hot path and raises NotImplementedError."""
+
+    def __init__(self, n_analogs=200, thresh=None, kdtree_kwargs=None, query_kwargs=None, logistic_kwargs=None,
+                 lr_kwargs=None):
+        self.n_analogs = n_analogs
+        self.thresh = thresh
+        self.kdtree_kwargs = kdtree_kwargs
+        self.query_kwargs = query_kwargs
+        self.logistic_kwargs = logistic_kwargs
+        self.lr_kwargs = lr_kwargs
+
+    def predict(self, X):
+        X2 = self._query(X)
+        if self.thresh is not None:
+            raise NotImplementedError("AnalogRegression(thresh=...) (per-step LogisticRegression, gard.py:206-212) is "
+                                      "not supported on the HIP engine")
+        if self.lr_kwargs:
+            raise NotImplementedError("lr_kwargs are not supported on the HIP engine (plain OLS with intercept)")
+        out, _ = self._grid.predict_regression(X2[:, :, None])
+        out = out[:, :, 0]
+        return pd.DataFrame(out, columns=self.output_names) if isinstance(X, pd.DataFrame) else out
+
+
+class PureAnalog(AnalogBase):
+    """PureAnalog (gard.py:227-364)."""
+
+    def __init__(self, n_analogs=200, kind="best_analog", thresh=None, kdtree_kwargs=None, query_kwargs=None):
+        self.n_analogs = n_analogs
+        self.kind = kind
+        self.thresh = thresh
+        self.kdtree_kwargs = kdtree_kwargs
+        self.query_kwargs = query_kwargs
+
+    def predict(self, X):
+        X2 = self._query(X)
+        out, _ = self._grid.predict_pure(X2[:, :, None], self.kind, self.thresh)
+        out = out[:, :, 0]
+        if isinstance(X, pd.DataFrame):
+            return pd.DataFrame(out, columns=self.output_names)  # fresh RangeIndex (gard.py:350-358, note N6)
+        return out
+
+    def kneighbors(self, X):
+        """(dist, inds) of the k_ nearest training rows -- what ``kdtree_.query`` returns (gard.py:299)."""
+        X2 = self._query(X)
+        k = 1 if (self.kind == "best_analog" or self.n_analogs == 1) else self.k_
+        _, _, inds, dist = self._grid.ctx.analog_predict(self._grid.state, X2[:, :, None], k, _lib.ANALOG_MEAN, None, None, True)
+        return dist[:, :, 0], inds[:, :, 0]

@@ -1,0 +1,151 @@
+"""GPU parity: HIP analog path vs golden KDTree queries / PureAnalog / AnalogRegression outputs."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import analog_oracle as ao
+from _cases import analog_inputs, assert_close, load
+
+pytestmark = pytest.mark.gpu
+KINDS = {"best_analog": 0, "sample_analogs": 1, "weight_analogs": 2, "mean_analogs": 3}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from skdownscale_amd.engine import default_context
+
+    return default_context()
+
+
+@pytest.mark.parametrize("F", [1, 3])
+@pytest.mark.parametrize("resident", [False, True])
+def test_neighbors_bit_exact(ctx, F, resident):
+    g = load(f"g5_analog_F{F}")
+    X, y, Xq = analog_inputs(g)
+    st = ctx.analog_fit(ctx.to_device(X), ctx.to_device(y)) if resident else ctx.analog_fit(X, y)
+    for k in (1, 30):
+        if resident:
+            _, _, inds, dist = ctx.analog_predict(st, ctx.to_device(Xq), k, 3, want_neighbors=True)
+            inds, dist = inds.to_host(), dist.to_host()
+        else:
+            _, _, inds, dist = ctx.analog_predict(st, Xq, k, 3, want_neighbors=True)
+        assert np.array_equal(inds, g[f"inds_k{k}"])  # bit-exact analog index selection
+        assert np.array_equal(dist, g[f"dist_k{k}"])
+
+
+@pytest.mark.parametrize("F", [1, 3])
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_pure_analog_golden(ctx, F, kind):
+    g = load(f"g5_analog_F{F}")
+    X, y, Xq = analog_inputs(g)
+    st = ctx.analog_fit(X, y)
+    for k in (1, 30):
+        kk, kc = (1, 0) if (kind == "best_analog" or k == 1) else (k, KINDS[kind])
+        for thresh, tt in ((None, "none"), (0.0, "t0")):
+            tag = f"{kind}_k{k}_{tt}"
+            samp = g["samp_" + tag] if kind == "sample_analogs" else None
+            out, status = ctx.analog_predict(st, Xq, kk, kc, thresh, samp)
+            assert (status == 0).all()
+            assert_close(out, g["out_" + tag], what=tag)
+
+
+@pytest.mark.parametrize("F", [1, 3])
+def test_analog_regression_golden(ctx, F):
+    g = load(f"g5_analog_F{F}")
+    X, y, Xq = analog_inputs(g)
+    st = ctx.analog_fit(X, y)
+    out, _ = ctx.analogreg_predict(st, Xq[: int(g["Tr"])], 30)
+    assert_close(out, g["out_analogreg_k30"], what="analogreg")
+
+
+@pytest.mark.parametrize("F,T,Tq,C,k", [(1, 50, 70, 5, 50), (2, 300, 33, 3, 7), (1, 1000, 1, 1, 200), (4, 129, 257, 2, 30)])
+def test_vs_oracle_edge_sizes_and_ties(ctx, F, T, Tq, C, k):
+    """k == T, single query, heavy exact ties (integer data): index order defined as (rdist, index)."""
+    rng = np.random.default_rng(F * 100 + T)
+    X = rng.integers(-5, 6, (T, F, C)).astype(np.float64)  # ties everywhere
+    y = rng.standard_normal((T, C))
+    Xq = rng.integers(-6, 7, (Tq, F, C)).astype(np.float64)
+    st = ctx.analog_fit(X, y)
+    out, status, inds, dist = ctx.analog_predict(st, Xq, k, 2, None, None, True)
+    for c in range(C):
+        d, i = ao.knn(X[:, :, c], Xq[:, :, c], k)
+        assert np.array_equal(inds[:, :, c], i)
+        assert np.array_equal(dist[:, :, c], d)
+    exp = ao.pointwise_analog(X, y, Xq, k, ao.KIND_WEIGHT)
+    assert_close(out, exp, what="ties weight")
+
+
+def test_masked_cells_and_nan_query(ctx):
+    g = load("g5_analog_F1")
+    X, y, Xq = analog_inputs(g)
+    X = np.concatenate([X, X[:, :, :1]], axis=2)
+    y = np.concatenate([y, y[:, :1]], axis=1)
+    Xq = np.concatenate([Xq, Xq[:, :, :1]], axis=2)
+    X[0, 0, 1] = np.nan
+    st = ctx.analog_fit(X, y)
+    out, status = ctx.analog_predict(st, Xq, 30, 3)
+    assert status.tolist() == [0, 1, 0] and np.isnan(out[:, :, 1]).all()
+    assert_close(out[:, :, [0, 2]], g["out_mean_analogs_k30_none"][:, :, [0, 0]], what="masked neighbours")
+    Xq[5, 0, 2] = np.nan
+    _, status = ctx.analog_predict(st, Xq, 30, 3)
+    assert status.tolist() == [0, 1, 2]
+
+
+# ---- estimator surface (test_pointwise_models.py:144-200) ----
+
+@pytest.fixture(scope="module")
+def sample_X_y():
+    n = 365
+    index = pd.date_range("2019-01-01", periods=n)
+    rng = np.random.default_rng(0)
+    X = pd.DataFrame({"foo": np.sin(np.linspace(-10 * np.pi, 10 * np.pi, n)) * 10, "bar": rng.random(n)}, index=index)
+    return X, X["foo"] + 2
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_gard_analog_models(sample_X_y, kind):
+    from skdownscale_amd import PureAnalog
+
+    X, y = sample_X_y
+    model = PureAnalog(kind=kind, n_analogs=3)
+    model.fit(X, y)
+    out = model.predict(X)
+    assert len(out["pred"]) == len(out["prediction_error"]) == len(out["exceedance_prob"]) == len(X)
+    assert (out["exceedance_prob"] == 1).all()
+    model = PureAnalog(kind=kind, n_analogs=3, thresh=0)
+    model.fit(X, y)
+    prob = model.predict(X)["exceedance_prob"]
+    assert (prob <= 1).all() and (prob >= 0).all()
+    if kind != "sample_analogs":
+        exp, _, _ = ao.pure_analog_predict(X.values, y.values, X.values, 3, ao.KIND_NAMES[kind], 0.0)
+        assert_close(model.predict(X).values, exp, what=f"estimator {kind}")
+
+
+def test_gard_models_default_and_regression(sample_X_y):
+    import warnings
+
+    from skdownscale_amd import AnalogRegression, PointWiseDownscaler, PureAnalog, GridArray
+
+    X, y = sample_X_y
+    assert len(PureAnalog().fit(X, y).predict(X)) == len(X)
+    out = AnalogRegression().fit(X, y).predict(X)
+    assert (out["exceedance_prob"] == 1).all() and list(out.columns) == ["pred", "exceedance_prob", "prediction_error"]
+    exp, _ = ao.analog_regression_predict(X.values, y.values, X.values, 200)
+    assert_close(out.values, exp, rtol=1e-6, what="analogreg estimator")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m = PureAnalog(n_analogs=500, kind="mean_analogs").fit(X, y)
+    assert m.k_ == 365 and any("n_analogs" in str(x.message) for x in w)
+    with pytest.raises(NotImplementedError):
+        AnalogRegression(thresh=3).fit(X, y).predict(X)
+    # grid driver: 3 output columns on a 'variable' axis (core.py:130-135)
+    T = len(X)
+    idx = X.index
+    Xg = GridArray(np.repeat(X.values[:, :, None], 4, axis=2).reshape(T, 2, 2, 2), ("time", "variable", "y", "x"), {"time": idx})
+    yg = GridArray(np.repeat(y.values[:, None], 4, axis=1).reshape(T, 2, 2), ("time", "y", "x"), {"time": idx})
+    pw = PointWiseDownscaler(PureAnalog(n_analogs=10, kind="weight_analogs"))
+    pw.fit(Xg, yg)
+    res = pw.predict(Xg)
+    assert res.dims == ("time", "variable", "y", "x") and res.shape == (T, 3, 2, 2)
+    exp, _, _ = ao.pure_analog_predict(X.values, y.values, X.values, 10, ao.KIND_WEIGHT)
+    assert_close(res.values[:, :, 1, 1], exp, what="pointwise analog")

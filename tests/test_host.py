@@ -1,0 +1,127 @@
+"""CPU: host-side logic that needs no GPU -- grid driver plumbing, groupers, sharding (gloo, world_size 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_groupers_and_group_keys():
+    from skdownscale_amd.groupers import DAY_GROUPER, MONTH_GROUPER, group_keys
+
+    idx = pd.date_range("1980-01-01", periods=14600, freq="D")
+    k = group_keys(idx, MONTH_GROUPER)
+    assert np.array_equal(k, [MONTH_GROUPER(x) for x in idx])
+    sizes = np.bincount(k)[1:]
+    assert sizes.tolist() == [1240, 1130, 1240, 1200, 1240, 1200, 1240, 1240, 1200, 1240, 1200, 1230]
+    assert np.array_equal(group_keys(idx[:40], DAY_GROUPER), idx[:40].day)
+    assert np.array_equal(group_keys(idx[:10], lambda x: x.year), [1980] * 10)
+
+
+def test_estimator_params_and_clone():
+    """The binding sklearn contract of the reference's test suite: check_estimator_cloneable."""
+    from sklearn.base import clone
+
+    from skdownscale_amd import AnalogRegression, BcsdPrecipitation, BcsdTemperature, PureAnalog
+
+    for est in (BcsdTemperature(), BcsdPrecipitation(return_anoms=False), PureAnalog(n_analogs=7, kind="mean_analogs", thresh=0.1),
+                AnalogRegression(n_analogs=12)):
+        c = clone(est)
+        assert type(c) is type(est) and c.get_params() == est.get_params()
+        est.set_params(**est.get_params())
+    assert PureAnalog.n_outputs == 3 and PureAnalog.output_names == ["pred", "exceedance_prob", "prediction_error"]
+    assert set(BcsdTemperature().get_params()) == {"time_grouper", "climate_trend_grouper", "climate_trend", "return_anoms", "qm_kwargs"}
+
+
+def test_pointwise_generic_loop_matches_reference_behaviour():
+    """test_pointwise_runner.py:13-63 with a plain sklearn Pipeline: per-cell loop, sizes preserved, masked cells NaN."""
+    from sklearn.linear_model import LinearRegression
+    from sklearn.pipeline import Pipeline
+    from sklearn.preprocessing import StandardScaler
+
+    from skdownscale_amd import GridArray, GridDataset, PointWiseDownscaler
+
+    rng = np.random.default_rng(0)
+    times = pd.date_range("1979-01-01", freq="1D", periods=100)
+    a = rng.random((100, 2, 3))
+    a[0, 1, 2] = np.nan  # masked cell
+    X = GridDataset(a=GridArray(a, ("time", "y", "x"), {"time": times}))
+    y = GridArray(X["a"].values * 3 + 1, ("time", "y", "x"), {"time": times})
+    model = PointWiseDownscaler(Pipeline([("standardize", StandardScaler()), ("linear regression", LinearRegression())]))
+    a[1:, 1, 2] = 0.5
+    model.fit(X, y)
+    out = model.predict(X)
+    assert isinstance(out, GridArray) and out.sizes == {"time": 100, "y": 2, "x": 3}
+    assert np.isnan(out.values[:, 1, 2]).all()
+    ok = ~np.isnan(out.values)
+    np.testing.assert_allclose(out.values[ok], y.values[ok], rtol=1e-9)
+    with pytest.raises(TypeError):
+        PointWiseDownscaler(object())
+    with pytest.raises(ValueError, match="Expected at most 1 positional argument"):
+        model.fit(X, y, y)
+
+
+def test_unsupported_configurations_raise():
+    from skdownscale_amd import BcsdTemperature
+    from skdownscale_amd.bcsd import check_supported
+
+    check_supported(BcsdTemperature())
+    check_supported(BcsdTemperature(qm_kwargs={"qt_kwargs": {"n_endpoints": 10}}))
+    for bad in (BcsdTemperature(time_grouper="daily_nasa-nex"), BcsdTemperature(qm_kwargs={"detrend": True}),
+                BcsdTemperature(qm_kwargs={"qt_kwargs": {"extrapolate": None}})):
+        with pytest.raises(NotImplementedError):
+            check_supported(bad)
+
+
+def test_cell_partition():
+    from skdownscale_amd.shard import cell_partition
+
+    assert cell_partition(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert cell_partition(1_000_000, 8)[-1] == (875_000, 1_000_000)
+    for C, W in [(1, 4), (7, 8), (100_000, 8)]:
+        b = cell_partition(C, W)
+        assert b[0][0] == 0 and b[-1][1] == C and all(b[i][1] == b[i + 1][0] for i in range(W - 1))
+
+
+WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path[:0] = [os.path.join(r"{root}", "scikit-downscale_amd"), os.path.join(r"{root}", "oracle")]
+import bcsd_oracle as bo
+from skdownscale_amd import synth
+from skdownscale_amd.shard import gather_field, local_cells
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+C, T = 7, 731
+index = synth.daily_calendar(T)
+gid = bo.month_group_id(index)
+s, e = local_cells(C, world, rank)
+cells = np.arange(s, e)
+f = lambda n: synth.tas_field(n, 1, index, cells, C)
+out, _ = bo.pointwise_fit_predict(bo.TAS, f("X_hist"), f("y_obs"), f("X_fut"), gid, gid)   # stand-in for the engine on CPU
+full = gather_field(torch.from_numpy(out), C, dst=0)
+if rank == 0:
+    allc = np.arange(C)
+    g = lambda n: synth.tas_field(n, 1, index, allc, C)
+    exp, _ = bo.pointwise_fit_predict(bo.TAS, g("X_hist"), g("y_obs"), g("X_fut"), gid, gid)
+    assert full.shape == (T, C) and np.array_equal(full.numpy(), exp), "sharded result differs from the single-rank result"
+    print("GATHER_OK")
+else:
+    assert full is None
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_gather_world_size_2_gloo(tmp_path):
+    """N > 1 path on CPU: cells sharded over 2 ranks, ragged blocks, gather to root == unsharded result."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29617", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "GATHER_OK" in res.stdout
