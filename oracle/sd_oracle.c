@@ -190,18 +190,39 @@ int sdo_bcsd_fit_predict(int kind, const double* X, const double* y, const doubl
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
+    /* Cells are processed in blocks of 8 (one 64-byte line of the [T, C] field): the block's columns are
+     * gathered into contiguous per-cell series first, so the strided field is touched once per line. */
+    const int64_t nblk = (C + 7) / 8;
 #pragma omp parallel
     {
         double* buf = (double*)malloc(sizeof(double) * 6 * (size_t)nmax);
-#pragma omp for schedule(dynamic, 4)
-        for (int64_t c = 0; c < C; ++c) {
-            const int st = bcsd_cell(kind, X ? X + c : NULL, y + c, C, Xp + c, C, ord, off, ordp, offp, G, return_anoms,
-                                     out + c, C, buf, nmax);
-            status[c] = st;
-            if (st != ST_OK)
-                for (int64_t t = 0; t < Tp; ++t) out[t * C + c] = NAN; /* core.py:119 */
+        double* cx = (double*)malloc(sizeof(double) * 8 * (size_t)(2 * T + 2 * Tp));
+        double* cy = cx + 8 * T;
+        double* cp = cy + 8 * T;
+        double* co = cp + 8 * Tp;
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t b = 0; b < nblk; ++b) {
+            const int64_t c0 = b * 8;
+            const int w = (int)((C - c0) < 8 ? (C - c0) : 8);
+            for (int64_t t = 0; t < T; ++t)
+                for (int k = 0; k < w; ++k) {
+                    if (X) cx[k * T + t] = X[t * C + c0 + k];
+                    cy[k * T + t] = y[t * C + c0 + k];
+                }
+            for (int64_t t = 0; t < Tp; ++t)
+                for (int k = 0; k < w; ++k) cp[k * Tp + t] = Xp[t * C + c0 + k];
+            for (int k = 0; k < w; ++k) {
+                const int st = bcsd_cell(kind, X ? cx + k * T : NULL, cy + k * T, 1, cp + k * Tp, 1, ord, off, ordp, offp, G,
+                                         return_anoms, co + k * Tp, 1, buf, nmax);
+                status[c0 + k] = st;
+                if (st != ST_OK)
+                    for (int64_t t = 0; t < Tp; ++t) co[k * Tp + t] = NAN; /* core.py:119 */
+            }
+            for (int64_t t = 0; t < Tp; ++t)
+                for (int k = 0; k < w; ++k) out[t * C + c0 + k] = co[k * Tp + t];
         }
         free(buf);
+        free(cx);
     }
     free(ord); free(ordp); free(off); free(offp);
     return 0;

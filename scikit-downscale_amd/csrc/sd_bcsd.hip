@@ -10,6 +10,10 @@
 // Data layout: fields are [T, ld] with cells contiguous, so a workgroup reads W*8-byte row
 // fragments (coalesced over the cell axis) and transposes them through LDS into cell-major
 // segments; sorted state is stored cell-major [C][T] so each wave streams contiguous segments.
+#include <cmath>
+#include <cstdlib>
+
+#include "sd_bcsd_rs.h"
 #include "sd_internal.h"
 
 namespace {
@@ -299,15 +303,16 @@ __global__ void __launch_bounds__(256) status_public_kernel(const int32_t* __res
     }
 }
 
-// fill rows of cells whose status != 0 with NaN (masked / failed cells; core.py:119)
+// fill the columns of cells whose status != 0 with NaN (masked / failed cells; core.py:119).
+// One workgroup per 32 cells; an all-OK strip costs one status read.
 __global__ void __launch_bounds__(256) nan_fill_kernel(double* __restrict__ out, int64_t ld, int64_t Tp, int64_t C,
                                                        const int32_t* __restrict__ st_a, const int32_t* __restrict__ st_b) {
-    const int64_t total = Tp * C;
+    const int64_t c = (int64_t)blockIdx.x * 32 + (threadIdx.x & 31);
+    const bool bad = c < C && (st_a[c] | (st_b ? st_b[c] : 0)) != 0;
+    if (!__syncthreads_or(bad)) return;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t t = i / C, c = i - t * C;
-        if ((st_a[c] | (st_b ? st_b[c] : 0)) != 0) out[t * ld + c] = nan;
-    }
+    if (bad)
+        for (int64_t t = threadIdx.x >> 5; t < Tp; t += 8) out[t * ld + c] = nan;
 }
 
 int pick_tile_width(size_t lds_max, int nmax, int tiles, int* W, int* stride) {
@@ -342,6 +347,58 @@ int upload_group_table(sd_ctx* ctx, const int32_t* gid, int64_t T, int G, DevGro
     SD_HIP(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
     d->nmax = gt.nmax;
     d->host_off = gt.off;
+    return SD_OK;
+}
+
+
+int rs_ablate() {
+    const char* e = getenv("SD_RS_ABLATE");
+    return e ? atoi(e) : 0;
+}
+
+bool use_rs_path(int nmax) {
+    const char* e = getenv("SD_BCSD_PATH");  // "v1" forces the generic LDS-bitonic kernels (A/B testing)
+    if (e && e[0] == 'v' && e[1] == '1') return false;
+    return sd_bcsd_rs_supported(nmax);
+}
+
+double h_pp_denom(int n) { return ((double)n + 1.0 - kAlpha) - kBeta; }
+double h_pp_at(int i, double denom) { return ((double)(i + 1) - kAlpha) / denom; }
+
+// Inverse-CDF lookup tables (quantile.py:523-545): for every (group, rank r of the predict segment)
+// the fitted-CDF bracket index and interpolation weight; identical for all cells.
+//   idx >= 0 : value = ys[idx] + w * (ys[idx+1] - ys[idx])   (w == 0: exact hit / last point)
+//   idx = -1 / -2 : lower / upper OLS tail evaluated at p = val ; idx = -3 : group absent in fit
+struct QTables {
+    sd_scratch idx, val;
+};
+int build_q_tables(sd_ctx* ctx, const std::vector<int64_t>& off_f, const std::vector<int64_t>& off_p, int G, QTables* q) {
+    const int64_t Tp = off_p[G];
+    std::vector<int32_t> qi(Tp);
+    std::vector<double> qv(Tp);
+    for (int g = 0; g < G; ++g) {
+        const int n = (int)(off_f[g + 1] - off_f[g]), m = (int)(off_p[g + 1] - off_p[g]);
+        const double dn = h_pp_denom(n), dm = h_pp_denom(m);
+        for (int r = 0; r < m; ++r) {
+            const int64_t t = off_p[g] + r;
+            const double p = h_pp_at(r, dm);
+            if (n == 0) { qi[t] = -3; qv[t] = 0.0; continue; }
+            if (p < h_pp_at(0, dn)) { qi[t] = -1; qv[t] = p; continue; }
+            if (p > h_pp_at(n - 1, dn)) { qi[t] = -2; qv[t] = p; continue; }
+            int i = (int)std::floor(p * dn + kAlpha) - 1;
+            i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+            while (i + 1 < n && h_pp_at(i + 1, dn) <= p) ++i;
+            while (i > 0 && h_pp_at(i, dn) > p) --i;
+            const double pi = h_pp_at(i, dn);
+            qi[t] = i;
+            qv[t] = (i == n - 1 || pi == p) ? 0.0 : (p - pi) / (h_pp_at(i + 1, dn) - pi);
+        }
+    }
+    SD_HIP(hipMalloc(&q->idx.p, sizeof(int32_t) * Tp));
+    SD_HIP(hipMalloc(&q->val.p, sizeof(double) * Tp));
+    SD_HIP(hipMemcpyAsync(q->idx.p, qi.data(), sizeof(int32_t) * Tp, hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(hipMemcpyAsync(q->val.p, qv.data(), sizeof(double) * Tp, hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
     return SD_OK;
 }
 
@@ -422,7 +479,8 @@ int sd_bcsd_fit_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_
     DevGroupTable gt;
     SD_TRY(upload_group_table(ctx, group_id, T, G, &gt));
     int W = 0, stride = 0;
-    SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 1, &W, &stride));
+    const bool rs = use_rs_path(gt.nmax);
+    if (!rs) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 1, &W, &stride));
     sd_bcsd_state* st = nullptr;
     int rc = alloc_state(ctx, kind, G, T, C, return_anoms, &st);
     if (rc != SD_OK) {
@@ -436,6 +494,16 @@ int sd_bcsd_fit_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_
         const double* first = X_dev ? X_dev : y_dev;
         SD_LAUNCH(ctx, "bcsd_mask_kernel", bcsd_mask_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, first, C,
                   st->status);
+        if (rs) {
+            sdrs::Params p = {};
+            p.kind = kind; p.G = G; p.return_anoms = return_anoms; p.RS = sd_bcsd_rs_row_stride(gt.nmax);
+            p.C = C; p.Tf = T; p.ntiles = (C + 7) / 8;
+            p.X = X_dev; p.y = y_dev; p.ld = ld;
+            p.ord_f = (const int32_t*)gt.order.p; p.off_f = (const int32_t*)gt.off.p;
+            p.ys = st->ys; p.x_climo = st->x_climo; p.y_climo = st->y_climo; p.status_fit = st->status;
+            p.ablate = rs_ablate();
+            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_FIT, p, gt.nmax));
+        } else
         switch (W) {
             case 8: SD_TRY(launch_fit<8>(ctx, kind, X_dev, y_dev, ld, gt, G, T, C, stride, return_anoms, st)); break;
             case 4: SD_TRY(launch_fit<4>(ctx, kind, X_dev, y_dev, ld, gt, G, T, C, stride, return_anoms, st)); break;
@@ -463,10 +531,27 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
     DevGroupTable gt;
     SD_TRY(upload_group_table(ctx, group_id_p, Tp, st->G, &gt));
     int W = 0, stride = 0;
-    SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 2, &W, &stride));
+    const int nmax_all = gt.nmax > st->nmax ? gt.nmax : st->nmax;
+    const bool rs = use_rs_path(nmax_all);
+    if (!rs) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 2, &W, &stride));
     sd_scratch status_p, status_pub;
     SD_HIP(hipMalloc(&status_p.p, sizeof(int32_t) * C));
     SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
+    QTables qt;
+    if (rs) {
+        SD_TRY(build_q_tables(ctx, st->goff, gt.host_off, st->G, &qt));
+        sdrs::Params p = {};
+        p.kind = st->kind; p.G = st->G; p.return_anoms = st->return_anoms; p.RS = sd_bcsd_rs_row_stride(nmax_all);
+        p.C = C; p.Tf = st->T; p.ntiles = (C + 7) / 8;
+        p.Xp = Xp_dev; p.ld_p = ld; p.out = out_dev; p.ld_out = ld_out;
+        p.off_f = (const int32_t*)st->goff_dev;
+        p.ord_p = (const int32_t*)gt.order.p; p.off_p = (const int32_t*)gt.off.p;
+        p.qidx = qt.idx.as<int32_t>(); p.qval = qt.val.as<double>();
+        p.ys = st->ys; p.x_climo = st->x_climo; p.y_climo = st->y_climo;
+        p.status_fit = st->status; p.status_p = status_p.as<int32_t>();
+        p.ablate = rs_ablate();
+        SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_PREDICT, p, nmax_all));
+    } else
     switch (W) {
         case 8: SD_TRY(launch_predict<8>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;
         case 4: SD_TRY(launch_predict<4>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;
@@ -474,7 +559,7 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
         default: SD_TRY(launch_predict<1>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;
     }
     // cells that are masked / failed in fit or non-finite in predict -> NaN rows
-    SD_LAUNCH(ctx, "nan_fill_kernel", nan_fill_kernel, dim3(2048), dim3(256), 0, out_dev, ld_out, Tp, C,
+    SD_LAUNCH(ctx, "nan_fill_kernel", nan_fill_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, out_dev, ld_out, Tp, C,
               (const int32_t*)st->status, (const int32_t*)status_p.p);
     if (cell_status) {
         SD_HIP(hipMalloc(&status_pub.p, sizeof(int32_t) * C));
@@ -490,12 +575,54 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
                             const int32_t* group_id, int G, int64_t T, int64_t C, int return_anoms,
                             const double* Xp_dev, int64_t ld_p, const int32_t* group_id_p, int64_t Tp,
                             double* out_dev, int64_t ld_out, int32_t* cell_status) {
-    // v1: fit then predict through a transient state (fused kernel lands with the register-resident path)
-    sd_bcsd_state* st = nullptr;
-    SD_TRY(sd_bcsd_fit_dev(ctx, kind, X_dev, y_dev, ld, group_id, G, T, C, return_anoms, &st));
-    int rc = sd_bcsd_predict_dev(ctx, st, Xp_dev, ld_p, group_id_p, Tp, out_dev, ld_out, cell_status);
-    sd_bcsd_state_destroy(st);
-    return rc;
+    SD_CHECK_ARG(ctx && y_dev && group_id && Xp_dev && group_id_p && out_dev, "sd_bcsd_fit_predict: NULL argument");
+    SD_CHECK_ARG(kind == SD_BCSD_TAS || kind == SD_BCSD_PR, "sd_bcsd_fit_predict: unknown kind %d", kind);
+    SD_CHECK_ARG(kind == SD_BCSD_PR || X_dev, "sd_bcsd_fit_predict: BcsdTemperature needs X");
+    SD_CHECK_ARG(T > 0 && Tp > 0 && C > 0 && G > 0 && ld >= C && ld_p >= C && ld_out >= C, "sd_bcsd_fit_predict: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    DevGroupTable gf, gp;
+    SD_TRY(upload_group_table(ctx, group_id, T, G, &gf));
+    SD_TRY(upload_group_table(ctx, group_id_p, Tp, G, &gp));
+    const int nmax_all = gf.nmax > gp.nmax ? gf.nmax : gp.nmax;
+    if (!use_rs_path(nmax_all)) {
+        // generic path: fit then predict through a transient state
+        sd_bcsd_state* st = nullptr;
+        SD_TRY(sd_bcsd_fit_dev(ctx, kind, X_dev, y_dev, ld, group_id, G, T, C, return_anoms, &st));
+        int rc = sd_bcsd_predict_dev(ctx, st, Xp_dev, ld_p, group_id_p, Tp, out_dev, ld_out, cell_status);
+        sd_bcsd_state_destroy(st);
+        return rc;
+    }
+    // fused register/LDS path: no persisted quantile state, HBM traffic = 3 reads + 1 write per sample
+    sd_scratch status_f, status_p, status_pub;
+    SD_HIP(hipMalloc(&status_f.p, sizeof(int32_t) * C));
+    SD_HIP(hipMalloc(&status_p.p, sizeof(int32_t) * C));
+    SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
+    QTables qt;
+    SD_TRY(build_q_tables(ctx, gf.host_off, gp.host_off, G, &qt));
+    const double* first = X_dev ? X_dev : y_dev;
+    SD_LAUNCH(ctx, "bcsd_mask_kernel", bcsd_mask_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, first, C,
+              status_f.as<int32_t>());
+    sdrs::Params p = {};
+    p.kind = kind; p.G = G; p.return_anoms = return_anoms; p.RS = sd_bcsd_rs_row_stride(nmax_all);
+    p.C = C; p.Tf = T; p.ntiles = (C + 7) / 8;
+    p.X = X_dev; p.y = y_dev; p.ld = ld;
+    p.Xp = Xp_dev; p.ld_p = ld_p; p.out = out_dev; p.ld_out = ld_out;
+    p.ord_f = (const int32_t*)gf.order.p; p.off_f = (const int32_t*)gf.off.p;
+    p.ord_p = (const int32_t*)gp.order.p; p.off_p = (const int32_t*)gp.off.p;
+    p.qidx = qt.idx.as<int32_t>(); p.qval = qt.val.as<double>();
+    p.status_fit = status_f.as<int32_t>(); p.status_p = status_p.as<int32_t>();
+    p.ablate = rs_ablate();
+    SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_FUSED, p, nmax_all));
+    SD_LAUNCH(ctx, "nan_fill_kernel", nan_fill_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, out_dev, ld_out, Tp, C,
+              (const int32_t*)status_f.p, (const int32_t*)status_p.p);
+    if (cell_status) {
+        SD_HIP(hipMalloc(&status_pub.p, sizeof(int32_t) * C));
+        SD_LAUNCH(ctx, "status_public_kernel", status_public_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
+                  (const int32_t*)status_f.p, (const int32_t*)status_p.p, C, status_pub.as<int32_t>());
+        SD_HIP(hipMemcpyAsync(cell_status, status_pub.p, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
 }
 
 int sd_bcsd_fit(sd_ctx* ctx, int kind, const double* X, const double* y, const int32_t* group_id, int G, int64_t T,

@@ -1,0 +1,27 @@
+// Register/LDS merge-sort BCSD path (sd_bcsd_rs.hip): parameters and launcher.
+#pragma once
+#include "sd_internal.h"
+
+namespace sdrs {
+
+enum { MODE_FIT = 0, MODE_PREDICT = 1, MODE_FUSED = 2 };
+
+struct Params {
+    int kind, G, return_anoms, RS;
+    int64_t C, Tf, ntiles;
+    const double* X; const double* y; int64_t ld;    // fit fields [Tf, ld]
+    const double* Xp; int64_t ld_p;                    // predict field [Tp, ld_p]
+    double* out; int64_t ld_out;
+    const int32_t* ord_f; const int32_t* off_f;        // fit group table
+    const int32_t* ord_p; const int32_t* off_p;        // predict group table
+    const int32_t* qidx; const double* qval;           // inverse-CDF tables, indexed off_p[g] + rank
+    double* ys; double* x_climo; double* y_climo;      // state: [C][Tf], [C][G], [C][G]
+    int32_t* status_fit; int32_t* status_p;
+    int ablate;  // development knob (SD_RS_ABLATE bitmask): skip phases to measure their marginal cost
+};
+
+}  // namespace sdrs
+
+bool sd_bcsd_rs_supported(int nmax);
+int sd_bcsd_rs_row_stride(int nmax);
+int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax);

@@ -1,0 +1,634 @@
+// BCSD quantile mapping, fast path: one 64-lane wave per (cell, month) segment, 8 adjacent cells per
+// 512-thread workgroup, two workgroups per CU.
+//
+// Per workgroup (tile of 8 cells x one time group g):
+//   1. x_hist rows are streamed (16-byte loads, 4 lanes per 64-byte row fragment) and reduced to the
+//      per-cell climatology -- never stored.
+//   2. x_fut rows are loaded the same way and transposed through LDS into one row per cell; the owning
+//      wave pulls its row into registers (K consecutive samples per lane), applies the 9-sample
+//      rolling-mean shift (bcsd.py:247-256) in registers, sorts a copy (below), and ranks every sample
+//      in the sorted copy by a branch-free binary search (np.interp's "last xp <= x" rule).
+//   3. y rows are loaded/transposed the same way, reduced to y_climo and sorted; the sorted segment
+//      stays in the wave's LDS row and every sample is mapped through the precomputed inverse-CDF
+//      table (index + weight per rank, identical for all cells) and written back transposed.
+// Sort: each lane sorts its K registers with a Batcher odd-even merge network (v_min_f64/v_max_f64),
+// writes the run to its LDS row, then 6 merge rounds double the run length; in every round a lane
+// finds its co-rank by binary search (merge path) and merges exactly K outputs sequentially into
+// registers before the wave writes them back in place (LDS requests of one wave are served in
+// order, so no barrier is needed inside the sort).  K is odd so that lane-strided LDS accesses are
+// bank-conflict free.
+//
+// HBM traffic is the algorithmic minimum for the fused mode: 3 reads + 1 write of 8 bytes per
+// (cell, time step).  Workgroup ids are mapped XCD-aware (workgroup b runs on XCD b % 8): every XCD
+// owns a contiguous range of cell tiles, so the two 64-byte halves of a 128-byte line are fetched
+// by workgroups sharing an L2.
+#include <cstdlib>
+
+#include "sd_bcsd_rs.h"
+
+namespace sdrs {
+
+constexpr int kWave = 64;
+constexpr int kW = 8;          // cells per workgroup
+constexpr int kThreads = 512;  // 8 waves
+constexpr int kRowsPerPass = kThreads / 4;  // 4 lanes (16 B each) cover the 8 cells of one row
+
+__device__ __forceinline__ bool finite64(double v) {
+    return (__double_as_longlong(v) & 0x7ff0000000000000ll) != 0x7ff0000000000000ll;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_wave_barrier(); }
+
+// ---- Batcher odd-even merge sort network for K registers (built at compile time) ----------------
+template <int K>
+struct Net {
+    static constexpr int N = K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : 64;
+    static constexpr int kMax = 600;
+    int n = 0;
+    unsigned char a[kMax] = {}, b[kMax] = {};
+    constexpr Net() {
+        for (int p = 1; p < N; p <<= 1)
+            for (int k = p; k >= 1; k >>= 1)
+                for (int j = k % p; j + k < N; j += 2 * k)
+                    for (int i = 0; i < k; ++i) {
+                        const int lo = i + j, hi = i + j + k;
+                        if (hi < N && lo / (2 * p) == hi / (2 * p) && hi < K) {  // comparators touching the +inf padding are no-ops
+                            a[n] = (unsigned char)lo;
+                            b[n] = (unsigned char)hi;
+                            ++n;
+                        }
+                    }
+    }
+};
+
+template <int K>
+__device__ __forceinline__ void sort_registers(double (&v)[K]) {
+    constexpr Net<K> net{};
+#pragma unroll
+    for (int c = 0; c < net.n; ++c) {
+        const double lo = __builtin_fmin(v[net.a[c]], v[net.b[c]]);
+        const double hi = __builtin_fmax(v[net.a[c]], v[net.b[c]]);
+        v[net.a[c]] = lo;
+        v[net.b[c]] = hi;
+    }
+}
+
+constexpr int ceil_log2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
+
+// ---- bitonic merger for K registers (built at compile time) --------------------------------------
+// A lane's merge window is loaded as [A ascending | +inf filler | B descending] into w[0..K): a bitonic
+// sequence.  Conceptually it is padded with -inf up to the next power of two N and pushed through the
+// standard N-input bitonic merger; comparators against a known -inf are resolved at compile time
+// (pure register renaming), so only ~2K real comparators remain.  out[s] names the register that
+// holds the s-th smallest value afterwards.
+template <int K>
+struct MergeNet {
+    static constexpr int N = K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : 64;
+    int n = 0;
+    unsigned char a[200] = {}, b[200] = {}, out[K] = {};
+    constexpr MergeNet() {
+        int reg[N] = {};
+        bool ninf[N] = {};
+        for (int s = 0; s < N; ++s) {
+            reg[s] = s < K ? s : 0;
+            ninf[s] = s >= K;
+        }
+        for (int h = N / 2; h >= 1; h >>= 1)
+            for (int i = 0; i < N; ++i) {
+                if (i & h) continue;
+                const int j = i + h;
+                if (ninf[i]) continue;  // min(-inf, x) stays put
+                if (ninf[j]) {          // (x, -inf) -> (-inf, x): rename
+                    reg[j] = reg[i];
+                    ninf[j] = false;
+                    ninf[i] = true;
+                    continue;
+                }
+                a[n] = (unsigned char)reg[i];
+                b[n] = (unsigned char)reg[j];
+                ++n;
+            }
+        for (int s = 0; s < K; ++s) out[s] = (unsigned char)reg[N - K + s];
+    }
+};
+
+// ---- wave-level merge sort of row[0..n): runs of K per lane -> fully sorted, in place ------------
+// Round r merges pairs of runs of length K << r.  Every lane owns K consecutive output positions of
+// its pair: it finds its co-rank (merge path) by binary search, loads the matching windows of A and B
+// (exactly one LDS read per element, all independent), merges them in registers and the wave writes
+// the K outputs back in place.  LDS requests of one wave are served in order: no barrier needed.
+template <int K>
+__device__ __forceinline__ void merge_rounds(double* row, int n, int lane) {
+    constexpr MergeNet<K> net{};
+#pragma unroll 1
+    for (int r = 0; r < 6; ++r) {
+        const int L = K << r;
+        if (L >= n) break;  // wave-uniform: a single run left
+        const int gl = lane & ((2 << r) - 1);  // lane within its merge group
+        const int base = (lane - gl) * K;
+        const int a0 = base < n ? base : n;
+        const int a1 = base + L < n ? base + L : n;
+        const int b1 = base + 2 * L < n ? base + 2 * L : n;
+        const int LA = a1 - a0, LB = b1 - a1;
+        const int d0 = gl * K;
+        const int d = d0 < LA + LB ? d0 : LA + LB;
+        const int dend = d0 + K < LA + LB ? d0 + K : LA + LB;
+        // co-rank: smallest i with A[i] > B[d-1-i]; ties go to A (stable merge)
+        int lo = d - LB > 0 ? d - LB : 0, hi = d < LA ? d : LA;
+        const int nsteps = r + ceil_log2(K + 1);
+#pragma unroll 1
+        for (int s = 0; s < nsteps; ++s) {
+            const bool act = lo < hi;
+            const int mid = (lo + hi) >> 1;
+            const double va = row[act ? a0 + mid : 0];
+            const double vb = row[act ? a1 + d - 1 - mid : 0];
+            const bool le = va <= vb;
+            lo = (act && le) ? mid + 1 : lo;
+            hi = (act && !le) ? mid : hi;
+        }
+        const int inext = __shfl_down(lo, 1, kWave);
+        const int ihi = (dend == LA + LB) ? LA : inext;  // co-rank of the end of this lane's window
+        const int cnt = dend - d;
+        const int acnt = ihi - lo, bcnt = cnt - acnt;
+        const int pa = a0 + lo;
+        const int qb = a1 + (d - lo) + bcnt - 1 + (K - bcnt);  // B window is read backwards: index qb - s
+        double w[K];
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const bool from_a = s < acnt, from_b = s >= K - bcnt;
+            const int idx = from_a ? pa + s : qb - s;
+            const double v = row[(from_a || from_b) ? idx : 0];
+            w[s] = (from_a || from_b) ? v : __builtin_inf();
+            if (s % 7 == 6) __builtin_amdgcn_sched_barrier(0);  // issue the loads in batches: bounds the address temporaries
+        }
+#pragma unroll
+        for (int c = 0; c < net.n; ++c) {
+            const double mn = __builtin_fmin(w[net.a[c]], w[net.b[c]]);
+            const double mx = __builtin_fmax(w[net.a[c]], w[net.b[c]]);
+            w[net.a[c]] = mn;
+            w[net.b[c]] = mx;
+        }
+        wave_fence();
+        const int ob = a0 + d;
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            row[s < cnt ? ob + s : n] = w[net.out[s]];  // slot n is a write-only dump
+            if (s % 7 == 6) __builtin_amdgcn_sched_barrier(0);
+        }
+        wave_fence();
+    }
+}
+
+// sort the wave's segment: v[] = K consecutive samples per lane (pads = +inf), result in row[0..n)
+template <int K>
+__device__ __forceinline__ void sort_segment(double (&v)[K], double* row, int n, int lane) {
+    sort_registers<K>(v);
+    const int base = K * lane;
+#pragma unroll
+    for (int i = 0; i < K; ++i) row[base + i < n ? base + i : n] = v[i];
+    wave_fence();
+    merge_rounds<K>(row, n, lane);
+}
+
+// ---- tile movement ------------------------------------------------------------------------------
+// rows of one group for the 8 cells of the tile -> LDS rows (cell-major).  16-byte loads when possible.
+__device__ __forceinline__ void load_tile(const double* __restrict__ src, int64_t ld, const int32_t* __restrict__ ord,
+                                          int nrows, int64_t c0, int64_t C, bool vec_ok, double* tile, int RS,
+                                          int32_t* status) {
+    const int cp = threadIdx.x & 3, rr = threadIdx.x >> 2;
+    const int64_t c = c0 + 2 * cp;
+    double* d0 = tile + (2 * cp) * RS;
+    double* d1 = d0 + RS;
+    const bool full = vec_ok && c + 1 < C;
+#pragma unroll 4
+    for (int r = rr; r < nrows; r += kRowsPerPass) {
+        const double* p = src + (int64_t)ord[r] * ld + c;
+        double v0 = 0.0, v1 = 0.0;
+        if (full) {
+            const double2 v = *reinterpret_cast<const double2*>(p);
+            v0 = v.x;
+            v1 = v.y;
+        } else {
+            if (c < C) v0 = p[0];
+            if (c + 1 < C) v1 = p[1];
+        }
+        if (!finite64(v0) && c < C) atomicOr(&status[c], SDI_NONFINITE);
+        if (!finite64(v1) && c + 1 < C) atomicOr(&status[c + 1], SDI_NONFINITE);
+        d0[r] = v0;
+        d1[r] = v1;
+    }
+}
+
+__device__ __forceinline__ void store_tile(double* __restrict__ dst, int64_t ld, const int32_t* __restrict__ ord,
+                                           int nrows, int64_t c0, int64_t C, bool vec_ok, const double* tile, int RS) {
+    const int cp = threadIdx.x & 3, rr = threadIdx.x >> 2;
+    const int64_t c = c0 + 2 * cp;
+    const double* s0 = tile + (2 * cp) * RS;
+    const double* s1 = s0 + RS;
+    const bool full = vec_ok && c + 1 < C;
+#pragma unroll 4
+    for (int r = rr; r < nrows; r += kRowsPerPass) {
+        double* p = dst + (int64_t)ord[r] * ld + c;
+        if (full) {
+            *reinterpret_cast<double2*>(p) = make_double2(s0[r], s1[r]);
+        } else {
+            if (c < C) p[0] = s0[r];
+            if (c + 1 < C) p[1] = s1[r];
+        }
+    }
+}
+
+// column sums of one group's rows for the 8 cells (x climatology; nothing stored)
+__device__ __forceinline__ double tile_column_mean(const double* __restrict__ src, int64_t ld,
+                                                   const int32_t* __restrict__ ord, int nrows, int64_t c0, int64_t C,
+                                                   bool vec_ok, double* scratch, int32_t* status, int wave, int lane) {
+    const int cp = threadIdx.x & 3, rr = threadIdx.x >> 2;
+    const int64_t c = c0 + 2 * cp;
+    const bool full = vec_ok && c + 1 < C;
+    double s0 = 0.0, s1 = 0.0;
+    bool bad0 = false, bad1 = false;
+#pragma unroll 4
+    for (int r = rr; r < nrows; r += kRowsPerPass) {
+        const double* p = src + (int64_t)ord[r] * ld + c;
+        double v0 = 0.0, v1 = 0.0;
+        if (full) {
+            const double2 v = *reinterpret_cast<const double2*>(p);
+            v0 = v.x;
+            v1 = v.y;
+        } else {
+            if (c < C) v0 = p[0];
+            if (c + 1 < C) v1 = p[1];
+        }
+        bad0 |= !finite64(v0);
+        bad1 |= !finite64(v1);
+        s0 += v0;
+        s1 += v1;
+    }
+    if (bad0 && c < C) atomicOr(&status[c], SDI_NONFINITE);
+    if (bad1 && c + 1 < C) atomicOr(&status[c + 1], SDI_NONFINITE);
+#pragma unroll
+    for (int o = 4; o <= 32; o <<= 1) {  // lanes with equal (lane & 3) hold the same cell pair
+        s0 += __shfl_xor(s0, o, kWave);
+        s1 += __shfl_xor(s1, o, kWave);
+    }
+    if (lane < 4) {
+        scratch[wave * kW + 2 * lane] = s0;
+        scratch[wave * kW + 2 * lane + 1] = s1;
+    }
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < kW; ++w) tot += scratch[w * kW + wave];  // wave <-> cell c0 + wave
+    __syncthreads();
+    return tot / (double)nrows;
+}
+
+template <int K>
+__device__ __forceinline__ void load_blocked(const double* row, int cnt, int lane, double pad, double (&v)[K]) {
+    const int base = K * lane;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const int j = base + i;
+        const double t = row[j < cnt ? j : 0];
+        v[i] = j < cnt ? t : pad;
+    }
+}
+
+// rolling(9, center=True, min_periods=1).mean() at register i of the lane (bcsd.py:247-250).
+// The lane holds K consecutive samples x[]; nb[0..3] / nb[4..7] are the 4 samples before / after them
+// (from the neighbouring lanes).  Samples outside [0, m) are 0 and the divisor is the clipped count.
+template <int K>
+struct Halo {
+    static_assert(K >= 4, "the 4-sample halo must come from the adjacent lane only");
+    double nb[8];
+};
+
+template <int K>
+__device__ __forceinline__ Halo<K> build_halo(const double (&x)[K], int lane) {
+    Halo<K> h;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // K < 4: the 4-sample halo spans more than one neighbouring lane -> use the generic shuffle distance
+        const double l = __shfl_up(x[(K - 4 + k) >= 0 ? (K - 4 + k) : 0], 1, kWave);
+        const double r = __shfl_down(x[k < K ? k : K - 1], 1, kWave);
+        h.nb[k] = lane == 0 ? 0.0 : l;
+        h.nb[4 + k] = lane == kWave - 1 ? 0.0 : r;
+    }
+    return h;
+}
+
+template <int K>
+__device__ __forceinline__ double window_at(const double (&x)[K], const Halo<K>& h, int p /* -4 .. K+3, static */) {
+    return p < 0 ? h.nb[4 + p] : (p >= K ? h.nb[4 + (p - K)] : x[p]);
+}
+
+template <int K>
+__device__ __forceinline__ double rolling_at(const double (&x)[K], const Halo<K>& h, int i, int j, int m,
+                                             const double* rcp /* LDS: 1/c for c = 0..9 */) {
+    double s = 0.0;
+#pragma unroll
+    for (int d = -4; d <= 4; ++d) s += window_at<K>(x, h, i + d);
+    const int lo = j - 4 > 0 ? j - 4 : 0;
+    const int hi = j + 5 < m ? j + 5 : m;
+    // s / count, correctly rounded like the reference's division but without the ~12-instruction
+    // division sequence: rcp[] holds the correctly rounded reciprocals of 1..9; one Markstein
+    // correction step (q + (s - c*q) * (1/c)) yields the correctly rounded quotient for these divisors.
+    const int c = hi - lo > 1 ? hi - lo : 1;
+    const double cd = (double)c;
+    const double rc = rcp[c];
+    const double q = s * rc;
+    return __builtin_fma(__builtin_fma(-cd, q, s), rc, q);
+}
+
+constexpr double kAlpha = 0.4, kBeta = 0.4;
+__device__ __forceinline__ double pp_denom(int n) { return ((double)n + 1.0 - kAlpha) - kBeta; }
+__device__ __forceinline__ double pp_at(int i, double denom) { return ((double)(i + 1) - kAlpha) / denom; }
+
+__device__ void ols_line(const double* ysg, int first, int e, double denom, double* slope, double* icpt) {
+    double xm = 0.0, ym = 0.0;
+    for (int i = 0; i < e; ++i) {
+        xm += pp_at(first + i, denom);
+        ym += ysg[first + i];
+    }
+    xm /= (double)e;
+    ym /= (double)e;
+    double sxx = 0.0, sxy = 0.0;
+    for (int i = 0; i < e; ++i) {
+        const double dx = pp_at(first + i, denom) - xm;
+        sxx += dx * dx;
+        sxy += dx * (ysg[first + i] - ym);
+    }
+    const double s = sxx > 0.0 ? sxy / sxx : 0.0;
+    *slope = s;
+    *icpt = ym - s * xm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// OCC = waves per SIMD the register allocation is capped for: 4 -> 128 VGPRs (2 workgroups per CU),
+// 2 -> 256 VGPRs (1 workgroup per CU, no spills).
+template <int K, int MODE, int OCC, int KIND>
+__global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) {
+    constexpr bool kTas = KIND == SD_BCSD_TAS;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* tile = reinterpret_cast<double*>(smem_raw);
+    const int RS = p.RS;
+    double* scratch = tile + kW * RS;  // 64 doubles
+    double* rcp = scratch + 64;        // 16 doubles: correctly rounded 1/c, c = 1..9
+    if (threadIdx.x < 16) {
+        const double tab[16] = {0.0, 1.0, 0.5, 1.0 / 3.0, 0.25, 0.2, 1.0 / 6.0, 1.0 / 7.0, 0.125, 1.0 / 9.0, 0, 0, 0, 0, 0, 0};
+        rcp[threadIdx.x] = tab[threadIdx.x];
+    }
+
+    // XCD-aware workgroup -> (tile, group): XCD x owns tiles [x*tx, (x+1)*tx)
+    const int64_t tx = (p.ntiles + 7) / 8;
+    const int xcd = blockIdx.x & 7;
+    const int64_t jb = blockIdx.x >> 3;
+    const int64_t tile_id = xcd * tx + jb % tx;
+    const int g = (int)(jb / tx);
+    if (tile_id >= p.ntiles || g >= p.G) return;
+    const int64_t c0 = tile_id * kW;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int64_t c = c0 + wave;
+    const bool cell_ok = c < p.C;
+    double* row = tile + wave * RS;
+
+    const int begf = p.off_f[g], n = p.off_f[g + 1] - begf;
+    int begp = 0, m = 0;
+    if (MODE != MODE_FIT) {
+        begp = p.off_p[g];
+        m = p.off_p[g + 1] - begp;
+        if (m == 0) return;
+    } else if (n == 0) {
+        return;
+    }
+    const bool vec_f = (p.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
+                       (p.X == nullptr || (reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
+
+    // ---- x climatology (bcsd.py:222); PR only validates X ------------------------------------------
+    double xc = 0.0;
+    if (MODE != MODE_PREDICT) {
+        if (p.X != nullptr && n > 0 && !(p.ablate & 32)) {
+            xc = tile_column_mean(p.X, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, scratch, p.status_fit, wave, lane);
+            if (MODE == MODE_FIT && kTas && lane == 0 && cell_ok) p.x_climo[c * p.G + g] = xc;
+        }
+    } else if (kTas && cell_ok) {
+        xc = p.x_climo[c * p.G + g];
+    }
+
+    constexpr int CH = K >= 14 ? (K + 2) / 3 : K;  // samples processed together in the search / lookup phases
+    double x[K];   // predict samples of the lane (K consecutive time steps), later the outputs
+    unsigned rank2[(K + 1) / 2];  // two 16-bit ranks per register (segments are < 65536 samples)
+#pragma unroll
+    for (int i = 0; i < (K + 1) / 2; ++i) rank2[i] = 0u;
+    if (MODE != MODE_FIT) {
+        const bool vec_p = (p.ld_p % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.Xp) & 15) == 0);
+        load_tile(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile, RS, p.status_p);
+        __syncthreads();
+        load_blocked<K>(row, m, lane, 0.0, x);
+        {
+            double s[K];
+            if (kTas) {
+                const Halo<K> h = build_halo<K>(x, lane);
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const int j = K * lane + i;
+                    const double shift = rolling_at<K>(x, h, i, j, m, rcp) - xc;   // bcsd.py:253
+                    s[i] = j < m ? x[i] - shift : __builtin_inf();          // bcsd.py:256
+                    if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);      // bound the number of window sums in flight
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; ++i) s[i] = K * lane + i < m ? x[i] : __builtin_inf();
+            }
+            wave_fence();
+            if (!(p.ablate & 1)) sort_segment<K>(s, row, m, lane);  // self ECDF: np.sort(u) (quantile.py:462 via 505-521)
+        }
+        // rank = (#sorted <= u) - 1: np.interp's exact-hit index = max rank among ties (quantile.py:488).
+        // Branch-free binary search, CH independent chains at a time (bounded register pressure).
+        int top = 1;
+        while (top * 2 <= m) top *= 2;
+        {
+            Halo<K> h = {};
+            if (kTas) h = build_halo<K>(x, lane);
+#pragma unroll
+            for (int cbeg = 0; cbeg < K; cbeg += CH) {
+                double uu[CH];
+                int pos[CH];
+#pragma unroll
+                for (int ii = 0; ii < CH; ++ii) {
+                    const int i = cbeg + ii < K ? cbeg + ii : K - 1;
+                    uu[ii] = x[i];
+                    if (kTas) uu[ii] = x[i] - (rolling_at<K>(x, h, i, K * lane + i, m, rcp) - xc);
+                    pos[ii] = 0;
+                }
+#pragma unroll 1
+                for (int step = (p.ablate & 2) ? 0 : top; step >= 1; step >>= 1) {
+#pragma unroll
+                    for (int ii = 0; ii < CH; ++ii) {
+                        const int cand = pos[ii] + step;
+                        const double v = row[(cand < m ? cand : m) - 1];
+                        pos[ii] = (cand <= m && v <= uu[ii]) ? cand : pos[ii];
+                    }
+                }
+#pragma unroll
+                for (int ii = 0; ii < CH; ++ii) {
+                    const int i = cbeg + ii;
+                    if (i < K) {
+                        const unsigned rk = (unsigned)(pos[ii] > 0 ? pos[ii] - 1 : 0);
+                        rank2[i >> 1] |= (i & 1) ? (rk << 16) : rk;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();  // every wave is done with its x_fut row: the tile is reused for y
+    }
+
+    // ---- y: climatology + sorted segment in the wave's row ------------------------------------------
+    double yc = 0.0;
+    if (MODE != MODE_PREDICT) {
+        if (n > 0) {
+            load_tile(p.y, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, tile, RS, p.status_fit);
+            __syncthreads();
+            double v[K];
+            load_blocked<K>(row, n, lane, 0.0, v);
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) s += v[i];
+            yc = wave_sum(s) / (double)n;  // bcsd.py:223 / 138
+            if (lane == 0 && cell_ok) {
+                if (MODE == MODE_FIT) p.y_climo[c * p.G + g] = yc;
+                if (!kTas && p.return_anoms && yc <= 0.0) atomicOr(&p.status_fit[c], SDI_BAD_CLIMO);  // bcsd.py:140-141
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) v[i] = K * lane + i < n ? v[i] : __builtin_inf();
+            wave_fence();
+            if (!(p.ablate & 4)) sort_segment<K>(v, row, n, lane);  // quantile.py:462 np.sort
+            if (MODE == MODE_FIT && cell_ok) {
+                double* dst = p.ys + c * p.Tf + begf;
+                for (int i = lane; i < n; i += kWave) dst[i] = row[i];
+            }
+        }
+    } else {
+        if (cell_ok) {
+            yc = p.y_climo[c * p.G + g];
+            const double* src = p.ys + c * p.Tf + begf;
+            for (int i = lane; i < n; i += kWave) row[i] = src[i];
+        }
+        wave_fence();
+    }
+    if (MODE == MODE_FIT) return;
+
+    // ---- map ranks through the fitted inverse CDF (quantile.py:523-545), restore shift --------------
+    {
+        double slo = 0.0, ilo = 0.0, shi = 0.0, ihi = 0.0;
+        if (m > n && n > 0) {  // tails are reachable only when the predict segment is longer
+            const int e = n < 10 ? n : 10;
+            const double dn = pp_denom(n);
+            ols_line(row, 0, e, dn, &slo, &ilo);
+            ols_line(row, n - e, e, dn, &shi, &ihi);
+        }
+        const double nan = __longlong_as_double(0x7ff8000000000000ll);
+        Halo<K> h = {};
+        if (kTas) h = build_halo<K>(x, lane);
+        const int32_t* qi = p.qidx + begp;
+        const double* qv = p.qval + begp;
+        // results overwrite x[] in place; the rolling window of sample i still needs the original
+        // x[i-4..i+4], so a result is written back 4 iterations late (static ring of 4).
+        double pend[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int j = K * lane + i;
+            const int r = (int)((i & 1) ? (rank2[i >> 1] >> 16) : (rank2[i >> 1] & 0xffffu));
+            const int idx = (p.ablate & 8) ? 0 : qi[r];
+            const double w = (p.ablate & 8) ? 0.0 : qv[r];
+            double q;
+            if (idx >= 0) {
+                const double y0 = row[idx];
+                const double y1 = row[idx + 1 < n ? idx + 1 : idx];
+                q = w == 0.0 ? y0 : y0 + w * (y1 - y0);
+            } else if (idx == -1) {
+                q = w * slo + ilo;
+            } else if (idx == -2) {
+                q = w * shi + ihi;
+            } else {
+                q = nan;
+            }
+            double res;
+            if (kTas) {
+                const double shift = rolling_at<K>(x, h, i, j, m, rcp) - xc;
+                res = shift + q;                       // bcsd.py:263
+                if (p.return_anoms) res = res - yc;    // bcsd.py:266-267
+            } else {
+                res = p.return_anoms ? q / yc : q;     // bcsd.py:170-185
+            }
+            if (i >= 4) x[i - 4] = pend[i & 3];
+            pend[i & 3] = res;
+            if ((i + 1) % CH == 0) __builtin_amdgcn_sched_barrier(0);  // keep the loads of later samples from piling up
+        }
+#pragma unroll
+        for (int i = (K >= 4 ? K - 4 : 0); i < K; ++i) x[i] = pend[i & 3];
+        wave_fence();
+        const int base = K * lane;
+#pragma unroll
+        for (int i = 0; i < K; ++i) row[base + i < m ? base + i : m] = x[i];
+    }
+    __syncthreads();
+    const bool vec_o = (p.ld_out % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+    if (!(p.ablate & 64)) store_tile(p.out, p.ld_out, p.ord_p + begp, m, c0, p.C, vec_o, tile, RS);
+}
+
+template <int K, int MODE, int OCC, int KIND>
+int launch_kok(sd_ctx* ctx, const Params& p, const char* name) {
+    const size_t lds = ((size_t)kW * p.RS + 64 + 16) * sizeof(double);
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_rs_kernel<K, MODE, OCC, KIND>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t tx = (p.ntiles + 7) / 8;
+    const int64_t nblocks = 8 * tx * p.G;
+    SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "grid too large");
+    SD_LAUNCH(ctx, name, (bcsd_rs_kernel<K, MODE, OCC, KIND>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
+    return SD_OK;
+}
+
+template <int K, int MODE, int OCC>
+int launch_ko(sd_ctx* ctx, const Params& p, const char* name) {
+    return p.kind == SD_BCSD_TAS ? launch_kok<K, MODE, OCC, SD_BCSD_TAS>(ctx, p, name)
+                                 : launch_kok<K, MODE, OCC, SD_BCSD_PR>(ctx, p, name);
+}
+
+template <int K, int MODE>
+int launch_k(sd_ctx* ctx, const Params& p, const char* name) {
+    return launch_ko<K, MODE, (K > 21 ? 2 : 4)>(ctx, p, name);
+}
+
+template <int MODE>
+int launch_mode(sd_ctx* ctx, const Params& p, int nmax, const char* name) {
+    if (nmax <= 64 * 5) return launch_k<5, MODE>(ctx, p, name);
+    if (nmax <= 64 * 13) return launch_k<13, MODE>(ctx, p, name);
+    if (nmax <= 64 * 21) return launch_k<21, MODE>(ctx, p, name);
+    if (nmax <= 64 * 33) return launch_k<33, MODE>(ctx, p, name);
+    return sd_set_error(SD_ERR_UNSUPPORTED, "segment of %d samples exceeds the register-sort path", nmax);
+}
+
+}  // namespace sdrs
+
+// Entry points used by sd_bcsd.hip ---------------------------------------------------------------
+bool sd_bcsd_rs_supported(int nmax) { return nmax >= 1 && nmax <= 64 * 33; }
+
+int sd_bcsd_rs_row_stride(int nmax) {
+    int rs = nmax + 1;  // one readable slot past the end (merge heads)
+    while (rs % 8 != 2) ++rs;  // cell rows land 8 banks apart: conflict-free transposing stores
+    return rs;
+}
+
+int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax) {
+    switch (mode) {
+        case sdrs::MODE_FIT: return sdrs::launch_mode<sdrs::MODE_FIT>(ctx, p, nmax, "bcsd_rs_fit_kernel");
+        case sdrs::MODE_PREDICT: return sdrs::launch_mode<sdrs::MODE_PREDICT>(ctx, p, nmax, "bcsd_rs_predict_kernel");
+        default: return sdrs::launch_mode<sdrs::MODE_FUSED>(ctx, p, nmax, "bcsd_rs_fused_kernel");
+    }
+}

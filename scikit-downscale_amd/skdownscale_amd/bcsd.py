@@ -22,7 +22,8 @@ from .base import TimeSynchronousDownscaler
 from .engine import DeviceArray, default_context
 from .groupers import DAY_GROUPER, MONTH_GROUPER, group_keys
 
-Cdf = collections.namedtuple("CDF", ["pp", "vals"])  # quantile.py:20
+Cdf = collections.namedtuple("Cdf", ["pp", "vals"])  # quantile.py:20
+FittedCunnane = collections.namedtuple("FittedCunnane", ["cdf_"])
 
 _QT_DEFAULTS = dict(alpha=0.4, beta=0.4, extrapolate="both", n_endpoints=10)  # quantile.py:419-426
 
@@ -37,7 +38,7 @@ class _FittedQuantileMapper:
     exposes ``x_cdf_fit_.cdf_`` = (plotting positions, sorted values)."""
 
     def __init__(self, vals):
-        self.x_cdf_fit_ = collections.namedtuple("FittedCunnane", ["cdf_"])(Cdf(plotting_positions(len(vals)), vals))
+        self.x_cdf_fit_ = FittedCunnane(Cdf(plotting_positions(len(vals)), vals))
 
 
 def check_supported(model):
