@@ -41,7 +41,12 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
     return v;
 }
-__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_wave_barrier(); }
+// Lanes of one wave exchange data through LDS inside the sort.  The hardware serves a wave's LDS
+// requests in order; for the compiler the exchange needs a wavefront-scope fence plus the wave barrier.
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // ---- Batcher odd-even merge sort network for K registers (built at compile time) ----------------
 template <int K>
@@ -465,20 +470,23 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
                     if (kTas) uu[ii] = x[i] - (rolling_at<K>(x, h, i, K * lane + i, m, rcp) - xc);
                     pos[ii] = 0;
                 }
+                const double wsel = row[m - top];
+#pragma unroll
+                for (int ii = 0; ii < CH; ++ii) pos[ii] = wsel <= uu[ii] ? m - top : 0;
 #pragma unroll 1
-                for (int step = (p.ablate & 2) ? 0 : top; step >= 1; step >>= 1) {
+                for (int half = top >> 1; half >= 1; half >>= 1) {
 #pragma unroll
                     for (int ii = 0; ii < CH; ++ii) {
-                        const int cand = pos[ii] + step;
-                        const double v = row[(cand < m ? cand : m) - 1];
-                        pos[ii] = (cand <= m && v <= uu[ii]) ? cand : pos[ii];
+                        const double v = row[pos[ii] + half - 1];
+                        pos[ii] += v <= uu[ii] ? half : 0;
                     }
                 }
 #pragma unroll
                 for (int ii = 0; ii < CH; ++ii) {
                     const int i = cbeg + ii;
                     if (i < K) {
-                        const unsigned rk = (unsigned)(pos[ii] > 0 ? pos[ii] - 1 : 0);
+                        const int cnt = pos[ii] + (row[pos[ii]] <= uu[ii] ? 1 : 0);
+                        const unsigned rk = (unsigned)(cnt > 0 ? cnt - 1 : 0);
                         rank2[i >> 1] |= (i & 1) ? (rk << 16) : rk;
                     }
                 }

@@ -1,0 +1,18 @@
+import os, sys, numpy as np
+sys.path[:0] = ["scikit-downscale_amd", "oracle", "tests"]
+from skdownscale_amd import synth
+from skdownscale_amd.engine import default_context
+ctx = default_context()
+C = 8
+index = synth.daily_calendar(14600)
+gid = (np.asarray(index.month) - 1).astype(np.int32)
+cells = np.arange(C)
+X, y, Xp = (synth.tas_field(n, 0, index, cells, C) for n in ("X_hist", "y_obs", "X_fut"))
+st = ctx.bcsd_fit(0, X, y, gid, 12, True)
+e = st.export()
+e["x_climo"][:] = 0.0
+st0 = ctx.bcsd_import(e)
+ref0, _ = ctx.bcsd_predict(st0, Xp, gid)
+os.environ["SD_RS_ABLATE"] = "32"
+out, _ = ctx.bcsd_fit_predict(0, ctx.to_device(X), ctx.to_device(y), gid, 12, ctx.to_device(Xp), gid)
+print("fused(no colmean) vs predict(x_climo=0): max diff", np.abs(out.to_host() - ref0).max())

@@ -23,7 +23,11 @@ else:
 err = np.abs(out - exp).max()
 print("T", T, "Tp", Tp, "C", C, mode, "max err", err, "OK" if err < 1e-9 else "MISMATCH")
 '''
-for T, Tp, C in [(365, 365, 6), (1461, 1461, 6), (3650, 3650, 9), (8000, 8000, 8), (14600, 14600, 8), (14600, 20000, 5), (14600, 3000, 3), (20000, 14600, 4), (24000, 24000, 3)]:
+import os
+CASES = [(365, 365, 6), (1461, 1461, 6), (3650, 3650, 9), (8000, 8000, 8), (14600, 14600, 8), (14600, 20000, 5), (14600, 3000, 3), (20000, 14600, 4), (24000, 24000, 3)]
+if os.environ.get('DEV_CASES') == 'k21':
+    CASES = [(14600, 14600, 8), (14600, 3000, 3)]
+for T, Tp, C in CASES:
     for mode in ("split", "fused"):
         r = subprocess.run([sys.executable, "-c", CASE.format(T=T, Tp=Tp, C=C, mode=mode)], capture_output=True, text=True)
         print(r.stdout.strip() or f"T {T} Tp {Tp} {mode}: CRASH rc={r.returncode}", (r.stderr.strip().splitlines() or [""])[-1][:200] if r.returncode else "")
