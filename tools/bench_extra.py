@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""Secondary measurements (BASELINE configs 3 and 4): BcsdPrecipitation and PureAnalog on one MI355X.
+
+Not the headline bench (bench.py); prints one JSON line per workload with the same roofline convention:
+algorithmic bytes per cell / kernel time from HIP events on the engine's stream.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scikit-downscale_amd"))
+from skdownscale_amd import _lib, synth  # noqa: E402
+from skdownscale_amd.engine import Context  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["bcsd_pr", "analog", "analogreg"], default="analog")
+    ap.add_argument("--cells", type=int, default=8192)
+    ap.add_argument("--times", type=int, default=14600)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--k", type=int, default=30)
+    ap.add_argument("--kind", default="mean_analogs")
+    args = ap.parse_args()
+    ctx = Context(0)
+    T, C = args.times, args.cells
+    index = synth.daily_calendar(T)
+    gid = (np.asarray(index.month) - 1).astype(np.int32)
+
+    def field(kind, stream, **kw):
+        d = ctx.empty((T, C))
+        ctx.synth_fill(d, kind, 0, stream, c_full=C, **kw)
+        return d
+
+    if args.workload == "bcsd_pr":
+        f = {n: field(synth.PRECIP, synth.PR_FIELDS[n]["stream"], amp=synth.PR_FIELDS[n]["amp"], p_dry=synth.PR_FIELDS[n]["p_dry"])
+             for n in ("X_hist", "y_obs", "X_fut")}
+        out = ctx.empty((T, C))
+        step = lambda: ctx.bcsd_fit_predict(_lib.BCSD_PR, f["X_hist"], f["y_obs"], gid, 12, f["X_fut"], gid, True, out=out)  # noqa: E731
+        bytes_per_cell = 8 * (T + 2 * T)  # y_obs, X_fut, out (X_hist is only validated: + 8*T actually read)
+        name = f"BcsdPrecipitation zero-inflated, {C} cells x {T} steps"
+    else:
+        X = field(synth.GAUSS, 20)
+        y = field(synth.GAUSS, 20, amp=2.0, stream2=21, amp2=1.0)
+        Xq = field(synth.GAUSS, 22)
+        X3 = ctx.wrap(X.ptr, (T, 1, C))
+        Xq3 = ctx.wrap(Xq.ptr, (T, 1, C))
+        out = ctx.empty((T, 3, C))
+        kinds = {"best_analog": 0, "sample_analogs": 1, "weight_analogs": 2, "mean_analogs": 3}
+
+        def step():
+            st = ctx.analog_fit(X3, y)
+            if args.workload == "analog":
+                r = ctx.analog_predict(st, Xq3, args.k, kinds[args.kind], out=out)
+            else:
+                r = ctx.analogreg_predict(st, Xq3, args.k, out=out)
+            st.close()
+            return r
+        bytes_per_cell = 8 * (T + T + T + 3 * T)
+        name = f"{'PureAnalog ' + args.kind if args.workload == 'analog' else 'AnalogRegression'} k={args.k} F=1, {C} cells x {T} steps"
+    step()
+    ctx.synchronize()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    ctx.prof_enable(False)
+    prof = {k: v["ms"] / args.steps for k, v in ctx.prof().items()}
+    kms = sum(prof.values())
+    achieved = C * bytes_per_cell / (kms * 1e-3) / 1e9
+    print(json.dumps({"workload": name, "cells_per_s": C / dt, "ms_per_step": dt * 1e3, "kernel_ms_per_step": prof,
+                      "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                                   "algorithmic_bytes_per_cell": bytes_per_cell}}))
+
+
+if __name__ == "__main__":
+    main()
