@@ -549,6 +549,7 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
         p.qidx = qt.idx.as<int32_t>(); p.qval = qt.val.as<double>();
         p.ys = st->ys; p.x_climo = st->x_climo; p.y_climo = st->y_climo;
         p.status_fit = st->status; p.status_p = status_p.as<int32_t>();
+        p.identity = (st->goff == gt.host_off) ? 1 : 0;
         p.ablate = rs_ablate();
         SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_PREDICT, p, nmax_all));
     } else
@@ -611,8 +612,21 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
     p.ord_p = (const int32_t*)gp.order.p; p.off_p = (const int32_t*)gp.off.p;
     p.qidx = qt.idx.as<int32_t>(); p.qval = qt.val.as<double>();
     p.status_fit = status_f.as<int32_t>(); p.status_p = status_p.as<int32_t>();
+    p.identity = (gf.host_off == gp.host_off) ? 1 : 0;
     p.ablate = rs_ablate();
-    SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_FUSED, p, nmax_all));
+    {
+        // Two kernels, no persisted sorted state: RANK writes 2 bytes/sample (rank of every x_fut sample in its
+        // shifted segment) + x_climo; APPLY sorts y_obs on chip, maps the ranks and restores the shift.  (One
+        // monolithic kernel needs > 128 VGPRs; its spills tripled the HBM traffic -- profiles/r01/pmc_*.csv.)
+        const size_t rank_bytes = ((sizeof(uint16_t) * (size_t)Tp * C + 255) / 256) * 256;
+        void* ws = nullptr;
+        SD_TRY(sd_workspace(ctx, rank_bytes + sizeof(double) * (size_t)G * C, &ws));
+        p.ranks = static_cast<uint16_t*>(ws);
+        p.Tp = Tp;
+        p.x_climo = reinterpret_cast<double*>(static_cast<char*>(ws) + rank_bytes);
+        SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_RANK, p, nmax_all));
+        SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_APPLY, p, nmax_all));
+    }
     SD_LAUNCH(ctx, "nan_fill_kernel", nan_fill_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, out_dev, ld_out, Tp, C,
               (const int32_t*)status_f.p, (const int32_t*)status_p.p);
     if (cell_status) {

@@ -4,7 +4,9 @@
 
 namespace sdrs {
 
-enum { MODE_FIT = 0, MODE_PREDICT = 1, MODE_FUSED = 2 };
+// MODE_RANK + MODE_APPLY = the fused path as two kernels: RANK ranks every x_fut sample within its shifted
+// segment (2 bytes/sample, cell-major), APPLY sorts y_obs, maps the ranks and restores the shift.
+enum { MODE_FIT = 0, MODE_PREDICT = 1, MODE_FUSED = 2, MODE_RANK = 3, MODE_APPLY = 4 };
 
 struct Params {
     int kind, G, return_anoms, RS;
@@ -17,6 +19,8 @@ struct Params {
     const int32_t* qidx; const double* qval;           // inverse-CDF tables, indexed off_p[g] + rank
     double* ys; double* x_climo; double* y_climo;      // state: [C][Tf], [C][G], [C][G]
     int32_t* status_fit; int32_t* status_p;
+    uint16_t* ranks; int64_t Tp;                       // MODE_RANK / MODE_APPLY: ranks [C][Tp], cell-major
+    int identity;  // 1: every group has equal fit / predict length (inverse CDF = identity on ranks)
     int ablate;  // development knob (SD_RS_ABLATE bitmask): skip phases to measure their marginal cost
 };
 

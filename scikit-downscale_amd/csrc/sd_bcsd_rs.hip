@@ -415,24 +415,35 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
 
     // ---- x climatology (bcsd.py:222); PR only validates X ------------------------------------------
     double xc = 0.0;
-    if (MODE != MODE_PREDICT) {
+    if (MODE == MODE_APPLY) {
+        if (kTas && cell_ok) xc = p.x_climo[c * p.G + g];
+    } else if (MODE != MODE_PREDICT) {
         if (p.X != nullptr && n > 0 && !(p.ablate & 32)) {
             xc = tile_column_mean(p.X, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, scratch, p.status_fit, wave, lane);
-            if (MODE == MODE_FIT && kTas && lane == 0 && cell_ok) p.x_climo[c * p.G + g] = xc;
+            if ((MODE == MODE_FIT || MODE == MODE_RANK) && kTas && lane == 0 && cell_ok) p.x_climo[c * p.G + g] = xc;
         }
     } else if (kTas && cell_ok) {
         xc = p.x_climo[c * p.G + g];
     }
 
     constexpr int CH = K >= 14 ? (K + 2) / 3 : K;  // samples processed together in the search / lookup phases
-    double x[K];   // predict samples of the lane (K consecutive time steps), later the outputs
     unsigned rank2[(K + 1) / 2];  // two 16-bit ranks per register (segments are < 65536 samples)
 #pragma unroll
     for (int i = 0; i < (K + 1) / 2; ++i) rank2[i] = 0u;
-    if (MODE != MODE_FIT) {
-        const bool vec_p = (p.ld_p % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.Xp) & 15) == 0);
+    const bool vec_p = MODE != MODE_FIT && (p.ld_p % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.Xp) & 15) == 0);
+    if (MODE == MODE_APPLY) {
+        if (cell_ok) {
+            const uint16_t* rk = p.ranks + c * p.Tp + begp + K * lane;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const unsigned v = K * lane + i < m ? rk[i] : 0u;
+                rank2[i >> 1] |= (i & 1) ? (v << 16) : v;
+            }
+        }
+    } else if (MODE != MODE_FIT) {
         load_tile(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile, RS, p.status_p);
         __syncthreads();
+        double x[K];  // the lane's K consecutive predict samples; dead after this phase (the tile is read again at the end)
         load_blocked<K>(row, m, lane, 0.0, x);
         {
             double s[K];
@@ -493,6 +504,15 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (MODE == MODE_RANK) {
+            if (cell_ok) {
+                uint16_t* rk = p.ranks + c * p.Tp + begp + K * lane;
+#pragma unroll
+                for (int i = 0; i < K; ++i)
+                    if (K * lane + i < m) rk[i] = (uint16_t)((i & 1) ? (rank2[i >> 1] >> 16) : (rank2[i >> 1] & 0xffffu));
+            }
+            return;
+        }
         __syncthreads();  // every wave is done with its x_fut row: the tile is reused for y
     }
 
@@ -531,7 +551,8 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
     }
     if (MODE == MODE_FIT) return;
 
-    // ---- map ranks through the fitted inverse CDF (quantile.py:523-545), restore shift --------------
+    // ---- map ranks through the fitted inverse CDF (quantile.py:523-545) ------------------------------
+    double q[K];
     {
         double slo = 0.0, ilo = 0.0, shi = 0.0, ihi = 0.0;
         if (m > n && n > 0) {  // tails are reachable only when the predict segment is longer
@@ -541,49 +562,58 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
             ols_line(row, n - e, e, dn, &shi, &ihi);
         }
         const double nan = __longlong_as_double(0x7ff8000000000000ll);
-        Halo<K> h = {};
-        if (kTas) h = build_halo<K>(x, lane);
         const int32_t* qi = p.qidx + begp;
         const double* qv = p.qval + begp;
-        // results overwrite x[] in place; the rolling window of sample i still needs the original
-        // x[i-4..i+4], so a result is written back 4 iterations late (static ring of 4).
-        double pend[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            const int j = K * lane + i;
             const int r = (int)((i & 1) ? (rank2[i >> 1] >> 16) : (rank2[i >> 1] & 0xffffu));
             const int idx = (p.ablate & 8) ? 0 : qi[r];
             const double w = (p.ablate & 8) ? 0.0 : qv[r];
-            double q;
+            double t;
             if (idx >= 0) {
                 const double y0 = row[idx];
                 const double y1 = row[idx + 1 < n ? idx + 1 : idx];
-                q = w == 0.0 ? y0 : y0 + w * (y1 - y0);
+                t = w == 0.0 ? y0 : y0 + w * (y1 - y0);
             } else if (idx == -1) {
-                q = w * slo + ilo;
+                t = w * slo + ilo;
             } else if (idx == -2) {
-                q = w * shi + ihi;
+                t = w * shi + ihi;
             } else {
-                q = nan;
+                t = nan;
             }
-            double res;
-            if (kTas) {
-                const double shift = rolling_at<K>(x, h, i, j, m, rcp) - xc;
-                res = shift + q;                       // bcsd.py:263
-                if (p.return_anoms) res = res - yc;    // bcsd.py:266-267
-            } else {
-                res = p.return_anoms ? q / yc : q;     // bcsd.py:170-185
-            }
-            if (i >= 4) x[i - 4] = pend[i & 3];
-            pend[i & 3] = res;
-            if ((i + 1) % CH == 0) __builtin_amdgcn_sched_barrier(0);  // keep the loads of later samples from piling up
+            q[i] = t;
+            if ((i + 1) % CH == 0) __builtin_amdgcn_sched_barrier(0);  // keep later samples' loads from piling up
         }
+    }
+
+    // ---- restore the climate-trend shift (bcsd.py:263-267) / ratio anomalies (bcsd.py:170-185) ------
+    if (kTas) {
+        // The x_fut tile is read a second time (this workgroup fetched it moments ago: L2 / Infinity
+        // Cache): keeping the 2K sample registers alive across the y phase instead forces spills, which
+        // PMC counters showed as ~3x the algorithmic HBM traffic (profiles/r01/pmc_*.csv).
+        __syncthreads();  // all lookups done: rows are free again
+        load_tile(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile, RS, p.status_p);
+        __syncthreads();
+        double x[K];
+        load_blocked<K>(row, m, lane, 0.0, x);
+        const Halo<K> h = build_halo<K>(x, lane);
 #pragma unroll
-        for (int i = (K >= 4 ? K - 4 : 0); i < K; ++i) x[i] = pend[i & 3];
-        wave_fence();
+        for (int i = 0; i < K; ++i) {
+            const double shift = rolling_at<K>(x, h, i, K * lane + i, m, rcp) - xc;
+            double res = shift + q[i];               // bcsd.py:263
+            if (p.return_anoms) res = res - yc;      // bcsd.py:266-267
+            q[i] = res;
+            if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) q[i] = p.return_anoms ? q[i] / yc : q[i];  // bcsd.py:170-185
+    }
+    wave_fence();
+    {
         const int base = K * lane;
 #pragma unroll
-        for (int i = 0; i < K; ++i) row[base + i < m ? base + i : m] = x[i];
+        for (int i = 0; i < K; ++i) row[base + i < m ? base + i : m] = q[i];
     }
     __syncthreads();
     const bool vec_o = (p.ld_out % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
@@ -637,6 +667,8 @@ int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax) {
     switch (mode) {
         case sdrs::MODE_FIT: return sdrs::launch_mode<sdrs::MODE_FIT>(ctx, p, nmax, "bcsd_rs_fit_kernel");
         case sdrs::MODE_PREDICT: return sdrs::launch_mode<sdrs::MODE_PREDICT>(ctx, p, nmax, "bcsd_rs_predict_kernel");
-        default: return sdrs::launch_mode<sdrs::MODE_FUSED>(ctx, p, nmax, "bcsd_rs_fused_kernel");
+        case sdrs::MODE_RANK: return sdrs::launch_mode<sdrs::MODE_RANK>(ctx, p, nmax, "bcsd_rs_rank_kernel");
+        case sdrs::MODE_APPLY: return sdrs::launch_mode<sdrs::MODE_APPLY>(ctx, p, nmax, "bcsd_rs_apply_kernel");
+        default: return sd_set_error(SD_ERR_INVALID, "unknown register-sort mode %d", mode);
     }
 }

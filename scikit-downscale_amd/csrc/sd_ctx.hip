@@ -64,6 +64,7 @@ int sd_ctx_destroy(sd_ctx* ctx) {
     (void)hipEventDestroy(ctx->t1);
     (void)hipEventDestroy(ctx->p0);
     (void)hipEventDestroy(ctx->p1);
+    if (ctx->ws_ptr) (void)hipFree(ctx->ws_ptr);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SD_OK;
@@ -174,6 +175,20 @@ int sd_prof_names(sd_ctx* ctx, char* buf, size_t buf_len) {
 }
 
 }  // extern "C"
+
+int sd_workspace(sd_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->ws_size) {
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->ws_ptr) SD_HIP(hipFree(ctx->ws_ptr));
+        ctx->ws_ptr = nullptr;
+        ctx->ws_size = 0;
+        const size_t want = bytes + bytes / 8;
+        SD_HIP(hipMalloc(&ctx->ws_ptr, want));
+        ctx->ws_size = want;
+    }
+    *out = ctx->ws_ptr;
+    return SD_OK;
+}
 
 int sd_prof_begin(sd_ctx* ctx) {
     if (ctx->prof_on) SD_HIP(hipEventRecord(ctx->p0, ctx->stream));

@@ -32,6 +32,10 @@ struct sd_ctx {
     std::map<std::string, sd_prof_entry> prof;
     int cu_count = 0;
     size_t lds_max = 0;
+    // grow-only device workspace reused by calls on this context (hipMalloc/hipFree of GB-sized
+    // scratch costs tens of ms per call)
+    void* ws_ptr = nullptr;
+    size_t ws_size = 0;
 };
 
 struct sd_bcsd_state {
@@ -60,6 +64,9 @@ struct sd_analog_state {
 };
 
 int sd_set_error(int code, const char* fmt, ...);
+// Returns a device pointer to at least `bytes` of context-owned scratch (valid until the next call on
+// the context asks for more).  Calls on a context are serialised, so one buffer is enough.
+int sd_workspace(sd_ctx* ctx, size_t bytes, void** out);
 
 #define SD_CHECK_ARG(cond, ...)                                  \
     do {                                                         \
