@@ -201,6 +201,9 @@ __device__ __forceinline__ void sort_segment(double (&v)[K], double* row, int n,
 
 // ---- tile movement ------------------------------------------------------------------------------
 // rows of one group for the 8 cells of the tile -> LDS rows (cell-major).  16-byte loads when possible.
+// A thread owns rows rr, rr+128, ... (at most RPT of them); all of its loads are issued before the first
+// use so the whole tile costs one memory latency, not one per batch.
+template <int RPT>
 __device__ __forceinline__ void load_tile(const double* __restrict__ src, int64_t ld, const int32_t* __restrict__ ord,
                                           int nrows, int64_t c0, int64_t C, bool vec_ok, double* tile, int RS,
                                           int32_t* status) {
@@ -209,23 +212,41 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ src, int64_
     double* d0 = tile + (2 * cp) * RS;
     double* d1 = d0 + RS;
     const bool full = vec_ok && c + 1 < C;
-#pragma unroll 4
-    for (int r = rr; r < nrows; r += kRowsPerPass) {
-        const double* p = src + (int64_t)ord[r] * ld + c;
-        double v0 = 0.0, v1 = 0.0;
-        if (full) {
-            const double2 v = *reinterpret_cast<const double2*>(p);
-            v0 = v.x;
-            v1 = v.y;
-        } else {
-            if (c < C) v0 = p[0];
-            if (c + 1 < C) v1 = p[1];
-        }
-        if (!finite64(v0) && c < C) atomicOr(&status[c], SDI_NONFINITE);
-        if (!finite64(v1) && c + 1 < C) atomicOr(&status[c + 1], SDI_NONFINITE);
-        d0[r] = v0;
-        d1[r] = v1;
+    int t[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = rr + k * kRowsPerPass;
+        t[k] = ord[r < nrows ? r : 0];
     }
+    double v0[RPT], v1[RPT];
+    if (full) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const double2 v = *reinterpret_cast<const double2*>(src + (int64_t)t[k] * ld + c);
+            v0[k] = v.x;
+            v1[k] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const double* p = src + (int64_t)t[k] * ld + c;
+            v0[k] = c < C ? p[0] : 0.0;
+            v1[k] = c + 1 < C ? p[1] : 0.0;
+        }
+    }
+    bool bad0 = false, bad1 = false;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = rr + k * kRowsPerPass;
+        if (r < nrows) {
+            bad0 |= !finite64(v0[k]);
+            bad1 |= !finite64(v1[k]);
+            d0[r] = v0[k];
+            d1[r] = v1[k];
+        }
+    }
+    if (bad0 && c < C) atomicOr(&status[c], SDI_NONFINITE);
+    if (bad1 && c + 1 < C) atomicOr(&status[c + 1], SDI_NONFINITE);
 }
 
 __device__ __forceinline__ void store_tile(double* __restrict__ dst, int64_t ld, const int32_t* __restrict__ ord,
@@ -248,6 +269,7 @@ __device__ __forceinline__ void store_tile(double* __restrict__ dst, int64_t ld,
 }
 
 // column sums of one group's rows for the 8 cells (x climatology; nothing stored)
+template <int RPT>
 __device__ __forceinline__ double tile_column_mean(const double* __restrict__ src, int64_t ld,
                                                    const int32_t* __restrict__ ord, int nrows, int64_t c0, int64_t C,
                                                    bool vec_ok, double* scratch, int32_t* status, int wave, int lane) {
@@ -256,22 +278,32 @@ __device__ __forceinline__ double tile_column_mean(const double* __restrict__ sr
     const bool full = vec_ok && c + 1 < C;
     double s0 = 0.0, s1 = 0.0;
     bool bad0 = false, bad1 = false;
-#pragma unroll 4
-    for (int r = rr; r < nrows; r += kRowsPerPass) {
-        const double* p = src + (int64_t)ord[r] * ld + c;
-        double v0 = 0.0, v1 = 0.0;
+    int t[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = rr + k * kRowsPerPass;
+        t[k] = ord[r < nrows ? r : 0];
+    }
+    double v0[RPT], v1[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const double* p = src + (int64_t)t[k] * ld + c;
         if (full) {
             const double2 v = *reinterpret_cast<const double2*>(p);
-            v0 = v.x;
-            v1 = v.y;
+            v0[k] = v.x;
+            v1[k] = v.y;
         } else {
-            if (c < C) v0 = p[0];
-            if (c + 1 < C) v1 = p[1];
+            v0[k] = c < C ? p[0] : 0.0;
+            v1[k] = c + 1 < C ? p[1] : 0.0;
         }
-        bad0 |= !finite64(v0);
-        bad1 |= !finite64(v1);
-        s0 += v0;
-        s1 += v1;
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const bool in = rr + k * kRowsPerPass < nrows;
+        bad0 |= in && !finite64(v0[k]);
+        bad1 |= in && !finite64(v1[k]);
+        s0 += in ? v0[k] : 0.0;
+        s1 += in ? v1[k] : 0.0;
     }
     if (bad0 && c < C) atomicOr(&status[c], SDI_NONFINITE);
     if (bad1 && c + 1 < C) atomicOr(&status[c + 1], SDI_NONFINITE);
@@ -419,7 +451,7 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
         if (kTas && cell_ok) xc = p.x_climo[c * p.G + g];
     } else if (MODE != MODE_PREDICT) {
         if (p.X != nullptr && n > 0 && !(p.ablate & 32)) {
-            xc = tile_column_mean(p.X, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, scratch, p.status_fit, wave, lane);
+            xc = tile_column_mean<(K + 1) / 2>(p.X, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, scratch, p.status_fit, wave, lane);
             if ((MODE == MODE_FIT || MODE == MODE_RANK) && kTas && lane == 0 && cell_ok) p.x_climo[c * p.G + g] = xc;
         }
     } else if (kTas && cell_ok) {
@@ -441,7 +473,7 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
             }
         }
     } else if (MODE != MODE_FIT) {
-        load_tile(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile, RS, p.status_p);
+        load_tile<(K + 1) / 2>(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile, RS, p.status_p);
         __syncthreads();
         double x[K];  // the lane's K consecutive predict samples; dead after this phase (the tile is read again at the end)
         load_blocked<K>(row, m, lane, 0.0, x);
@@ -520,7 +552,7 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
     double yc = 0.0;
     if (MODE != MODE_PREDICT) {
         if (n > 0) {
-            load_tile(p.y, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, tile, RS, p.status_fit);
+            load_tile<(K + 1) / 2>(p.y, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, tile, RS, p.status_fit);
             __syncthreads();
             double v[K];
             load_blocked<K>(row, n, lane, 0.0, v);
@@ -592,7 +624,7 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
         // Cache): keeping the 2K sample registers alive across the y phase instead forces spills, which
         // PMC counters showed as ~3x the algorithmic HBM traffic (profiles/r01/pmc_*.csv).
         __syncthreads();  // all lookups done: rows are free again
-        load_tile(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile, RS, p.status_p);
+        load_tile<(K + 1) / 2>(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile, RS, p.status_p);
         __syncthreads();
         double x[K];
         load_blocked<K>(row, m, lane, 0.0, x);
