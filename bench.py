@@ -210,8 +210,18 @@ def main():
     kernel_ms = sum(kern[k] * launches_per_step[k] for k in kern)  # hot-path kernel time per step
     alg_bytes = float(C) * T * BYTES_PER_CELL_STEP
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    # HBM bytes per step from the committed rocprofv3 PMC passes of this exact workload (separate --pmc runs,
+    # gfx950 FETCH_SIZE correction calibrated on a known byte count: profiles/pmc_traffic.json); null otherwise
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f)
+        if pt["workload"]["cells"] == C and pt["workload"]["timesteps"] == T and pt["workload"]["kernel"] == "+".join(sorted(kern)):
+            traffic = pt["traffic_bytes_per_step"]
+    except Exception:  # noqa: BLE001
+        traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None, "kernel": "+".join(sorted(kern)), "kernel_ms_per_step": kernel_ms,
+                "traffic": traffic, "kernel": "+".join(sorted(kern)), "kernel_ms_per_step": kernel_ms,
                 "algorithmic_bytes_per_step": alg_bytes,
                 "per_kernel_avg_ms": kern}
     line = {
