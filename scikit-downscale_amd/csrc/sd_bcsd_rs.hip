@@ -381,6 +381,38 @@ __device__ __forceinline__ double rolling_at(const double (&x)[K], const Halo<K>
     return __builtin_fma(__builtin_fma(-cd, q, s), rc, q);
 }
 
+
+// 9-sample centred rolling means for CH consecutive samples j0..j0+CH-1 read straight from the wave's LDS
+// row (segment in time order): the CH+8 window values are read once (lane stride K is odd: conflict-free),
+// samples outside [0, m) count as 0, the divisor is the clipped window length (bcsd.py:247-250).
+template <int CH>
+__device__ __forceinline__ void rolling_from_lds(const double* row, int j0, int m, const double* rcp, double (&mean)[CH],
+                                                 double (&centre)[CH]) {
+    double w[CH + 8];
+#pragma unroll
+    for (int t = 0; t < CH + 8; ++t) {
+        const int j = j0 - 4 + t;
+        const bool in = j >= 0 && j < m;
+        const double v = row[in ? j : 0];
+        w[t] = in ? v : 0.0;
+    }
+#pragma unroll
+    for (int ii = 0; ii < CH; ++ii) {
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) s += w[ii + d];
+        const int j = j0 + ii;
+        const int lo = j - 4 > 0 ? j - 4 : 0;
+        const int hi = j + 5 < m ? j + 5 : m;
+        const int c = hi - lo > 1 ? (hi - lo < 10 ? hi - lo : 9) : 1;
+        const double cd = (double)c;
+        const double rc = rcp[c];
+        const double q = s * rc;
+        mean[ii] = __builtin_fma(__builtin_fma(-cd, q, s), rc, q);  // correctly rounded s / c (Markstein step)
+        centre[ii] = w[ii + 4];
+    }
+}
+
 constexpr double kAlpha = 0.4, kBeta = 0.4;
 __device__ __forceinline__ double pp_denom(int n) { return ((double)n + 1.0 - kAlpha) - kBeta; }
 __device__ __forceinline__ double pp_at(int i, double denom) { return ((double)(i + 1) - kAlpha) / denom; }
@@ -475,60 +507,65 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
     } else if (MODE != MODE_FIT) {
         load_tile<(K + 1) / 2>(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile, RS, p.status_p);
         __syncthreads();
-        double x[K];  // the lane's K consecutive predict samples; dead after this phase (the tile is read again at the end)
-        load_blocked<K>(row, m, lane, 0.0, x);
-        {
-            double s[K];
-            if (kTas) {
-                const Halo<K> h = build_halo<K>(x, lane);
+        double u[K];  // u = X - (rolling mean - x_climo) (bcsd.py:247-256); PR maps raw X (bcsd.py:167)
 #pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    const int j = K * lane + i;
-                    const double shift = rolling_at<K>(x, h, i, j, m, rcp) - xc;   // bcsd.py:253
-                    s[i] = j < m ? x[i] - shift : __builtin_inf();          // bcsd.py:256
-                    if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);      // bound the number of window sums in flight
-                }
+        for (int cbeg = 0; cbeg < K; cbeg += CH) {
+            double mean[CH], xv[CH];
+            if (kTas) {
+                rolling_from_lds<CH>(row, K * lane + cbeg, m, rcp, mean, xv);
             } else {
 #pragma unroll
-                for (int i = 0; i < K; ++i) s[i] = K * lane + i < m ? x[i] : __builtin_inf();
+                for (int ii = 0; ii < CH; ++ii) {
+                    const int j = K * lane + cbeg + ii;
+                    xv[ii] = row[j < m ? j : 0];
+                    mean[ii] = 0.0;
+                }
             }
-            wave_fence();
-            if (!(p.ablate & 1)) sort_segment<K>(s, row, m, lane);  // self ECDF: np.sort(u) (quantile.py:462 via 505-521)
+#pragma unroll
+            for (int ii = 0; ii < CH; ++ii) {
+                const int i = cbeg + ii;
+                if (i < K) {
+                    const double uv = kTas ? xv[ii] - (mean[ii] - xc) : xv[ii];  // bcsd.py:253-256
+                    u[i] = K * lane + i < m ? uv : __builtin_inf();
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wave_fence();
+        if (!(p.ablate & 1)) {
+            double s[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) s[i] = u[i];
+            sort_segment<K>(s, row, m, lane);  // self ECDF: np.sort(u) (quantile.py:462 via 505-521)
         }
         // rank = (#sorted <= u) - 1: np.interp's exact-hit index = max rank among ties (quantile.py:488).
         // Branch-free binary search, CH independent chains at a time (bounded register pressure).
         int top = 1;
         while (top * 2 <= m) top *= 2;
         {
-            Halo<K> h = {};
-            if (kTas) h = build_halo<K>(x, lane);
+            const double wsel = row[m - top];
 #pragma unroll
             for (int cbeg = 0; cbeg < K; cbeg += CH) {
-                double uu[CH];
                 int pos[CH];
 #pragma unroll
                 for (int ii = 0; ii < CH; ++ii) {
                     const int i = cbeg + ii < K ? cbeg + ii : K - 1;
-                    uu[ii] = x[i];
-                    if (kTas) uu[ii] = x[i] - (rolling_at<K>(x, h, i, K * lane + i, m, rcp) - xc);
-                    pos[ii] = 0;
+                    pos[ii] = wsel <= u[i] ? m - top : 0;
                 }
-                const double wsel = row[m - top];
-#pragma unroll
-                for (int ii = 0; ii < CH; ++ii) pos[ii] = wsel <= uu[ii] ? m - top : 0;
 #pragma unroll 1
-                for (int half = top >> 1; half >= 1; half >>= 1) {
+                for (int half = (p.ablate & 2) ? 0 : top >> 1; half >= 1; half >>= 1) {
 #pragma unroll
                     for (int ii = 0; ii < CH; ++ii) {
+                        const int i = cbeg + ii < K ? cbeg + ii : K - 1;
                         const double v = row[pos[ii] + half - 1];
-                        pos[ii] += v <= uu[ii] ? half : 0;
+                        pos[ii] += v <= u[i] ? half : 0;
                     }
                 }
 #pragma unroll
                 for (int ii = 0; ii < CH; ++ii) {
                     const int i = cbeg + ii;
                     if (i < K) {
-                        const int cnt = pos[ii] + (row[pos[ii]] <= uu[ii] ? 1 : 0);
+                        const int cnt = pos[ii] + (row[pos[ii]] <= u[i] ? 1 : 0);
                         const unsigned rk = (unsigned)(cnt > 0 ? cnt - 1 : 0);
                         rank2[i >> 1] |= (i & 1) ? (rk << 16) : rk;
                     }
