@@ -551,7 +551,14 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
         p.status_fit = st->status; p.status_p = status_p.as<int32_t>();
         p.identity = (st->goff == gt.host_off) ? 1 : 0;
         p.ablate = rs_ablate();
-        SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_PREDICT, p, nmax_all));
+        p.from_state = 1;
+        const size_t rank_bytes = sizeof(uint16_t) * (size_t)Tp * C;
+        void* ws = nullptr;
+        SD_TRY(sd_workspace(ctx, rank_bytes, &ws));
+        p.ranks = static_cast<uint16_t*>(ws);
+        p.Tp = Tp;
+        SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_RANK, p, nmax_all));
+        SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_APPLY, p, nmax_all));
     } else
     switch (W) {
         case 8: SD_TRY(launch_predict<8>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;

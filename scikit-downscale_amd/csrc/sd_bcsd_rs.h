@@ -20,6 +20,7 @@ struct Params {
     double* ys; double* x_climo; double* y_climo;      // state: [C][Tf], [C][G], [C][G]
     int32_t* status_fit; int32_t* status_p;
     uint16_t* ranks; int64_t Tp;                       // MODE_RANK / MODE_APPLY: ranks [C][Tp], cell-major
+    int from_state;  // RANK/APPLY: 1 = predict from a fitted state (x_climo, y_climo, ys given), 0 = fit on the fly from X, y
     int identity;  // 1: every group has equal fit / predict length (inverse CDF = identity on ranks)
     int ablate;  // development knob (SD_RS_ABLATE bitmask): skip phases to measure their marginal cost
 };

@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
 
     // ---- x climatology (bcsd.py:222); PR only validates X ------------------------------------------
     double xc = 0.0;
-    if (MODE == MODE_APPLY) {
+    if (MODE == MODE_APPLY || (MODE == MODE_RANK && p.from_state)) {
         if (kTas && cell_ok) xc = p.x_climo[c * p.G + g];
     } else if (MODE != MODE_PREDICT) {
         if (p.X != nullptr && n > 0 && !(p.ablate & 32)) {
@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
 
     // ---- y: climatology + sorted segment in the wave's row ------------------------------------------
     double yc = 0.0;
-    if (MODE != MODE_PREDICT) {
+    if (MODE != MODE_PREDICT && !(MODE == MODE_APPLY && p.from_state)) {
         if (n > 0) {
             load_tile<(K + 1) / 2>(p.y, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, tile, RS, p.status_fit);
             __syncthreads();
@@ -663,16 +663,20 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
         __syncthreads();  // all lookups done: rows are free again
         load_tile<(K + 1) / 2>(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile, RS, p.status_p);
         __syncthreads();
-        double x[K];
-        load_blocked<K>(row, m, lane, 0.0, x);
-        const Halo<K> h = build_halo<K>(x, lane);
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-            const double shift = rolling_at<K>(x, h, i, K * lane + i, m, rcp) - xc;
-            double res = shift + q[i];               // bcsd.py:263
-            if (p.return_anoms) res = res - yc;      // bcsd.py:266-267
-            q[i] = res;
-            if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        for (int cbeg = 0; cbeg < K; cbeg += CH) {
+            double mean[CH], xv[CH];
+            rolling_from_lds<CH>(row, K * lane + cbeg, m, rcp, mean, xv);
+#pragma unroll
+            for (int ii = 0; ii < CH; ++ii) {
+                const int i = cbeg + ii;
+                if (i < K) {
+                    double res = (mean[ii] - xc) + q[i];     // bcsd.py:253,263
+                    if (p.return_anoms) res = res - yc;      // bcsd.py:266-267
+                    q[i] = res;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
 #pragma unroll
@@ -735,7 +739,6 @@ int sd_bcsd_rs_row_stride(int nmax) {
 int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax) {
     switch (mode) {
         case sdrs::MODE_FIT: return sdrs::launch_mode<sdrs::MODE_FIT>(ctx, p, nmax, "bcsd_rs_fit_kernel");
-        case sdrs::MODE_PREDICT: return sdrs::launch_mode<sdrs::MODE_PREDICT>(ctx, p, nmax, "bcsd_rs_predict_kernel");
         case sdrs::MODE_RANK: return sdrs::launch_mode<sdrs::MODE_RANK>(ctx, p, nmax, "bcsd_rs_rank_kernel");
         case sdrs::MODE_APPLY: return sdrs::launch_mode<sdrs::MODE_APPLY>(ctx, p, nmax, "bcsd_rs_apply_kernel");
         default: return sd_set_error(SD_ERR_INVALID, "unknown register-sort mode %d", mode);
