@@ -127,76 +127,80 @@ struct MergeNet {
 // (exactly one LDS read per element, all independent), merges them in registers and the wave writes
 // the K outputs back in place.  LDS requests of one wave are served in order: no barrier needed.
 template <int K>
-__device__ __forceinline__ void merge_rounds(double* row, int n, int lane) {
+__device__ __forceinline__ void merge_rounds(double* row, int np, int lane) {
+    // np = number of slots being sorted, a multiple of K: the +inf pads that fill the last lane's run are
+    // ordinary elements (they sort to the end), so every participating lane merges exactly K outputs and
+    // no per-element validity test is needed; lanes past np sit out (one divergent branch per round).
     constexpr MergeNet<K> net{};
 #pragma unroll 1
     for (int r = 0; r < 6; ++r) {
         const int L = K << r;
-        if (L >= n) break;  // wave-uniform: a single run left
+        if (L >= np) break;  // wave-uniform: a single run left
         const int gl = lane & ((2 << r) - 1);  // lane within its merge group
         const int base = (lane - gl) * K;
-        const int a0 = base < n ? base : n;
-        const int a1 = base + L < n ? base + L : n;
-        const int b1 = base + 2 * L < n ? base + 2 * L : n;
+        const int a0 = base < np ? base : np;
+        const int a1 = base + L < np ? base + L : np;
+        const int b1 = base + 2 * L < np ? base + 2 * L : np;
         const int LA = a1 - a0, LB = b1 - a1;
         const int d0 = gl * K;
-        const int d = d0 < LA + LB ? d0 : LA + LB;
-        const int dend = d0 + K < LA + LB ? d0 + K : LA + LB;
+        const bool busy = d0 < LA + LB;  // this lane owns K outputs of the pair (LA + LB is a multiple of K)
+        const int d = busy ? d0 : LA + LB;
         // co-rank: smallest i with A[i] > B[d-1-i]; ties go to A (stable merge)
         int lo = d - LB > 0 ? d - LB : 0, hi = d < LA ? d : LA;
         const int nsteps = r + ceil_log2(K + 1);
+        const double* pa0 = row + a0;
+        const double* pb0 = row + a1 + d - 1;
 #pragma unroll 1
         for (int s = 0; s < nsteps; ++s) {
-            const bool act = lo < hi;
-            const int mid = (lo + hi) >> 1;
-            const double va = row[act ? a0 + mid : 0];
-            const double vb = row[act ? a1 + d - 1 - mid : 0];
-            const bool le = va <= vb;
-            lo = (act && le) ? mid + 1 : lo;
-            hi = (act && !le) ? mid : hi;
+            const int mid = (lo + hi) >> 1;          // lo == hi (finished lane): reads stay inside the row, updates are no-ops
+            const bool le = (pa0[mid] <= pb0[-mid]) && (lo < hi);
+            lo = le ? mid + 1 : lo;
+            hi = le ? hi : mid;
         }
         const int inext = __shfl_down(lo, 1, kWave);
-        const int ihi = (dend == LA + LB) ? LA : inext;  // co-rank of the end of this lane's window
-        const int cnt = dend - d;
-        const int acnt = ihi - lo, bcnt = cnt - acnt;
-        const int pa = a0 + lo;
-        const int qb = a1 + (d - lo) + bcnt - 1 + (K - bcnt);  // B window is read backwards: index qb - s
+        const int ihi = (d + K >= LA + LB) ? LA : inext;  // co-rank of the end of this lane's window
+        const int acnt = ihi - lo;                         // elements taken from A; K - acnt from B
         double w[K];
+        if (busy) {
+            const double* pa = row + a0 + lo;                       // A window, ascending: pa[s], s < acnt
+            const double* pq = row + a1 + (d - lo) + (K - acnt) - 1 + acnt;  // B window read backwards: pq[-s], s >= acnt
 #pragma unroll
-        for (int s = 0; s < K; ++s) {
-            const bool from_a = s < acnt, from_b = s >= K - bcnt;
-            const int idx = from_a ? pa + s : qb - s;
-            const double v = row[(from_a || from_b) ? idx : 0];
-            w[s] = (from_a || from_b) ? v : __builtin_inf();
-            if (s % 7 == 6) __builtin_amdgcn_sched_barrier(0);  // issue the loads in batches: bounds the address temporaries
-        }
+            for (int s = 0; s < K; ++s) {
+                const double* src = s < acnt ? pa : pq - 2 * s;     // (pq - 2s)[s] == pq[-s]
+                w[s] = src[s];
+                if (s % 7 == 6) __builtin_amdgcn_sched_barrier(0);  // issue the loads in batches
+            }
 #pragma unroll
-        for (int c = 0; c < net.n; ++c) {
-            const double mn = __builtin_fmin(w[net.a[c]], w[net.b[c]]);
-            const double mx = __builtin_fmax(w[net.a[c]], w[net.b[c]]);
-            w[net.a[c]] = mn;
-            w[net.b[c]] = mx;
+            for (int c = 0; c < net.n; ++c) {
+                const double mn = __builtin_fmin(w[net.a[c]], w[net.b[c]]);
+                const double mx = __builtin_fmax(w[net.a[c]], w[net.b[c]]);
+                w[net.a[c]] = mn;
+                w[net.b[c]] = mx;
+            }
         }
         wave_fence();
-        const int ob = a0 + d;
+        if (busy) {
+            double* dst = row + a0 + d;
 #pragma unroll
-        for (int s = 0; s < K; ++s) {
-            row[s < cnt ? ob + s : n] = w[net.out[s]];  // slot n is a write-only dump
-            if (s % 7 == 6) __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < K; ++s) dst[s] = w[net.out[s]];
         }
         wave_fence();
     }
 }
 
-// sort the wave's segment: v[] = K consecutive samples per lane (pads = +inf), result in row[0..n)
+// sort the wave's segment: v[] = K consecutive samples per lane (pads = +inf), result in row[0..n); the
+// row must have ceil(n / K) * K + 1 slots (the pads of the last run are stored and sorted like data).
 template <int K>
 __device__ __forceinline__ void sort_segment(double (&v)[K], double* row, int n, int lane) {
     sort_registers<K>(v);
-    const int base = K * lane;
+    const int np = (n + K - 1) / K * K;
+    if (K * lane < np) {
+        double* dst = row + K * lane;
 #pragma unroll
-    for (int i = 0; i < K; ++i) row[base + i < n ? base + i : n] = v[i];
+        for (int i = 0; i < K; ++i) dst[i] = v[i];
+    }
     wave_fence();
-    merge_rounds<K>(row, n, lane);
+    merge_rounds<K>(row, np, lane);
 }
 
 // ---- tile movement ------------------------------------------------------------------------------
@@ -731,8 +735,9 @@ int launch_mode(sd_ctx* ctx, const Params& p, int nmax, const char* name) {
 bool sd_bcsd_rs_supported(int nmax) { return nmax >= 1 && nmax <= 64 * 33; }
 
 int sd_bcsd_rs_row_stride(int nmax) {
-    int rs = nmax + 1;  // one readable slot past the end (merge heads)
-    while (rs % 8 != 2) ++rs;  // cell rows land 8 banks apart: conflict-free transposing stores
+    const int K = nmax <= 64 * 5 ? 5 : nmax <= 64 * 13 ? 13 : nmax <= 64 * 21 ? 21 : 33;  // as in launch_mode
+    int rs = (nmax + K - 1) / K * K + 1;  // the sort stores the +inf pads of the last run; one readable slot past the end
+    while (rs % 4 != 2) ++rs;  // cell rows land 8 or 24 banks apart: conflict-free transposing stores
     return rs;
 }
 
