@@ -443,7 +443,9 @@ __device__ void ols_line(const double* ysg, int first, int e, double denom, doub
 // ------------------------------------------------------------------------------------------------
 // OCC = waves per SIMD the register allocation is capped for: 4 -> 128 VGPRs (2 workgroups per CU),
 // 2 -> 256 VGPRs (1 workgroup per CU, no spills).
-template <int K, int MODE, int OCC, int KIND>
+// IDENT: every group has the same length in fit and predict, so the fitted inverse CDF evaluated at the
+// Cunnane position of rank r is exactly the r-th sorted observation (np.interp exact hit): no table needed.
+template <int K, int MODE, int OCC, int KIND, bool IDENT>
 __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) {
     constexpr bool kTas = KIND == SD_BCSD_TAS;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -626,7 +628,13 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
 
     // ---- map ranks through the fitted inverse CDF (quantile.py:523-545) ------------------------------
     double q[K];
-    {
+    if (IDENT) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int r = (int)((i & 1) ? (rank2[i >> 1] >> 16) : (rank2[i >> 1] & 0xffffu));
+            q[i] = row[r];
+        }
+    } else {
         double slo = 0.0, ilo = 0.0, shi = 0.0, ihi = 0.0;
         if (m > n && n > 0) {  // tails are reachable only when the predict segment is longer
             const int e = n < 10 ? n : 10;
@@ -697,16 +705,22 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
     if (!(p.ablate & 64)) store_tile(p.out, p.ld_out, p.ord_p + begp, m, c0, p.C, vec_o, tile, RS);
 }
 
-template <int K, int MODE, int OCC, int KIND>
-int launch_kok(sd_ctx* ctx, const Params& p, const char* name) {
+template <int K, int MODE, int OCC, int KIND, bool IDENT>
+int launch_koki(sd_ctx* ctx, const Params& p, const char* name) {
     const size_t lds = ((size_t)kW * p.RS + 64 + 16) * sizeof(double);
-    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_rs_kernel<K, MODE, OCC, KIND>),
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_rs_kernel<K, MODE, OCC, KIND, IDENT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t tx = (p.ntiles + 7) / 8;
     const int64_t nblocks = 8 * tx * p.G;
     SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "grid too large");
-    SD_LAUNCH(ctx, name, (bcsd_rs_kernel<K, MODE, OCC, KIND>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
+    SD_LAUNCH(ctx, name, (bcsd_rs_kernel<K, MODE, OCC, KIND, IDENT>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
     return SD_OK;
+}
+
+template <int K, int MODE, int OCC, int KIND>
+int launch_kok(sd_ctx* ctx, const Params& p, const char* name) {
+    if (MODE == MODE_APPLY && p.identity) return launch_koki<K, MODE, OCC, KIND, true>(ctx, p, name);
+    return launch_koki<K, MODE, OCC, KIND, false>(ctx, p, name);
 }
 
 template <int K, int MODE, int OCC>
