@@ -103,6 +103,53 @@ def test_vs_oracle_ragged_sizes(ctx, kind, C, T, Tp):
     assert_close(out, exp, what=f"ragged {kind} {C}x{T}->{Tp}")
 
 
+@pytest.mark.parametrize("T,Tp,C", [(365, 365, 6), (3650, 3650, 9), (8000, 8000, 8), (14600, 14600, 8), (14600, 20000, 5),
+                                    (14600, 3000, 3), (14600, 365, 4), (20000, 14600, 4), (24000, 24000, 3)])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_every_register_sort_width_split_and_fused(ctx, kind, T, Tp, C):
+    """Segment lengths from 31 to 2 046 samples exercise every K instantiation (5, 13, 21, 33) of the
+    register/LDS merge-sort kernels, in the split (fit, predict) and the fused (fit_predict) entry points,
+    with equal / longer / much shorter predict series (identity path, tail OLS path, table path)."""
+    rng = np.random.default_rng(T + Tp + kind)
+    index = pd.date_range("1980-01-01", periods=T, freq="D")
+    index_p = pd.date_range("1980-01-01", periods=Tp, freq="D")
+    if kind == 0:
+        X, y, Xp = (15 + 8 * rng.standard_normal((n, C)) for n in (T, T, Tp))
+    else:
+        X, y, Xp = (rng.gamma(0.7, 4.0, (n, C)) * (rng.random((n, C)) > 0.5) for n in (T, T, Tp))
+        y = y + 0.01
+    gid, gid_p = month_gid(index), month_gid(index_p)
+    exp, est = bo.pointwise_fit_predict(kind, X, y, Xp, gid, gid_p)
+    out, st = run_engine(ctx, kind, X, y, Xp, gid, gid_p)
+    assert np.array_equal(st, est)
+    assert_close(out, exp, what=f"split {kind} {T}->{Tp}")
+    fused, st = ctx.bcsd_fit_predict(kind, ctx.to_device(X), ctx.to_device(y), gid, 12, ctx.to_device(Xp), gid_p)
+    assert np.array_equal(st, est)
+    # same kernels; climatology sums are ordered by the register width K, which can differ between the fit
+    # launch (sized for the fit segments) and the fused launch (sized for the longer of fit / predict)
+    assert_close(fused.to_host(), out, rtol=1e-12, what=f"fused vs split {kind} {T}->{Tp}")
+    assert_close(fused.to_host(), exp, what=f"fused {kind} {T}->{Tp}")
+
+
+def test_generic_lds_kernels_still_agree(ctx, monkeypatch):
+    """SD_BCSD_PATH=v1 forces the generic LDS-bitonic kernels (fallback for segments > 2 112 samples)."""
+    monkeypatch.setenv("SD_BCSD_PATH", "v1")
+    g = load("g1_tas_small")
+    index, index_p, X, y, Xp = tas_inputs(g)
+    out, st = run_engine(ctx, 0, X, y, Xp, month_gid(index), month_gid(index_p))
+    assert_close(out, g["out_anoms"], what="generic kernels")
+    # a segment longer than the register-sort limit takes the generic path by itself
+    rng = np.random.default_rng(3)
+    T = 2300 * 2
+    gid = (np.arange(T) % 2).astype(np.int32)
+    X, y, Xp = (10 + rng.standard_normal((T, 3)) for _ in range(3))
+    monkeypatch.delenv("SD_BCSD_PATH")
+    exp, _ = bo.pointwise_fit_predict(0, X, y, Xp, gid, gid, G=2)
+    st2 = ctx.bcsd_fit(0, X, y, gid, 2, True)
+    out2, _ = ctx.bcsd_predict(st2, Xp, gid)
+    assert_close(out2, exp, what="long segments")
+
+
 def test_state_export_import_roundtrip(ctx):
     g = load("g1_tas_small")
     index, index_p, X, y, Xp = tas_inputs(g)
