@@ -356,6 +356,13 @@ int rs_ablate() {
     return e ? atoi(e) : 0;
 }
 
+// RANK -> APPLY shift slab (8 more bytes/sample through HBM each way, ~15 % fewer instructions in APPLY);
+// SD_RS_SHIFT=0 makes APPLY re-read the x_fut tile and recompute the rolling mean instead.
+bool rs_shift_slab() {
+    const char* e = getenv("SD_RS_SHIFT");
+    return !(e && e[0] == '0');
+}
+
 bool use_rs_path(int nmax) {
     const char* e = getenv("SD_BCSD_PATH");  // "v1" forces the generic LDS-bitonic kernels (A/B testing)
     if (e && e[0] == 'v' && e[1] == '1') return false;
@@ -552,11 +559,13 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
         p.identity = (st->goff == gt.host_off) ? 1 : 0;
         p.ablate = rs_ablate();
         p.from_state = 1;
-        const size_t rank_bytes = sizeof(uint16_t) * (size_t)Tp * C;
+        size_t rank_bytes = 0, shift_bytes = 0;
+        sd_bcsd_rs_handoff_bytes(nmax_all, C, st->G, &rank_bytes, &shift_bytes);
+        if (st->kind != SD_BCSD_TAS || !rs_shift_slab()) shift_bytes = 0;
         void* ws = nullptr;
-        SD_TRY(sd_workspace(ctx, rank_bytes, &ws));
-        p.ranks = static_cast<uint16_t*>(ws);
-        p.Tp = Tp;
+        SD_TRY(sd_workspace(ctx, rank_bytes + shift_bytes, &ws));
+        p.ranks = static_cast<uint32_t*>(ws);
+        p.shift = shift_bytes ? reinterpret_cast<double*>(static_cast<char*>(ws) + rank_bytes) : nullptr;
         SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_RANK, p, nmax_all));
         SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_APPLY, p, nmax_all));
     } else
@@ -625,12 +634,14 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
         // Two kernels, no persisted sorted state: RANK writes 2 bytes/sample (rank of every x_fut sample in its
         // shifted segment) + x_climo; APPLY sorts y_obs on chip, maps the ranks and restores the shift.  (One
         // monolithic kernel needs > 128 VGPRs; its spills tripled the HBM traffic -- profiles/r01/pmc_*.csv.)
-        const size_t rank_bytes = ((sizeof(uint16_t) * (size_t)Tp * C + 255) / 256) * 256;
+        size_t rank_bytes = 0, shift_bytes = 0;
+        sd_bcsd_rs_handoff_bytes(nmax_all, C, G, &rank_bytes, &shift_bytes);
+        if (kind != SD_BCSD_TAS || !rs_shift_slab()) shift_bytes = 0;
         void* ws = nullptr;
-        SD_TRY(sd_workspace(ctx, rank_bytes + sizeof(double) * (size_t)G * C, &ws));
-        p.ranks = static_cast<uint16_t*>(ws);
-        p.Tp = Tp;
-        p.x_climo = reinterpret_cast<double*>(static_cast<char*>(ws) + rank_bytes);
+        SD_TRY(sd_workspace(ctx, rank_bytes + shift_bytes + sizeof(double) * (size_t)G * C, &ws));
+        p.ranks = static_cast<uint32_t*>(ws);
+        p.shift = shift_bytes ? reinterpret_cast<double*>(static_cast<char*>(ws) + rank_bytes) : nullptr;
+        p.x_climo = reinterpret_cast<double*>(static_cast<char*>(ws) + rank_bytes + shift_bytes);
         SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_RANK, p, nmax_all));
         SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_APPLY, p, nmax_all));
     }

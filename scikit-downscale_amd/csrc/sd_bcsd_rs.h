@@ -4,9 +4,9 @@
 
 namespace sdrs {
 
-// MODE_RANK + MODE_APPLY = the fused path as two kernels: RANK ranks every x_fut sample within its shifted
-// segment (2 bytes/sample, cell-major), APPLY sorts y_obs, maps the ranks and restores the shift.
-enum { MODE_FIT = 0, MODE_PREDICT = 1, MODE_FUSED = 2, MODE_RANK = 3, MODE_APPLY = 4 };
+// MODE_RANK + MODE_APPLY = fit+predict (or predict from a state) as two kernels: RANK ranks every x_fut sample
+// within its shifted segment, APPLY sorts y_obs (or reads the fitted state), maps the ranks and restores the shift.
+enum { MODE_FIT = 0, MODE_RANK = 3, MODE_APPLY = 4 };
 
 struct Params {
     int kind, G, return_anoms, RS;
@@ -19,9 +19,11 @@ struct Params {
     const int32_t* qidx; const double* qval;           // inverse-CDF tables, indexed off_p[g] + rank
     double* ys; double* x_climo; double* y_climo;      // state: [C][Tf], [C][G], [C][G]
     int32_t* status_fit; int32_t* status_p;
-    uint16_t* ranks; int64_t Tp;                       // MODE_RANK / MODE_APPLY: ranks [C][Tp], cell-major
+    uint32_t* ranks;                                   // RANK -> APPLY: [C*G][(K+1)/2][64] packed 16-bit ranks
+    double* shift;                                     // RANK -> APPLY (TAS, optional): [C*G][K][64] rolling mean - x_climo
     int from_state;  // RANK/APPLY: 1 = predict from a fitted state (x_climo, y_climo, ys given), 0 = fit on the fly from X, y
     int identity;  // 1: every group has equal fit / predict length (inverse CDF = identity on ranks)
+    int first_generation, stagger_ticks;  // set by the launcher: staggered start of the first wave of workgroups
     int ablate;  // development knob (SD_RS_ABLATE bitmask): skip phases to measure their marginal cost
 };
 
@@ -29,4 +31,6 @@ struct Params {
 
 bool sd_bcsd_rs_supported(int nmax);
 int sd_bcsd_rs_row_stride(int nmax);
+// workspace bytes of the RANK -> APPLY hand-off slabs (both multiples of 256)
+void sd_bcsd_rs_handoff_bytes(int nmax, int64_t C, int G, size_t* rank_bytes, size_t* shift_bytes);
 int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax);

@@ -43,6 +43,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 // Lanes of one wave exchange data through LDS inside the sort.  The hardware serves a wave's LDS
 // requests in order; for the compiler the exchange needs a wavefront-scope fence plus the wave barrier.
+// min/max straight to the hardware instructions: __builtin_fmin/fmax make the compiler canonicalise every
+// freshly loaded operand first (one extra v_max_f64 x,x per element and merge round).  NaNs never reach the
+// sort of a cell whose result is kept (such cells are flagged non-finite and overwritten with NaN).
+__device__ __forceinline__ double vmin(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmax(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -75,8 +88,8 @@ __device__ __forceinline__ void sort_registers(double (&v)[K]) {
     constexpr Net<K> net{};
 #pragma unroll
     for (int c = 0; c < net.n; ++c) {
-        const double lo = __builtin_fmin(v[net.a[c]], v[net.b[c]]);
-        const double hi = __builtin_fmax(v[net.a[c]], v[net.b[c]]);
+        const double lo = vmin(v[net.a[c]], v[net.b[c]]);
+        const double hi = vmax(v[net.a[c]], v[net.b[c]]);
         v[net.a[c]] = lo;
         v[net.b[c]] = hi;
     }
@@ -172,8 +185,8 @@ __device__ __forceinline__ void merge_rounds(double* row, int np, int lane) {
             }
 #pragma unroll
             for (int c = 0; c < net.n; ++c) {
-                const double mn = __builtin_fmin(w[net.a[c]], w[net.b[c]]);
-                const double mx = __builtin_fmax(w[net.a[c]], w[net.b[c]]);
+                const double mn = vmin(w[net.a[c]], w[net.b[c]]);
+                const double mx = vmax(w[net.a[c]], w[net.b[c]]);
                 w[net.a[c]] = mn;
                 w[net.b[c]] = mx;
             }
@@ -339,67 +352,22 @@ __device__ __forceinline__ void load_blocked(const double* row, int cnt, int lan
     }
 }
 
-// rolling(9, center=True, min_periods=1).mean() at register i of the lane (bcsd.py:247-250).
-// The lane holds K consecutive samples x[]; nb[0..3] / nb[4..7] are the 4 samples before / after them
-// (from the neighbouring lanes).  Samples outside [0, m) are 0 and the divisor is the clipped count.
-template <int K>
-struct Halo {
-    static_assert(K >= 4, "the 4-sample halo must come from the adjacent lane only");
-    double nb[8];
-};
-
-template <int K>
-__device__ __forceinline__ Halo<K> build_halo(const double (&x)[K], int lane) {
-    Halo<K> h;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        // K < 4: the 4-sample halo spans more than one neighbouring lane -> use the generic shuffle distance
-        const double l = __shfl_up(x[(K - 4 + k) >= 0 ? (K - 4 + k) : 0], 1, kWave);
-        const double r = __shfl_down(x[k < K ? k : K - 1], 1, kWave);
-        h.nb[k] = lane == 0 ? 0.0 : l;
-        h.nb[4 + k] = lane == kWave - 1 ? 0.0 : r;
-    }
-    return h;
+// 9-sample centred rolling means (bcsd.py:247-250) for CH consecutive samples j0..j0+CH-1 of the wave's
+// segment, which sits in its LDS row in time order *at offset 4 with zeros on both sides* (zero_pads): the
+// CH+8 window values are plain reads at immediate offsets (lane stride K is odd: conflict-free), samples
+// outside [0, m) contribute 0 and the divisor is the clipped window length.
+constexpr int kPadFront = 4;
+__device__ __forceinline__ void zero_pads(double* row, int m, int lane, int nback) {
+    if (lane < kPadFront) row[lane] = 0.0;
+    if (lane < nback) row[kPadFront + m + lane] = 0.0;
 }
-
-template <int K>
-__device__ __forceinline__ double window_at(const double (&x)[K], const Halo<K>& h, int p /* -4 .. K+3, static */) {
-    return p < 0 ? h.nb[4 + p] : (p >= K ? h.nb[4 + (p - K)] : x[p]);
-}
-
-template <int K>
-__device__ __forceinline__ double rolling_at(const double (&x)[K], const Halo<K>& h, int i, int j, int m,
-                                             const double* rcp /* LDS: 1/c for c = 0..9 */) {
-    double s = 0.0;
-#pragma unroll
-    for (int d = -4; d <= 4; ++d) s += window_at<K>(x, h, i + d);
-    const int lo = j - 4 > 0 ? j - 4 : 0;
-    const int hi = j + 5 < m ? j + 5 : m;
-    // s / count, correctly rounded like the reference's division but without the ~12-instruction
-    // division sequence: rcp[] holds the correctly rounded reciprocals of 1..9; one Markstein
-    // correction step (q + (s - c*q) * (1/c)) yields the correctly rounded quotient for these divisors.
-    const int c = hi - lo > 1 ? hi - lo : 1;
-    const double cd = (double)c;
-    const double rc = rcp[c];
-    const double q = s * rc;
-    return __builtin_fma(__builtin_fma(-cd, q, s), rc, q);
-}
-
-
-// 9-sample centred rolling means for CH consecutive samples j0..j0+CH-1 read straight from the wave's LDS
-// row (segment in time order): the CH+8 window values are read once (lane stride K is odd: conflict-free),
-// samples outside [0, m) count as 0, the divisor is the clipped window length (bcsd.py:247-250).
 template <int CH>
 __device__ __forceinline__ void rolling_from_lds(const double* row, int j0, int m, const double* rcp, double (&mean)[CH],
                                                  double (&centre)[CH]) {
+    const double* win = row + (j0 < m ? j0 : 0);  // win[t] = sample j0 - 4 + t; lanes past the segment read in bounds
     double w[CH + 8];
 #pragma unroll
-    for (int t = 0; t < CH + 8; ++t) {
-        const int j = j0 - 4 + t;
-        const bool in = j >= 0 && j < m;
-        const double v = row[in ? j : 0];
-        w[t] = in ? v : 0.0;
-    }
+    for (int t = 0; t < CH + 8; ++t) w[t] = win[t];
 #pragma unroll
     for (int ii = 0; ii < CH; ++ii) {
         double s = 0.0;
@@ -441,35 +409,45 @@ __device__ void ols_line(const double* ysg, int first, int e, double denom, doub
 }
 
 // ------------------------------------------------------------------------------------------------
+// Samples handled together in the rolling / search / lookup phases (bounded register pressure).
+template <int K>
+struct Chunk {
+    static constexpr int CH = K >= 14 ? (K + 2) / 3 : K;
+};
+
+// LDS read at an absolute 32-bit LDS byte address (the search keeps positions as addresses)
+typedef __attribute__((address_space(3))) const double lds_cdouble_t;
+__device__ __forceinline__ double lds_f64(unsigned addr) { return *reinterpret_cast<lds_cdouble_t*>((uintptr_t)addr); }
+__device__ __forceinline__ unsigned lds_addr(const void* generic_ptr_into_lds) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)generic_ptr_into_lds;
+}
+
 // OCC = waves per SIMD the register allocation is capped for: 4 -> 128 VGPRs (2 workgroups per CU),
-// 2 -> 256 VGPRs (1 workgroup per CU, no spills).
+// 2 -> 256 VGPRs (1 workgroup per CU).
 // IDENT: every group has the same length in fit and predict, so the fitted inverse CDF evaluated at the
 // Cunnane position of rank r is exactly the r-th sorted observation (np.interp exact hit): no table needed.
-template <int K, int MODE, int OCC, int KIND, bool IDENT>
-__global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) {
+//
+// Hand-off between MODE_RANK and MODE_APPLY (context workspace, one slab per (cell, group) segment, written
+// and read with the same lane layout so every access is a fully coalesced 256/512-byte wave transaction):
+//   ranks: [segment][(K+1)/2][64] u32 -- two 16-bit ranks per word, exactly the rank2[] registers
+//   shift: [segment][K][64] f64       -- rolling mean - x_climo of every sample (TAS, optional: when absent
+//                                        APPLY re-reads the x_fut tile and recomputes it)
+template <int K, int MODE, int KIND, bool IDENT>
+__device__ __forceinline__ void segment_body(const Params& p, const int64_t tile_id, const int g, char* smem_raw) {
+    static_assert(MODE == MODE_FIT || MODE == MODE_RANK || MODE == MODE_APPLY, "unknown mode");
     constexpr bool kTas = KIND == SD_BCSD_TAS;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int CH = Chunk<K>::CH;
+    constexpr int NR = (K + 1) / 2;
     double* tile = reinterpret_cast<double*>(smem_raw);
     const int RS = p.RS;
     double* scratch = tile + kW * RS;  // 64 doubles
-    double* rcp = scratch + 64;        // 16 doubles: correctly rounded 1/c, c = 1..9
-    if (threadIdx.x < 16) {
-        const double tab[16] = {0.0, 1.0, 0.5, 1.0 / 3.0, 0.25, 0.2, 1.0 / 6.0, 1.0 / 7.0, 0.125, 1.0 / 9.0, 0, 0, 0, 0, 0, 0};
-        rcp[threadIdx.x] = tab[threadIdx.x];
-    }
-
-    // XCD-aware workgroup -> (tile, group): XCD x owns tiles [x*tx, (x+1)*tx)
-    const int64_t tx = (p.ntiles + 7) / 8;
-    const int xcd = blockIdx.x & 7;
-    const int64_t jb = blockIdx.x >> 3;
-    const int64_t tile_id = xcd * tx + jb % tx;
-    const int g = (int)(jb / tx);
-    if (tile_id >= p.ntiles || g >= p.G) return;
+    const double* rcp = scratch + 64;  // 16 doubles: correctly rounded 1/c, c = 1..9
     const int64_t c0 = tile_id * kW;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int64_t c = c0 + wave;
     const bool cell_ok = c < p.C;
     double* row = tile + wave * RS;
+    const int64_t seg = c * p.G + g;
 
     const int begf = p.off_f[g], n = p.off_f[g + 1] - begf;
     int begp = 0, m = 0;
@@ -482,56 +460,44 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
     }
     const bool vec_f = (p.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
                        (p.X == nullptr || (reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
+    const bool vec_p = MODE != MODE_FIT && (p.ld_p % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.Xp) & 15) == 0);
 
     // ---- x climatology (bcsd.py:222); PR only validates X ------------------------------------------
     double xc = 0.0;
     if (MODE == MODE_APPLY || (MODE == MODE_RANK && p.from_state)) {
-        if (kTas && cell_ok) xc = p.x_climo[c * p.G + g];
-    } else if (MODE != MODE_PREDICT) {
-        if (p.X != nullptr && n > 0 && !(p.ablate & 32)) {
-            xc = tile_column_mean<(K + 1) / 2>(p.X, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, scratch, p.status_fit, wave, lane);
-            if ((MODE == MODE_FIT || MODE == MODE_RANK) && kTas && lane == 0 && cell_ok) p.x_climo[c * p.G + g] = xc;
-        }
-    } else if (kTas && cell_ok) {
-        xc = p.x_climo[c * p.G + g];
+        if (kTas && cell_ok) xc = p.x_climo[seg];
+    } else if (p.X != nullptr && n > 0 && !(p.ablate & 32)) {
+        xc = tile_column_mean<NR>(p.X, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, scratch, p.status_fit, wave, lane);
+        if (kTas && lane == 0 && cell_ok) p.x_climo[seg] = xc;
     }
 
-    constexpr int CH = K >= 14 ? (K + 2) / 3 : K;  // samples processed together in the search / lookup phases
-    unsigned rank2[(K + 1) / 2];  // two 16-bit ranks per register (segments are < 65536 samples)
-#pragma unroll
-    for (int i = 0; i < (K + 1) / 2; ++i) rank2[i] = 0u;
-    const bool vec_p = MODE != MODE_FIT && (p.ld_p % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.Xp) & 15) == 0);
-    if (MODE == MODE_APPLY) {
-        if (cell_ok) {
-            const uint16_t* rk = p.ranks + c * p.Tp + begp + K * lane;
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const unsigned v = K * lane + i < m ? rk[i] : 0u;
-                rank2[i >> 1] |= (i & 1) ? (v << 16) : v;
-            }
-        }
-    } else if (MODE != MODE_FIT) {
-        load_tile<(K + 1) / 2>(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile, RS, p.status_p);
+    if (MODE == MODE_RANK) {
+        // ---- x_fut segment -> shifted series u -> rank of every sample in sort(u) --------------------
+        load_tile<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile + kPadFront, RS, p.status_p);
+        if (kTas) zero_pads(row, m, lane, CH + 4);
         __syncthreads();
         double u[K];  // u = X - (rolling mean - x_climo) (bcsd.py:247-256); PR maps raw X (bcsd.py:167)
+        double* sh = (kTas && p.shift != nullptr && cell_ok) ? p.shift + (seg * K) * kWave + lane : nullptr;
 #pragma unroll
         for (int cbeg = 0; cbeg < K; cbeg += CH) {
             double mean[CH], xv[CH];
             if (kTas) {
                 rolling_from_lds<CH>(row, K * lane + cbeg, m, rcp, mean, xv);
             } else {
+                const double* src = row + kPadFront + (K * lane + cbeg < m ? K * lane + cbeg : 0);
 #pragma unroll
-                for (int ii = 0; ii < CH; ++ii) {
-                    const int j = K * lane + cbeg + ii;
-                    xv[ii] = row[j < m ? j : 0];
-                    mean[ii] = 0.0;
-                }
+                for (int ii = 0; ii < CH; ++ii) xv[ii] = src[ii];
             }
 #pragma unroll
             for (int ii = 0; ii < CH; ++ii) {
                 const int i = cbeg + ii;
                 if (i < K) {
-                    const double uv = kTas ? xv[ii] - (mean[ii] - xc) : xv[ii];  // bcsd.py:253-256
+                    double uv = xv[ii];
+                    if (kTas) {
+                        const double shift = mean[ii] - xc;  // bcsd.py:253
+                        uv = xv[ii] - shift;                 // bcsd.py:256
+                        if (sh != nullptr) sh[i * kWave] = shift;
+                    }
                     u[i] = K * lane + i < m ? uv : __builtin_inf();
                 }
             }
@@ -545,57 +511,64 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
             sort_segment<K>(s, row, m, lane);  // self ECDF: np.sort(u) (quantile.py:462 via 505-521)
         }
         // rank = (#sorted <= u) - 1: np.interp's exact-hit index = max rank among ties (quantile.py:488).
-        // Branch-free binary search, CH independent chains at a time (bounded register pressure).
-        int top = 1;
-        while (top * 2 <= m) top *= 2;
-        {
-            const double wsel = row[m - top];
+        // Branch-free binary search (len -> len - len/2 per step, the same wave-uniform stride for every lane),
+        // CH independent chains at a time; positions are kept as LDS byte addresses (add, compare, select per
+        // step).  A stride that is a multiple of 16 doubles would put the probes of all lanes on one or two
+        // banks (the 2^k candidates of step k are whole strides apart): such strides are shortened by one.
+        unsigned rank2[NR];  // two 16-bit ranks per register (segments are < 65536 samples)
 #pragma unroll
-            for (int cbeg = 0; cbeg < K; cbeg += CH) {
-                int pos[CH];
+        for (int i = 0; i < NR; ++i) rank2[i] = 0u;
+        const unsigned rowb = lds_addr(row);
+#pragma unroll
+        for (int cbeg = 0; cbeg < K; cbeg += CH) {
+            unsigned pb[CH];  // byte address of sorted[base - 1]
+#pragma unroll
+            for (int ii = 0; ii < CH; ++ii) pb[ii] = rowb - 8u;
+#pragma unroll 1
+            for (int len = (p.ablate & 2) ? 1 : m; len > 1;) {
+                int half = len >> 1;
+                if ((half & 15) == 0) --half;
+                len -= half;
+                const unsigned h8 = (unsigned)half * 8u;
 #pragma unroll
                 for (int ii = 0; ii < CH; ++ii) {
                     const int i = cbeg + ii < K ? cbeg + ii : K - 1;
-                    pos[ii] = wsel <= u[i] ? m - top : 0;
+                    const unsigned t = pb[ii] + h8;
+                    pb[ii] = lds_f64(t) <= u[i] ? t : pb[ii];
                 }
-#pragma unroll 1
-                for (int half = (p.ablate & 2) ? 0 : top >> 1; half >= 1; half >>= 1) {
-#pragma unroll
-                    for (int ii = 0; ii < CH; ++ii) {
-                        const int i = cbeg + ii < K ? cbeg + ii : K - 1;
-                        const double v = row[pos[ii] + half - 1];
-                        pos[ii] += v <= u[i] ? half : 0;
-                    }
-                }
-#pragma unroll
-                for (int ii = 0; ii < CH; ++ii) {
-                    const int i = cbeg + ii;
-                    if (i < K) {
-                        const int cnt = pos[ii] + (row[pos[ii]] <= u[i] ? 1 : 0);
-                        const unsigned rk = (unsigned)(cnt > 0 ? cnt - 1 : 0);
-                        rank2[i >> 1] |= (i & 1) ? (rk << 16) : rk;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        if (MODE == MODE_RANK) {
-            if (cell_ok) {
-                uint16_t* rk = p.ranks + c * p.Tp + begp + K * lane;
 #pragma unroll
-                for (int i = 0; i < K; ++i)
-                    if (K * lane + i < m) rk[i] = (uint16_t)((i & 1) ? (rank2[i >> 1] >> 16) : (rank2[i >> 1] & 0xffffu));
+            for (int ii = 0; ii < CH; ++ii) {
+                const int i = cbeg + ii;
+                if (i < K) {
+                    const int below = (int)(pb[ii] - rowb) >> 3;  // base - 1
+                    const int r = below + (lds_f64(pb[ii] + 8u) <= u[i] ? 1 : 0);
+                    const unsigned rk = (unsigned)(r > 0 ? r : 0);
+                    rank2[i >> 1] |= (i & 1) ? (rk << 16) : rk;
+                }
             }
-            return;
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();  // every wave is done with its x_fut row: the tile is reused for y
+        if (cell_ok) {
+            uint32_t* rk = p.ranks + (seg * NR) * kWave + lane;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) rk[i * kWave] = rank2[i];
+        }
+        return;
+    }
+
+    unsigned rank2[NR];
+    if (MODE == MODE_APPLY) {  // issued first: the loads fly while y is sorted
+        const uint32_t* rk = p.ranks + (seg * NR) * kWave + lane;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) rank2[i] = cell_ok ? rk[i * kWave] : 0u;
     }
 
     // ---- y: climatology + sorted segment in the wave's row ------------------------------------------
     double yc = 0.0;
-    if (MODE != MODE_PREDICT && !(MODE == MODE_APPLY && p.from_state)) {
+    if (!(MODE == MODE_APPLY && p.from_state)) {
         if (n > 0) {
-            load_tile<(K + 1) / 2>(p.y, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, tile, RS, p.status_fit);
+            load_tile<NR>(p.y, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, tile, RS, p.status_fit);
             __syncthreads();
             double v[K];
             load_blocked<K>(row, n, lane, 0.0, v);
@@ -604,7 +577,7 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
             for (int i = 0; i < K; ++i) s += v[i];
             yc = wave_sum(s) / (double)n;  // bcsd.py:223 / 138
             if (lane == 0 && cell_ok) {
-                if (MODE == MODE_FIT) p.y_climo[c * p.G + g] = yc;
+                if (MODE == MODE_FIT) p.y_climo[seg] = yc;
                 if (!kTas && p.return_anoms && yc <= 0.0) atomicOr(&p.status_fit[c], SDI_BAD_CLIMO);  // bcsd.py:140-141
             }
 #pragma unroll
@@ -618,7 +591,7 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
         }
     } else {
         if (cell_ok) {
-            yc = p.y_climo[c * p.G + g];
+            yc = p.y_climo[seg];
             const double* src = p.ys + c * p.Tf + begf;
             for (int i = lane; i < n; i += kWave) row[i] = src[i];
         }
@@ -669,32 +642,44 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
 
     // ---- restore the climate-trend shift (bcsd.py:263-267) / ratio anomalies (bcsd.py:170-185) ------
     if (kTas) {
-        // The x_fut tile is read a second time (this workgroup fetched it moments ago: L2 / Infinity
-        // Cache): keeping the 2K sample registers alive across the y phase instead forces spills, which
-        // PMC counters showed as ~3x the algorithmic HBM traffic (profiles/r01/pmc_*.csv).
-        __syncthreads();  // all lookups done: rows are free again
-        load_tile<(K + 1) / 2>(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile, RS, p.status_p);
-        __syncthreads();
+        if (p.shift != nullptr) {
+            if (cell_ok) {
+                const double* sh = p.shift + (seg * K) * kWave + lane;
 #pragma unroll
-        for (int cbeg = 0; cbeg < K; cbeg += CH) {
-            double mean[CH], xv[CH];
-            rolling_from_lds<CH>(row, K * lane + cbeg, m, rcp, mean, xv);
-#pragma unroll
-            for (int ii = 0; ii < CH; ++ii) {
-                const int i = cbeg + ii;
-                if (i < K) {
-                    double res = (mean[ii] - xc) + q[i];     // bcsd.py:253,263
-                    if (p.return_anoms) res = res - yc;      // bcsd.py:266-267
+                for (int i = 0; i < K; ++i) {
+                    double res = sh[i * kWave] + q[i];   // bcsd.py:253,263
+                    if (p.return_anoms) res = res - yc;  // bcsd.py:266-267
                     q[i] = res;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // No shift slab: read the x_fut tile a second time (this workgroup's RANK twin fetched it moments
+            // ago: L2 / Infinity Cache) and recompute the rolling mean.
+            __syncthreads();  // all lookups done: rows are free again
+            load_tile<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile + kPadFront, RS, p.status_p);
+            zero_pads(row, m, lane, CH + 4);
+            __syncthreads();
+#pragma unroll
+            for (int cbeg = 0; cbeg < K; cbeg += CH) {
+                double mean[CH], xv[CH];
+                rolling_from_lds<CH>(row, K * lane + cbeg, m, rcp, mean, xv);
+#pragma unroll
+                for (int ii = 0; ii < CH; ++ii) {
+                    const int i = cbeg + ii;
+                    if (i < K) {
+                        double res = (mean[ii] - xc) + q[i];  // bcsd.py:253,263
+                        if (p.return_anoms) res = res - yc;   // bcsd.py:266-267
+                        q[i] = res;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     } else {
 #pragma unroll
         for (int i = 0; i < K; ++i) q[i] = p.return_anoms ? q[i] / yc : q[i];  // bcsd.py:170-185
     }
-    wave_fence();
+    wave_fence();  // the wave's own row is rewritten in time order
     {
         const int base = K * lane;
 #pragma unroll
@@ -705,6 +690,45 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
     if (!(p.ablate & 64)) store_tile(p.out, p.ld_out, p.ord_p + begp, m, c0, p.C, vec_o, tile, RS);
 }
 
+// Every segment is a memory phase (tile loads) followed by a long compute phase (sort, search).  All
+// workgroups are alike, so without help the whole chip runs in lockstep: HBM saturated while everybody loads,
+// idle while everybody sorts, kernel time = the sum of the two.  The first generation of workgroups (the ones
+// that find the chip empty) therefore starts staggered over one workgroup duration; equal durations keep the
+// offsets alive for the rest of the launch.  The two workgroups of a tile pair (the 64-byte halves of the same
+// 128-byte lines) keep a common offset.
+__device__ __forceinline__ void stagger_first_generation(const Params& p) {
+    if (p.stagger_ticks <= 0 || blockIdx.x >= (unsigned)p.first_generation) return;
+    const unsigned pair = blockIdx.x >> 4, xcd = blockIdx.x & 7;
+    unsigned h = (pair * 8u + xcd) * 2654435761u;
+    h ^= h >> 15;
+    const long long wait = (long long)(h % 61u) * p.stagger_ticks / 61;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(64);
+}
+
+template <int K, int MODE, int OCC, int KIND, bool IDENT>
+__global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    {
+        double* rcp = reinterpret_cast<double*>(smem_raw) + kW * p.RS + 64;
+        if (threadIdx.x < 16) {
+            const double tab[16] = {0.0, 1.0, 0.5, 1.0 / 3.0, 0.25, 0.2, 1.0 / 6.0, 1.0 / 7.0, 0.125, 1.0 / 9.0, 0, 0, 0, 0, 0, 0};
+            rcp[threadIdx.x] = tab[threadIdx.x];
+        }
+    }
+    stagger_first_generation(p);
+    // XCD-aware workgroup -> (tile, group): workgroup b runs on XCD b % 8; XCD x owns tiles [x*tx, (x+1)*tx)
+    // and walks them tile-fastest, so the two 64-byte halves of a 128-byte line are fetched by workgroups
+    // that are adjacent in time on the same L2.
+    const int64_t tx = (p.ntiles + 7) / 8;
+    const int xcd = blockIdx.x & 7;
+    const int64_t jb = blockIdx.x >> 3;
+    const int64_t tile_id = xcd * tx + jb % tx;
+    const int g = (int)(jb / tx);
+    if (tile_id >= p.ntiles || g >= p.G) return;
+    segment_body<K, MODE, KIND, IDENT>(p, tile_id, g, smem_raw);
+}
+
 template <int K, int MODE, int OCC, int KIND, bool IDENT>
 int launch_koki(sd_ctx* ctx, const Params& p, const char* name) {
     const size_t lds = ((size_t)kW * p.RS + 64 + 16) * sizeof(double);
@@ -713,7 +737,12 @@ int launch_koki(sd_ctx* ctx, const Params& p, const char* name) {
     const int64_t tx = (p.ntiles + 7) / 8;
     const int64_t nblocks = 8 * tx * p.G;
     SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "grid too large");
-    SD_LAUNCH(ctx, name, (bcsd_rs_kernel<K, MODE, OCC, KIND, IDENT>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
+    Params q = p;
+    q.first_generation = ctx->cu_count * (lds * 2 <= ctx->lds_max && OCC >= 4 ? 2 : 1);
+    // one workgroup lasts roughly 2 us per register-sort width unit (100 MHz ticks); SD_RS_STAGGER_US overrides
+    const char* e = getenv("SD_RS_STAGGER_US");
+    q.stagger_ticks = (int)((e ? atof(e) : 2.0 * K) * 100.0);
+    SD_LAUNCH(ctx, name, (bcsd_rs_kernel<K, MODE, OCC, KIND, IDENT>), dim3((unsigned)nblocks), dim3(kThreads), lds, q);
     return SD_OK;
 }
 
@@ -748,11 +777,22 @@ int launch_mode(sd_ctx* ctx, const Params& p, int nmax, const char* name) {
 // Entry points used by sd_bcsd.hip ---------------------------------------------------------------
 bool sd_bcsd_rs_supported(int nmax) { return nmax >= 1 && nmax <= 64 * 33; }
 
+static int rs_width(int nmax) { return nmax <= 64 * 5 ? 5 : nmax <= 64 * 13 ? 13 : nmax <= 64 * 21 ? 21 : 33; }  // as in launch_mode
+
 int sd_bcsd_rs_row_stride(int nmax) {
-    const int K = nmax <= 64 * 5 ? 5 : nmax <= 64 * 13 ? 13 : nmax <= 64 * 21 ? 21 : 33;  // as in launch_mode
+    const int K = rs_width(nmax);
+    const int CH = K >= 14 ? (K + 2) / 3 : K;
     int rs = (nmax + K - 1) / K * K + 1;  // the sort stores the +inf pads of the last run; one readable slot past the end
+    const int roll = sdrs::kPadFront + nmax + CH + 4;  // time-ordered segment with zero pads for the rolling windows
+    if (rs < roll) rs = roll;
     while (rs % 4 != 2) ++rs;  // cell rows land 8 or 24 banks apart: conflict-free transposing stores
     return rs;
+}
+
+void sd_bcsd_rs_handoff_bytes(int nmax, int64_t C, int G, size_t* rank_bytes, size_t* shift_bytes) {
+    const size_t K = (size_t)rs_width(nmax), segs = (size_t)C * (size_t)G;
+    *rank_bytes = segs * ((K + 1) / 2) * 64 * sizeof(uint32_t);
+    *shift_bytes = segs * K * 64 * sizeof(double);
 }
 
 int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax) {
