@@ -23,7 +23,7 @@ struct Params {
     double* shift;                                     // RANK -> APPLY (TAS, optional): [C*G][K][64] rolling mean - x_climo
     int from_state;  // RANK/APPLY: 1 = predict from a fitted state (x_climo, y_climo, ys given), 0 = fit on the fly from X, y
     int identity;  // 1: every group has equal fit / predict length (inverse CDF = identity on ranks)
-    int first_generation, stagger_ticks;  // set by the launcher: staggered start of the first wave of workgroups
+    long long* trace;  // development: per-phase wall-clock stamps of sampled workgroups (SD_RS_TRACE=1)
     int ablate;  // development knob (SD_RS_ABLATE bitmask): skip phases to measure their marginal cost
 };
 

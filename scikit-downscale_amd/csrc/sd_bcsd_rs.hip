@@ -220,50 +220,70 @@ __device__ __forceinline__ void sort_segment(double (&v)[K], double* row, int n,
 // rows of one group for the 8 cells of the tile -> LDS rows (cell-major).  16-byte loads when possible.
 // A thread owns rows rr, rr+128, ... (at most RPT of them); all of its loads are issued before the first
 // use so the whole tile costs one memory latency, not one per batch.
+// The two halves of a tile load can be separated (TileRegs): issue early, commit to LDS when the rows are free.
 template <int RPT>
-__device__ __forceinline__ void load_tile(const double* __restrict__ src, int64_t ld, const int32_t* __restrict__ ord,
-                                          int nrows, int64_t c0, int64_t C, bool vec_ok, double* tile, int RS,
-                                          int32_t* status) {
+struct TileRegs {
+    double v0[RPT], v1[RPT];
+};
+
+template <int RPT>
+__device__ __forceinline__ void tile_issue(const double* __restrict__ src, int64_t ld, const int32_t* __restrict__ ord,
+                                           int nrows, int64_t c0, int64_t C, bool vec_ok, TileRegs<RPT>& t, int rmask = -1) {
     const int cp = threadIdx.x & 3, rr = threadIdx.x >> 2;
     const int64_t c = c0 + 2 * cp;
-    double* d0 = tile + (2 * cp) * RS;
-    double* d1 = d0 + RS;
     const bool full = vec_ok && c + 1 < C;
-    int t[RPT];
+    int ti[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int r = rr + k * kRowsPerPass;
-        t[k] = ord[r < nrows ? r : 0];
+        ti[k] = ord[r < nrows ? r : 0] & rmask;
     }
-    double v0[RPT], v1[RPT];
     if (full) {
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const double2 v = *reinterpret_cast<const double2*>(src + (int64_t)t[k] * ld + c);
-            v0[k] = v.x;
-            v1[k] = v.y;
+            const double2 v = *reinterpret_cast<const double2*>(src + (int64_t)ti[k] * ld + c);
+            t.v0[k] = v.x;
+            t.v1[k] = v.y;
         }
     } else {
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const double* p = src + (int64_t)t[k] * ld + c;
-            v0[k] = c < C ? p[0] : 0.0;
-            v1[k] = c + 1 < C ? p[1] : 0.0;
+            const double* p = src + (int64_t)ti[k] * ld + c;
+            t.v0[k] = c < C ? p[0] : 0.0;
+            t.v1[k] = c + 1 < C ? p[1] : 0.0;
         }
     }
+}
+
+template <int RPT>
+__device__ __forceinline__ void tile_commit(const TileRegs<RPT>& t, int nrows, int64_t c0, int64_t C, double* tile, int RS,
+                                            int32_t* status) {
+    const int cp = threadIdx.x & 3, rr = threadIdx.x >> 2;
+    const int64_t c = c0 + 2 * cp;
+    double* d0 = tile + (2 * cp) * RS;
+    double* d1 = d0 + RS;
     bool bad0 = false, bad1 = false;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int r = rr + k * kRowsPerPass;
         if (r < nrows) {
-            bad0 |= !finite64(v0[k]);
-            bad1 |= !finite64(v1[k]);
-            d0[r] = v0[k];
-            d1[r] = v1[k];
+            bad0 |= !finite64(t.v0[k]);
+            bad1 |= !finite64(t.v1[k]);
+            d0[r] = t.v0[k];
+            d1[r] = t.v1[k];
         }
     }
     if (bad0 && c < C) atomicOr(&status[c], SDI_NONFINITE);
     if (bad1 && c + 1 < C) atomicOr(&status[c + 1], SDI_NONFINITE);
+}
+
+template <int RPT>
+__device__ __forceinline__ void load_tile(const double* __restrict__ src, int64_t ld, const int32_t* __restrict__ ord,
+                                          int nrows, int64_t c0, int64_t C, bool vec_ok, double* tile, int RS,
+                                          int32_t* status) {
+    TileRegs<RPT> t;
+    tile_issue<RPT>(src, ld, ord, nrows, c0, C, vec_ok, t);
+    tile_commit<RPT>(t, nrows, c0, C, tile, RS, status);
 }
 
 __device__ __forceinline__ void store_tile(double* __restrict__ dst, int64_t ld, const int32_t* __restrict__ ord,
@@ -285,42 +305,21 @@ __device__ __forceinline__ void store_tile(double* __restrict__ dst, int64_t ld,
     }
 }
 
-// column sums of one group's rows for the 8 cells (x climatology; nothing stored)
+// column means of one group's rows for the 8 cells from issued tile registers (x climatology; nothing stored)
 template <int RPT>
-__device__ __forceinline__ double tile_column_mean(const double* __restrict__ src, int64_t ld,
-                                                   const int32_t* __restrict__ ord, int nrows, int64_t c0, int64_t C,
-                                                   bool vec_ok, double* scratch, int32_t* status, int wave, int lane) {
+__device__ __forceinline__ double tile_reduce_mean(const TileRegs<RPT>& t, int nrows, int64_t c0, int64_t C, double* scratch,
+                                                   int32_t* status, int wave, int lane) {
     const int cp = threadIdx.x & 3, rr = threadIdx.x >> 2;
     const int64_t c = c0 + 2 * cp;
-    const bool full = vec_ok && c + 1 < C;
     double s0 = 0.0, s1 = 0.0;
     bool bad0 = false, bad1 = false;
-    int t[RPT];
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int r = rr + k * kRowsPerPass;
-        t[k] = ord[r < nrows ? r : 0];
-    }
-    double v0[RPT], v1[RPT];
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const double* p = src + (int64_t)t[k] * ld + c;
-        if (full) {
-            const double2 v = *reinterpret_cast<const double2*>(p);
-            v0[k] = v.x;
-            v1[k] = v.y;
-        } else {
-            v0[k] = c < C ? p[0] : 0.0;
-            v1[k] = c + 1 < C ? p[1] : 0.0;
-        }
-    }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const bool in = rr + k * kRowsPerPass < nrows;
-        bad0 |= in && !finite64(v0[k]);
-        bad1 |= in && !finite64(v1[k]);
-        s0 += in ? v0[k] : 0.0;
-        s1 += in ? v1[k] : 0.0;
+        bad0 |= in && !finite64(t.v0[k]);
+        bad1 |= in && !finite64(t.v1[k]);
+        s0 += in ? t.v0[k] : 0.0;
+        s1 += in ? t.v1[k] : 0.0;
     }
     if (bad0 && c < C) atomicOr(&status[c], SDI_NONFINITE);
     if (bad1 && c + 1 < C) atomicOr(&status[c + 1], SDI_NONFINITE);
@@ -432,7 +431,20 @@ __device__ __forceinline__ unsigned lds_addr(const void* generic_ptr_into_lds) {
 //   ranks: [segment][(K+1)/2][64] u32 -- two 16-bit ranks per word, exactly the rank2[] registers
 //   shift: [segment][K][64] f64       -- rolling mean - x_climo of every sample (TAS, optional: when absent
 //                                        APPLY re-reads the x_fut tile and recomputes it)
-template <int K, int MODE, int KIND, bool IDENT>
+// development (make trace -> lib/libsd_downscale_trace.so, run with SD_RS_TRACE=1): phase stamps (100 MHz wall
+// clock) of every 1024th workgroup.  The stamps pin the instruction schedule (and cost registers), so the
+// production library is built without them.
+#ifdef SD_RS_TRACING
+#define SD_TR(i)                                                                                         \
+    do {                                                                                                 \
+        if (p.trace != nullptr && lane == 0 && (blockIdx.x & 1023) == 7)                                 \
+            p.trace[((int64_t)(blockIdx.x >> 10) * kW + wave) * 16 + (i)] = wall_clock64();              \
+    } while (0)
+#else
+#define SD_TR(i) do { } while (0)
+#endif
+
+template <int K, int MODE, int KIND, bool IDENT, bool SLAB>
 __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile_id, const int g, char* smem_raw) {
     static_assert(MODE == MODE_FIT || MODE == MODE_RANK || MODE == MODE_APPLY, "unknown mode");
     constexpr bool kTas = KIND == SD_BCSD_TAS;
@@ -443,6 +455,7 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
     double* scratch = tile + kW * RS;  // 64 doubles
     const double* rcp = scratch + 64;  // 16 doubles: correctly rounded 1/c, c = 1..9
     const int64_t c0 = tile_id * kW;
+    const int64_t c0l = (p.ablate & 128) ? 0 : c0;  // dev: every tile loads the cells of tile 0 (cache-resident inputs)
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int64_t c = c0 + wave;
     const bool cell_ok = c < p.C;
@@ -462,20 +475,34 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
                        (p.X == nullptr || (reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
     const bool vec_p = MODE != MODE_FIT && (p.ld_p % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.Xp) & 15) == 0);
 
+    SD_TR(0);
     // ---- x climatology (bcsd.py:222); PR only validates X ------------------------------------------
+    // RANK: the x_hist rows and then the x_fut tile are requested back to back (loads return in order), so the
+    // column sums are reduced while the tile is still in flight: one exposed memory latency instead of two.
     double xc = 0.0;
+    TileRegs<NR> xf;
+    const bool dual = MODE == MODE_RANK && !(p.ablate & 16);
     if (MODE == MODE_APPLY || (MODE == MODE_RANK && p.from_state)) {
         if (kTas && cell_ok) xc = p.x_climo[seg];
+        if (dual) tile_issue<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0l, p.C, vec_p, xf, (p.ablate & 256) ? 63 : -1);
     } else if (p.X != nullptr && n > 0 && !(p.ablate & 32)) {
-        xc = tile_column_mean<NR>(p.X, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, scratch, p.status_fit, wave, lane);
+        TileRegs<NR> xh;
+        tile_issue<NR>(p.X, p.ld, p.ord_f + begf, n, c0l, p.C, vec_f, xh, (p.ablate & 256) ? 63 : -1);
+        if (dual) tile_issue<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0l, p.C, vec_p, xf, (p.ablate & 256) ? 63 : -1);
+        xc = tile_reduce_mean<NR>(xh, n, c0, p.C, scratch, p.status_fit, wave, lane);
         if (kTas && lane == 0 && cell_ok) p.x_climo[seg] = xc;
+    } else if (dual) {
+        tile_issue<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0l, p.C, vec_p, xf, (p.ablate & 256) ? 63 : -1);
     }
 
+    SD_TR(1);
     if (MODE == MODE_RANK) {
         // ---- x_fut segment -> shifted series u -> rank of every sample in sort(u) --------------------
-        load_tile<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile + kPadFront, RS, p.status_p);
+        if (!dual) tile_issue<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0l, p.C, vec_p, xf, (p.ablate & 256) ? 63 : -1);
+        tile_commit<NR>(xf, m, c0, p.C, tile + kPadFront, RS, p.status_p);
         if (kTas) zero_pads(row, m, lane, CH + 4);
         __syncthreads();
+        SD_TR(2);
         double u[K];  // u = X - (rolling mean - x_climo) (bcsd.py:247-256); PR maps raw X (bcsd.py:167)
         double* sh = (kTas && p.shift != nullptr && cell_ok) ? p.shift + (seg * K) * kWave + lane : nullptr;
 #pragma unroll
@@ -504,12 +531,14 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
             __builtin_amdgcn_sched_barrier(0);
         }
         wave_fence();
+        SD_TR(3);
         if (!(p.ablate & 1)) {
             double s[K];
 #pragma unroll
             for (int i = 0; i < K; ++i) s[i] = u[i];
             sort_segment<K>(s, row, m, lane);  // self ECDF: np.sort(u) (quantile.py:462 via 505-521)
         }
+        SD_TR(4);
         // rank = (#sorted <= u) - 1: np.interp's exact-hit index = max rank among ties (quantile.py:488).
         // Branch-free binary search (len -> len - len/2 per step, the same wave-uniform stride for every lane),
         // CH independent chains at a time; positions are kept as LDS byte addresses (add, compare, select per
@@ -549,11 +578,13 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        SD_TR(5);
         if (cell_ok) {
             uint32_t* rk = p.ranks + (seg * NR) * kWave + lane;
 #pragma unroll
             for (int i = 0; i < NR; ++i) rk[i * kWave] = rank2[i];
         }
+        SD_TR(6);
         return;
     }
 
@@ -568,8 +599,9 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
     double yc = 0.0;
     if (!(MODE == MODE_APPLY && p.from_state)) {
         if (n > 0) {
-            load_tile<NR>(p.y, p.ld, p.ord_f + begf, n, c0, p.C, vec_f, tile, RS, p.status_fit);
+            load_tile<NR>(p.y, p.ld, p.ord_f + begf, n, c0l, p.C, vec_f, tile, RS, p.status_fit);
             __syncthreads();
+            SD_TR(2);
             double v[K];
             load_blocked<K>(row, n, lane, 0.0, v);
             double s = 0.0;
@@ -583,6 +615,7 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
 #pragma unroll
             for (int i = 0; i < K; ++i) v[i] = K * lane + i < n ? v[i] : __builtin_inf();
             wave_fence();
+            SD_TR(3);
             if (!(p.ablate & 4)) sort_segment<K>(v, row, n, lane);  // quantile.py:462 np.sort
             if (MODE == MODE_FIT && cell_ok) {
                 double* dst = p.ys + c * p.Tf + begf;
@@ -597,7 +630,14 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
         }
         wave_fence();
     }
+    SD_TR(4);
     if (MODE == MODE_FIT) return;
+
+    // No shift slab: the x_fut tile is read a second time (its RANK twin fetched it moments ago: L2 / Infinity
+    // Cache) to recompute the rolling mean; the loads are issued here and fly during the lookups.
+    constexpr bool reload = kTas && !SLAB;
+    TileRegs<NR> xf2;
+    if (reload) tile_issue<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0l, p.C, vec_p, xf2);
 
     // ---- map ranks through the fitted inverse CDF (quantile.py:523-545) ------------------------------
     double q[K];
@@ -640,9 +680,10 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
         }
     }
 
+    SD_TR(5);
     // ---- restore the climate-trend shift (bcsd.py:263-267) / ratio anomalies (bcsd.py:170-185) ------
     if (kTas) {
-        if (p.shift != nullptr) {
+        if (SLAB) {
             if (cell_ok) {
                 const double* sh = p.shift + (seg * K) * kWave + lane;
 #pragma unroll
@@ -653,12 +694,11 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
                 }
             }
         } else {
-            // No shift slab: read the x_fut tile a second time (this workgroup's RANK twin fetched it moments
-            // ago: L2 / Infinity Cache) and recompute the rolling mean.
             __syncthreads();  // all lookups done: rows are free again
-            load_tile<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0, p.C, vec_p, tile + kPadFront, RS, p.status_p);
+            tile_commit<NR>(xf2, m, c0, p.C, tile + kPadFront, RS, p.status_p);
             zero_pads(row, m, lane, CH + 4);
             __syncthreads();
+            SD_TR(6);
 #pragma unroll
             for (int cbeg = 0; cbeg < K; cbeg += CH) {
                 double mean[CH], xv[CH];
@@ -679,6 +719,7 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
 #pragma unroll
         for (int i = 0; i < K; ++i) q[i] = p.return_anoms ? q[i] / yc : q[i];  // bcsd.py:170-185
     }
+    SD_TR(7);
     wave_fence();  // the wave's own row is rewritten in time order
     {
         const int base = K * lane;
@@ -686,27 +727,13 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
         for (int i = 0; i < K; ++i) row[base + i < m ? base + i : m] = q[i];
     }
     __syncthreads();
+    SD_TR(8);
     const bool vec_o = (p.ld_out % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
     if (!(p.ablate & 64)) store_tile(p.out, p.ld_out, p.ord_p + begp, m, c0, p.C, vec_o, tile, RS);
+    SD_TR(9);
 }
 
-// Every segment is a memory phase (tile loads) followed by a long compute phase (sort, search).  All
-// workgroups are alike, so without help the whole chip runs in lockstep: HBM saturated while everybody loads,
-// idle while everybody sorts, kernel time = the sum of the two.  The first generation of workgroups (the ones
-// that find the chip empty) therefore starts staggered over one workgroup duration; equal durations keep the
-// offsets alive for the rest of the launch.  The two workgroups of a tile pair (the 64-byte halves of the same
-// 128-byte lines) keep a common offset.
-__device__ __forceinline__ void stagger_first_generation(const Params& p) {
-    if (p.stagger_ticks <= 0 || blockIdx.x >= (unsigned)p.first_generation) return;
-    const unsigned pair = blockIdx.x >> 4, xcd = blockIdx.x & 7;
-    unsigned h = (pair * 8u + xcd) * 2654435761u;
-    h ^= h >> 15;
-    const long long wait = (long long)(h % 61u) * p.stagger_ticks / 61;
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(64);
-}
-
-template <int K, int MODE, int OCC, int KIND, bool IDENT>
+template <int K, int MODE, int OCC, int KIND, bool IDENT, bool SLAB>
 __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     {
@@ -716,7 +743,6 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
             rcp[threadIdx.x] = tab[threadIdx.x];
         }
     }
-    stagger_first_generation(p);
     // XCD-aware workgroup -> (tile, group): workgroup b runs on XCD b % 8; XCD x owns tiles [x*tx, (x+1)*tx)
     // and walks them tile-fastest, so the two 64-byte halves of a 128-byte line are fetched by workgroups
     // that are adjacent in time on the same L2.
@@ -726,30 +752,63 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
     const int64_t tile_id = xcd * tx + jb % tx;
     const int g = (int)(jb / tx);
     if (tile_id >= p.ntiles || g >= p.G) return;
-    segment_body<K, MODE, KIND, IDENT>(p, tile_id, g, smem_raw);
+    segment_body<K, MODE, KIND, IDENT, SLAB>(p, tile_id, g, smem_raw);
 }
 
-template <int K, int MODE, int OCC, int KIND, bool IDENT>
+template <int K, int MODE, int OCC, int KIND, bool IDENT, bool SLAB>
 int launch_koki(sd_ctx* ctx, const Params& p, const char* name) {
-    const size_t lds = ((size_t)kW * p.RS + 64 + 16) * sizeof(double);
-    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_rs_kernel<K, MODE, OCC, KIND, IDENT>),
+    size_t lds = ((size_t)kW * p.RS + 64 + 16) * sizeof(double);
+    if (const char* e = getenv("SD_RS_LDS_PAD")) lds += (size_t)atoi(e);  // dev: force one workgroup per CU
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_rs_kernel<K, MODE, OCC, KIND, IDENT, SLAB>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t tx = (p.ntiles + 7) / 8;
     const int64_t nblocks = 8 * tx * p.G;
     SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "grid too large");
     Params q = p;
-    q.first_generation = ctx->cu_count * (lds * 2 <= ctx->lds_max && OCC >= 4 ? 2 : 1);
-    // one workgroup lasts roughly 2 us per register-sort width unit (100 MHz ticks); SD_RS_STAGGER_US overrides
-    const char* e = getenv("SD_RS_STAGGER_US");
-    q.stagger_ticks = (int)((e ? atof(e) : 2.0 * K) * 100.0);
-    SD_LAUNCH(ctx, name, (bcsd_rs_kernel<K, MODE, OCC, KIND, IDENT>), dim3((unsigned)nblocks), dim3(kThreads), lds, q);
+    const bool tracing = getenv("SD_RS_TRACE") != nullptr;
+    const size_t nsamp = (size_t)(nblocks >> 10) + 1, trace_bytes = nsamp * kW * 16 * sizeof(long long);
+    sd_scratch trace;
+    if (tracing) {
+        SD_HIP(hipMalloc(&trace.p, trace_bytes));
+        SD_HIP(hipMemsetAsync(trace.p, 0, trace_bytes, ctx->stream));
+        q.trace = trace.as<long long>();
+    }
+    SD_LAUNCH(ctx, name, (bcsd_rs_kernel<K, MODE, OCC, KIND, IDENT, SLAB>), dim3((unsigned)nblocks), dim3(kThreads), lds, q);
+    if (tracing) {  // mean time between consecutive stamps over the sampled waves, in microseconds
+        std::vector<long long> h(nsamp * kW * 16);
+        SD_HIP(hipMemcpyAsync(h.data(), trace.p, trace_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        double sum[16] = {};
+        long long cnt[16] = {};
+        for (size_t w = 0; w < nsamp * kW; ++w) {
+            long long prev = 0;
+            for (int i = 0; i < 16; ++i) {
+                const long long t = h[w * 16 + i];
+                if (t == 0) continue;
+                if (prev) { sum[i] += (double)(t - prev) * 0.01; ++cnt[i]; }
+                prev = t;
+            }
+        }
+        fprintf(stderr, "[trace] %s:", name);
+        for (int i = 1; i < 16; ++i)
+            if (cnt[i]) fprintf(stderr, " ->%d %.2fus", i, sum[i] / (double)cnt[i]);
+        fprintf(stderr, "\n");
+    }
     return SD_OK;
 }
 
 template <int K, int MODE, int OCC, int KIND>
 int launch_kok(sd_ctx* ctx, const Params& p, const char* name) {
-    if (MODE == MODE_APPLY && p.identity) return launch_koki<K, MODE, OCC, KIND, true>(ctx, p, name);
-    return launch_koki<K, MODE, OCC, KIND, false>(ctx, p, name);
+    // IDENT and SLAB only change MODE_APPLY code (RANK tests p.shift at run time: one store per sample)
+    if constexpr (MODE == MODE_APPLY) {
+        if constexpr (KIND == SD_BCSD_TAS) {
+            if (p.shift != nullptr)
+                return p.identity ? launch_koki<K, MODE, OCC, KIND, true, true>(ctx, p, name)
+                                  : launch_koki<K, MODE, OCC, KIND, false, true>(ctx, p, name);
+        }
+        if (p.identity) return launch_koki<K, MODE, OCC, KIND, true, false>(ctx, p, name);
+    }
+    return launch_koki<K, MODE, OCC, KIND, false, false>(ctx, p, name);
 }
 
 template <int K, int MODE, int OCC>

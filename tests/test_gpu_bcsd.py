@@ -131,6 +131,29 @@ def test_every_register_sort_width_split_and_fused(ctx, kind, T, Tp, C):
     assert_close(fused.to_host(), exp, what=f"fused {kind} {T}->{Tp}")
 
 
+def test_shift_slab_handoff_is_bit_identical(ctx, monkeypatch):
+    """SD_RS_SHIFT=1: RANK hands the rolling-mean shift to APPLY through the workspace instead of APPLY
+    recomputing it from a second read of x_fut -- same arithmetic, so the two must agree bit for bit,
+    in the fused entry point and in predict-from-state, equal and unequal segment lengths."""
+    rng = np.random.default_rng(11)
+    for T, Tp, C in ((3650, 3650, 9), (14600, 14600, 8), (14600, 20000, 5), (14600, 3000, 3)):
+        index = pd.date_range("1980-01-01", periods=T, freq="D")
+        index_p = pd.date_range("1980-01-01", periods=Tp, freq="D")
+        X, y, Xp = (15 + 8 * rng.standard_normal((n, C)) for n in (T, T, Tp))
+        gid, gid_p = month_gid(index), month_gid(index_p)
+        dX, dy, dXp = ctx.to_device(X), ctx.to_device(y), ctx.to_device(Xp)
+        monkeypatch.delenv("SD_RS_SHIFT", raising=False)
+        a, _ = ctx.bcsd_fit_predict(0, dX, dy, gid, 12, dXp, gid_p)
+        st = ctx.bcsd_fit(0, dX, dy, gid, 12, True)
+        b, _ = ctx.bcsd_predict(st, dXp, gid_p)
+        monkeypatch.setenv("SD_RS_SHIFT", "1")
+        a1, _ = ctx.bcsd_fit_predict(0, dX, dy, gid, 12, dXp, gid_p)
+        b1, _ = ctx.bcsd_predict(st, dXp, gid_p)
+        assert np.array_equal(a.to_host(), a1.to_host()), (T, Tp)
+        assert np.array_equal(b.to_host(), b1.to_host()), (T, Tp)
+    monkeypatch.delenv("SD_RS_SHIFT", raising=False)
+
+
 def test_generic_lds_kernels_still_agree(ctx, monkeypatch):
     """SD_BCSD_PATH=v1 forces the generic LDS-bitonic kernels (fallback for segments > 2 112 samples)."""
     monkeypatch.setenv("SD_BCSD_PATH", "v1")
