@@ -37,8 +37,8 @@ BYTES_PER_CELL_STEP = 32  # X_hist + y_obs + X_fut read, out written: 4 x 8 B pe
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cells", type=int, default=100_000, help="cells per GPU")
     ap.add_argument("--times", type=int, default=14_600)
     ap.add_argument("--seed", type=int, default=0)
