@@ -14,6 +14,7 @@
 // Neighbour lists go to an L2-resident scratch [k][threads] per workgroup, then the statistics
 // epilogue (gard.py:303-346) or the per-query OLS (gard.py:194-224) runs on them.
 #include <algorithm>
+#include <cstdlib>
 
 #include "sd_internal.h"
 
@@ -374,6 +375,182 @@ __global__ void __launch_bounds__(1024) analog_f1_predict_kernel(int mode, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// F == 1 predict, window form.  In one dimension the k nearest training values are k consecutive
+// entries of the sorted view unless a tie sits on the boundary, so a query costs one binary search
+// for the window start (2 LDS reads per step) and one pass over yx[L .. L+k) -- the analog values
+// in sorted-x order, k consecutive doubles.  No neighbour lists, no gathers.  Used for PureAnalog
+// kinds best / weight / mean when neither indices nor distances are requested; a query whose window
+// is not strictly separated from its outside neighbours (exact distance ties, tie runs cut by the
+// left boundary: KDTree order then depends on the training index) is answered by the exact
+// (rdist, index)-ordered walk below, as are 'sample_analogs' and AnalogRegression.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sq_dist(double q, double x) {
+    const double d = q - x;
+    return d * d;
+}
+
+__device__ void f1_walk_query(int mode, const PredictArgs& pa, int n, int64_t T, int64_t c, int64_t tq, double q,
+                              const double* xs /* LDS */, const int32_t* __restrict__ xi, const double* __restrict__ Xc_cell,
+                              const double* __restrict__ yc_cell, double* sd, int32_t* si, int nthr) {
+    const int tid = threadIdx.x, k = pa.k;
+    // r = first sorted position with x > q ; left part ends at r - 1
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (xs[mid] <= q) lo = mid + 1; else hi = mid;
+    }
+    int r = lo;          // next right candidate
+    int le = lo - 1;     // last element of the current left run (-1: exhausted)
+    int rs = 0, cur = 0; // current left run [rs, le], next to take = cur (ascending index order)
+    if (le >= 0) {
+        rs = le;
+        while (rs > 0 && xs[rs - 1] == xs[le]) --rs;
+        cur = rs;
+    }
+    for (int i = 0; i < k; ++i) {
+        double dl = 0.0, dr = 0.0;
+        const bool hl = le >= 0, hr = r < n;
+        if (hl) dl = sq_dist(q, xs[le]);
+        if (hr) dr = sq_dist(q, xs[r]);
+        bool take_left;
+        if (hl && hr) take_left = dl < dr || (dl == dr && xi[cur] < xi[r]);
+        else take_left = hl;
+        if (take_left) {
+            sd[(int64_t)i * nthr + tid] = dl;
+            si[(int64_t)i * nthr + tid] = xi[cur];
+            if (++cur > le) {
+                le = rs - 1;
+                if (le >= 0) {
+                    rs = le;
+                    while (rs > 0 && xs[rs - 1] == xs[le]) --rs;
+                    cur = rs;
+                }
+            }
+        } else {
+            sd[(int64_t)i * nthr + tid] = dr;
+            si[(int64_t)i * nthr + tid] = xi[r];
+            ++r;
+        }
+    }
+    finish_query(mode, pa, 1, T, c, tq, &q, Xc_cell, yc_cell, sd, si, nthr, true);
+}
+
+__global__ void __launch_bounds__(1024) analog_f1_window_kernel(const double* __restrict__ Xq, int64_t ld, int64_t Tq,
+                                                                int64_t T, int64_t C, const double* __restrict__ xs_all,
+                                                                const int32_t* __restrict__ xi_all,
+                                                                const double* __restrict__ yx_all,
+                                                                const double* __restrict__ Xc, const double* __restrict__ yc,
+                                                                const int32_t* __restrict__ fit_status, int32_t* status,
+                                                                double* scratch_d, int32_t* scratch_i, PredictArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* xs = reinterpret_cast<double*>(smem_raw);
+    const int nthr = blockDim.x, tid = threadIdx.x;
+    const int n = (int)T, k = pa.k;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    double* sd = scratch_d + (int64_t)blockIdx.x * k * nthr;
+    int32_t* si = scratch_i + (int64_t)blockIdx.x * k * nthr;
+    int64_t step, end;
+    for (int64_t c = first_cell(C, &step, &end); c < end; c += step) {
+        const bool active = fit_status[c] == 0;
+        const int32_t* xi = xi_all + c * T;
+        const double* yx = yx_all + c * T;
+        __syncthreads();
+        if (active)
+            for (int i = tid; i < n; i += nthr) xs[i] = xs_all[c * T + i];
+        __syncthreads();
+        for (int64_t tq = tid; tq < Tq; tq += nthr) {
+            const double q = Xq[tq * ld + c];
+            bool ok = active;
+            if (active && !sd_finite(q)) {
+                atomicOr(&status[c], SDI_NONFINITE);
+                ok = false;
+            }
+            double pred = nan, prob = nan, err = nan;
+            if (ok) {
+                // window start: smallest L with rdist(L) <= rdist(L + k) (rdist is unimodal along the sorted view)
+                int lo = 0, hi = n - k;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sq_dist(q, xs[mid]) > sq_dist(q, xs[mid + k])) lo = mid + 1; else hi = mid;
+                }
+                const int L = lo;
+                const double dL = sq_dist(q, xs[L]), dR = sq_dist(q, xs[L + k - 1]);
+                const double worst = dL > dR ? dL : dR;
+                const bool sep_l = L == 0 || sq_dist(q, xs[L - 1]) > worst;
+                const bool sep_r = L + k == n || sq_dist(q, xs[L + k]) > worst;
+                // 'best' needs a unique nearest element as well
+                bool unique = sep_l && sep_r;
+                if (unique) {
+                    const double* a = yx + L;
+                    const double a0 = a[0];
+                    double s1 = 0.0, s2 = 0.0, wsum = 0.0, awsum = 0.0, best_d = dL, best_a = a0;
+                    int nexc = 0, nbest = 0;
+                    constexpr int kBatch = 8;  // analog values are requested kBatch at a time (one latency per batch)
+                    for (int i0 = 0; i0 < k; i0 += kBatch) {
+                        double av[kBatch];
+#pragma unroll
+                        for (int j = 0; j < kBatch; ++j) av[j] = a[i0 + j < k ? i0 + j : k - 1];
+#pragma unroll
+                        for (int j = 0; j < kBatch; ++j) {
+                            const int i = i0 + j;
+                            if (i >= k) break;
+                            const double ai = av[j];
+                            const double e = ai - a0;
+                            s1 += e;
+                            s2 += e * e;
+                            nexc += (!pa.has_thresh || ai > pa.thresh) ? 1 : 0;  // gard.py:307
+                            if (pa.kind != SD_ANALOG_MEAN) {
+                                const double rd = sq_dist(q, xs[L + i]);
+                                if (pa.kind == SD_ANALOG_WEIGHT) {
+                                    const double d = sqrt(rd);
+                                    const double w = 1.0 / (d == 0.0 ? 1e-20 : d);  // gard.py:322-323
+                                    wsum += w;
+                                    awsum += ai * w;
+                                } else {
+                                    if (rd < best_d || i == 0) { best_d = rd; best_a = ai; nbest = 1; }
+                                    else if (rd == best_d) ++nbest;
+                                }
+                            }
+                        }
+                    }
+                    if (pa.kind == SD_ANALOG_BEST && nbest != 1) unique = false;  // two nearest at one distance: index order decides
+                    if (unique) {
+                        const bool any_masked = nexc != k;
+                        const double kk = (double)k;
+                        const double mean = a0 + s1 / kk;
+                        double p;
+                        if (pa.kind == SD_ANALOG_BEST) p = best_a;                                  // gard.py:311
+                        else if (pa.kind == SD_ANALOG_WEIGHT) p = any_masked ? nan : awsum / wsum;  // gard.py:319-327
+                        else p = any_masked ? nan : mean;                                           // gard.py:329-333
+                        if (pa.has_thresh) {
+                            p = nan_to_num(p);        // gard.py:341
+                            prob = (double)nexc / kk;  // gard.py:343
+                        } else {
+                            prob = 1.0;  // gard.py:346
+                        }
+                        if (any_masked) {
+                            err = nan;  // gard.py:342
+                        } else {
+                            const double m1 = s1 / kk;
+                            const double var = s2 / kk - m1 * m1;  // shifted by the first analog: no cancellation
+                            err = sqrt(var > 0.0 ? var : 0.0);     // ddof = 0 (gard.py:342,345)
+                        }
+                        pred = p;
+                    }
+                }
+                if (!unique) {
+                    f1_walk_query(0, pa, n, T, c, tq, q, xs, xi, Xc + c * T, yc + c * T, sd, si, nthr);
+                    continue;
+                }
+            }
+            pa.out[(tq * 3 + 0) * pa.ld_out + c] = pred;
+            pa.out[(tq * 3 + 1) * pa.ld_out + c] = prob;
+            pa.out[(tq * 3 + 2) * pa.ld_out + c] = err;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // general F predict: brute force, training rows staged through LDS, per-thread top-k in scratch
 // ------------------------------------------------------------------------------------------------
 constexpr int kBfThreads = 256;
@@ -510,7 +687,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
     pa.inds = inds;
     pa.dist = dist;
     sd_scratch status_p, sc_d, sc_i, status_pub;
-    SD_HIP(hipMalloc(&status_p.p, sizeof(int32_t) * C));
+    SD_HIP(status_p.alloc(ctx, sizeof(int32_t) * C));
     SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
     const bool f1 = st->xs != nullptr;
     const int nthr = f1 ? 1024 : kBfThreads;
@@ -518,9 +695,19 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
     nb = (nb / 8) * 8;
     if (nb < 8) nb = 8;
     if ((int64_t)nb > ((C + 7) / 8) * 8) nb = (int)(((C + 7) / 8) * 8);
-    SD_HIP(hipMalloc(&sc_d.p, sizeof(double) * (size_t)nb * k * nthr));
-    SD_HIP(hipMalloc(&sc_i.p, sizeof(int32_t) * (size_t)nb * k * nthr));
-    if (f1) {
+    SD_HIP(sc_d.alloc(ctx, sizeof(double) * (size_t)nb * k * nthr));
+    SD_HIP(sc_i.alloc(ctx, sizeof(int32_t) * (size_t)nb * k * nthr));
+    const bool window = f1 && mode == 0 && kind != SD_ANALOG_SAMPLE && !inds && !dist && st->yx != nullptr &&
+                        getenv("SD_ANALOG_WALK") == nullptr;
+    if (window) {
+        const size_t lds = sizeof(double) * T;
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_window_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SD_LAUNCH(ctx, "analog_f1_window_kernel", analog_f1_window_kernel, dim3(nb), dim3(nthr), lds, Xq, ld, Tq, T, C,
+                  (const double*)st->xs, (const int32_t*)st->xi, (const double*)st->yx, (const double*)st->X,
+                  (const double*)st->y, (const int32_t*)st->status, status_p.as<int32_t>(), sc_d.as<double>(),
+                  sc_i.as<int32_t>(), pa);
+    } else if (f1) {
         const size_t lds = sizeof(double) * T;
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_predict_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -536,7 +723,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
                   status_p.as<int32_t>(), sc_d.as<double>(), sc_i.as<int32_t>(), pa);
     }
     if (cell_status) {
-        SD_HIP(hipMalloc(&status_pub.p, sizeof(int32_t) * C));
+        SD_HIP(status_pub.alloc(ctx, sizeof(int32_t) * C));
         SD_LAUNCH(ctx, "analog_status_public_kernel", analog_status_public_kernel, dim3((unsigned)((C + 255) / 256)),
                   dim3(256), 0, (const int32_t*)st->status, (const int32_t*)status_p.p, C, status_pub.as<int32_t>());
         SD_HIP(hipMemcpyAsync(cell_status, status_pub.p, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->stream));
@@ -554,13 +741,13 @@ int predict_host(int mode, sd_ctx* ctx, const sd_analog_state* st, const double*
     const int64_t C = st->C;
     sd_scratch dq, dout, dinds, ddist, dsamp;
     const size_t qb = sizeof(double) * (size_t)Tq * st->F * C, ob = sizeof(double) * (size_t)Tq * 3 * C;
-    SD_HIP(hipMalloc(&dq.p, qb));
-    SD_HIP(hipMalloc(&dout.p, ob));
+    SD_HIP(dq.alloc(ctx, qb));
+    SD_HIP(dout.alloc(ctx, ob));
     SD_HIP(hipMemcpyAsync(dq.p, Xq, qb, hipMemcpyHostToDevice, ctx->stream));
-    if (inds) SD_HIP(hipMalloc(&dinds.p, sizeof(int64_t) * (size_t)Tq * k * C));
-    if (dist) SD_HIP(hipMalloc(&ddist.p, sizeof(double) * (size_t)Tq * k * C));
+    if (inds) SD_HIP(dinds.alloc(ctx, sizeof(int64_t) * (size_t)Tq * k * C));
+    if (dist) SD_HIP(ddist.alloc(ctx, sizeof(double) * (size_t)Tq * k * C));
     if (sample) {
-        SD_HIP(hipMalloc(&dsamp.p, sizeof(int32_t) * (size_t)Tq * C));
+        SD_HIP(dsamp.alloc(ctx, sizeof(int32_t) * (size_t)Tq * C));
         SD_HIP(hipMemcpyAsync(dsamp.p, sample, sizeof(int32_t) * (size_t)Tq * C, hipMemcpyHostToDevice, ctx->stream));
     }
     SD_TRY(predict_common(mode, ctx, st, dq.as<double>(), C, Tq, k, kind, has_thresh, thresh, dsamp.as<int32_t>(), C,
@@ -582,11 +769,12 @@ int sd_analog_state_destroy(sd_analog_state* st) {
         (void)hipSetDevice(st->ctx->device);
         (void)hipStreamSynchronize(st->ctx->stream);
     }
-    (void)hipFree(st->X);
-    (void)hipFree(st->y);
-    (void)hipFree(st->status);
-    (void)hipFree(st->xs);
-    (void)hipFree(st->xi);
+    sd_pool_release(st->ctx, st->X);
+    sd_pool_release(st->ctx, st->y);
+    sd_pool_release(st->ctx, st->status);
+    sd_pool_release(st->ctx, st->xs);
+    sd_pool_release(st->ctx, st->xi);
+    sd_pool_release(st->ctx, st->yx);
     delete st;
     return SD_OK;
 }
@@ -612,9 +800,9 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
     st->F = F;
     st->C = C;
     auto body = [&]() -> int {
-        SD_HIP(hipMalloc((void**)&st->X, sizeof(double) * (size_t)T * F * C));
-        SD_HIP(hipMalloc((void**)&st->y, sizeof(double) * (size_t)T * C));
-        SD_HIP(hipMalloc((void**)&st->status, sizeof(int32_t) * C));
+        SD_HIP(sd_pool_malloc(ctx, (void**)&st->X, sizeof(double) * (size_t)T * F * C));
+        SD_HIP(sd_pool_malloc(ctx, (void**)&st->y, sizeof(double) * (size_t)T * C));
+        SD_HIP(sd_pool_malloc(ctx, (void**)&st->status, sizeof(int32_t) * C));
         SD_HIP(hipMemsetAsync(st->status, 0, sizeof(int32_t) * C, ctx->stream));
         dim3 grid((unsigned)((C + 31) / 32), (unsigned)((T + 31) / 32));
         for (int f = 0; f < F; ++f)
@@ -624,14 +812,15 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
                   st->y, st->status, 0);
         const size_t lds = (size_t)T * (sizeof(double) + sizeof(uint16_t));
         if (F == 1 && T <= 65535 && lds <= ctx->lds_max) {
-            // sorted view for the 1-D fast path; yx is not kept (y gathered by index, L2-resident)
-            SD_HIP(hipMalloc((void**)&st->xs, sizeof(double) * (size_t)T * C));
-            SD_HIP(hipMalloc((void**)&st->xi, sizeof(int32_t) * (size_t)T * C));
+            // sorted view for the 1-D fast path: values, original indices, and y in the same order
+            SD_HIP(sd_pool_malloc(ctx, (void**)&st->xs, sizeof(double) * (size_t)T * C));
+            SD_HIP(sd_pool_malloc(ctx, (void**)&st->xi, sizeof(int32_t) * (size_t)T * C));
+            SD_HIP(sd_pool_malloc(ctx, (void**)&st->yx, sizeof(double) * (size_t)T * C));
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             int nb = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 4);
             SD_LAUNCH(ctx, "analog_sort_kernel", analog_sort_kernel, dim3(nb), dim3(1024), lds, (const double*)st->X,
-                      (const double*)st->y, T, C, st->xs, st->xi, (double*)nullptr);
+                      (const double*)st->y, T, C, st->xs, st->xi, st->yx);
             SD_HIP(hipStreamSynchronize(ctx->stream));
         }
         SD_HIP(hipStreamSynchronize(ctx->stream));
@@ -651,8 +840,8 @@ int sd_analog_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int 
     SD_CHECK_ARG(T > 0 && C > 0 && F >= 1, "sd_analog_fit: bad sizes");
     SD_HIP(hipSetDevice(ctx->device));
     sd_scratch dX, dy;
-    SD_HIP(hipMalloc(&dX.p, sizeof(double) * (size_t)T * F * C));
-    SD_HIP(hipMalloc(&dy.p, sizeof(double) * (size_t)T * C));
+    SD_HIP(dX.alloc(ctx, sizeof(double) * (size_t)T * F * C));
+    SD_HIP(dy.alloc(ctx, sizeof(double) * (size_t)T * C));
     SD_HIP(hipMemcpyAsync(dX.p, X, sizeof(double) * (size_t)T * F * C, hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(hipMemcpyAsync(dy.p, y, sizeof(double) * (size_t)T * C, hipMemcpyHostToDevice, ctx->stream));
     return sd_analog_fit_dev(ctx, dX.as<double>(), dy.as<double>(), C, T, F, C, out);

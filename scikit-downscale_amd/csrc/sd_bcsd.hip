@@ -340,8 +340,8 @@ int upload_group_table(sd_ctx* ctx, const int32_t* gid, int64_t T, int G, DevGro
     SD_TRY(sd_build_group_table(gid, T, G, &gt));
     SD_CHECK_ARG(T < (int64_t)1 << 31, "T too large");
     std::vector<int32_t> off32(gt.off.begin(), gt.off.end());
-    SD_HIP(hipMalloc(&d->order.p, sizeof(int32_t) * T));
-    SD_HIP(hipMalloc(&d->off.p, sizeof(int32_t) * (G + 1)));
+    SD_HIP(d->order.alloc(ctx, sizeof(int32_t) * T));
+    SD_HIP(d->off.alloc(ctx, sizeof(int32_t) * (G + 1)));
     SD_HIP(hipMemcpyAsync(d->order.p, gt.order.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(hipMemcpyAsync(d->off.p, off32.data(), sizeof(int32_t) * (G + 1), hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
@@ -402,8 +402,8 @@ int build_q_tables(sd_ctx* ctx, const std::vector<int64_t>& off_f, const std::ve
             qv[t] = (i == n - 1 || pi == p) ? 0.0 : (p - pi) / (h_pp_at(i + 1, dn) - pi);
         }
     }
-    SD_HIP(hipMalloc(&q->idx.p, sizeof(int32_t) * Tp));
-    SD_HIP(hipMalloc(&q->val.p, sizeof(double) * Tp));
+    SD_HIP(q->idx.alloc(ctx, sizeof(int32_t) * Tp));
+    SD_HIP(q->val.alloc(ctx, sizeof(double) * Tp));
     SD_HIP(hipMemcpyAsync(q->idx.p, qi.data(), sizeof(int32_t) * Tp, hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(hipMemcpyAsync(q->val.p, qv.data(), sizeof(double) * Tp, hipMemcpyHostToDevice, ctx->stream));
     SD_HIP(hipStreamSynchronize(ctx->stream));
@@ -446,11 +446,11 @@ int alloc_state(sd_ctx* ctx, int kind, int G, int64_t T, int64_t C, int return_a
     st->C = C;
     st->return_anoms = return_anoms;
     *out = st;
-    SD_HIP(hipMalloc((void**)&st->ys, sizeof(double) * T * C));
-    SD_HIP(hipMalloc((void**)&st->x_climo, sizeof(double) * G * C));
-    SD_HIP(hipMalloc((void**)&st->y_climo, sizeof(double) * G * C));
-    SD_HIP(hipMalloc((void**)&st->status, sizeof(int32_t) * C));
-    SD_HIP(hipMalloc((void**)&st->goff_dev, sizeof(int32_t) * (G + 1)));
+    SD_HIP(sd_pool_malloc(ctx, (void**)&st->ys, sizeof(double) * T * C));
+    SD_HIP(sd_pool_malloc(ctx, (void**)&st->x_climo, sizeof(double) * G * C));
+    SD_HIP(sd_pool_malloc(ctx, (void**)&st->y_climo, sizeof(double) * G * C));
+    SD_HIP(sd_pool_malloc(ctx, (void**)&st->status, sizeof(int32_t) * C));
+    SD_HIP(sd_pool_malloc(ctx, (void**)&st->goff_dev, sizeof(int32_t) * (G + 1)));
     SD_HIP(hipMemsetAsync(st->x_climo, 0, sizeof(double) * G * C, ctx->stream));
     SD_HIP(hipMemsetAsync(st->y_climo, 0, sizeof(double) * G * C, ctx->stream));
     return SD_OK;
@@ -466,11 +466,11 @@ int sd_bcsd_state_destroy(sd_bcsd_state* st) {
         (void)hipSetDevice(st->ctx->device);
         (void)hipStreamSynchronize(st->ctx->stream);
     }
-    (void)hipFree(st->ys);
-    (void)hipFree(st->x_climo);
-    (void)hipFree(st->y_climo);
-    (void)hipFree(st->status);
-    (void)hipFree(st->goff_dev);
+    sd_pool_release(st->ctx, st->ys);
+    sd_pool_release(st->ctx, st->x_climo);
+    sd_pool_release(st->ctx, st->y_climo);
+    sd_pool_release(st->ctx, st->status);
+    sd_pool_release(st->ctx, st->goff_dev);
     delete st;
     return SD_OK;
 }
@@ -543,7 +543,7 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
     const bool rs = use_rs_path(nmax_all);
     if (!rs) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 2, &W, &stride));
     sd_scratch status_p, status_pub;
-    SD_HIP(hipMalloc(&status_p.p, sizeof(int32_t) * C));
+    SD_HIP(status_p.alloc(ctx, sizeof(int32_t) * C));
     SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
     QTables qt;
     if (rs) {
@@ -580,7 +580,7 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
     SD_LAUNCH(ctx, "nan_fill_kernel", nan_fill_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, out_dev, ld_out, Tp, C,
               (const int32_t*)st->status, (const int32_t*)status_p.p);
     if (cell_status) {
-        SD_HIP(hipMalloc(&status_pub.p, sizeof(int32_t) * C));
+        SD_HIP(status_pub.alloc(ctx, sizeof(int32_t) * C));
         SD_LAUNCH(ctx, "status_public_kernel", status_public_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
                   (const int32_t*)st->status, (const int32_t*)status_p.p, C, status_pub.as<int32_t>());
         SD_HIP(hipMemcpyAsync(cell_status, status_pub.p, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->stream));
@@ -612,8 +612,8 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
     }
     // fused register/LDS path: no persisted quantile state, HBM traffic = 3 reads + 1 write per sample
     sd_scratch status_f, status_p, status_pub;
-    SD_HIP(hipMalloc(&status_f.p, sizeof(int32_t) * C));
-    SD_HIP(hipMalloc(&status_p.p, sizeof(int32_t) * C));
+    SD_HIP(status_f.alloc(ctx, sizeof(int32_t) * C));
+    SD_HIP(status_p.alloc(ctx, sizeof(int32_t) * C));
     SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
     QTables qt;
     SD_TRY(build_q_tables(ctx, gf.host_off, gp.host_off, G, &qt));
@@ -649,7 +649,7 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
     SD_LAUNCH(ctx, "nan_fill_kernel", nan_fill_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, out_dev, ld_out, Tp, C,
               (const int32_t*)status_f.p, (const int32_t*)status_p.p);
     if (cell_status) {
-        SD_HIP(hipMalloc(&status_pub.p, sizeof(int32_t) * C));
+        SD_HIP(status_pub.alloc(ctx, sizeof(int32_t) * C));
         SD_LAUNCH(ctx, "status_public_kernel", status_public_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
                   (const int32_t*)status_f.p, (const int32_t*)status_p.p, C, status_pub.as<int32_t>());
         SD_HIP(hipMemcpyAsync(cell_status, status_pub.p, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->stream));
@@ -666,10 +666,10 @@ int sd_bcsd_fit(sd_ctx* ctx, int kind, const double* X, const double* y, const i
     sd_scratch dX, dy;
     const size_t bytes = sizeof(double) * (size_t)T * (size_t)C;
     if (X) {
-        SD_HIP(hipMalloc(&dX.p, bytes));
+        SD_HIP(dX.alloc(ctx, bytes));
         SD_HIP(hipMemcpyAsync(dX.p, X, bytes, hipMemcpyHostToDevice, ctx->stream));
     }
-    SD_HIP(hipMalloc(&dy.p, bytes));
+    SD_HIP(dy.alloc(ctx, bytes));
     SD_HIP(hipMemcpyAsync(dy.p, y, bytes, hipMemcpyHostToDevice, ctx->stream));
     return sd_bcsd_fit_dev(ctx, kind, dX.as<double>(), dy.as<double>(), C, group_id, G, T, C, return_anoms, out);
 }
@@ -681,8 +681,8 @@ int sd_bcsd_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, cons
     SD_HIP(hipSetDevice(ctx->device));
     sd_scratch dX, dout;
     const size_t bytes = sizeof(double) * (size_t)Tp * (size_t)st->C;
-    SD_HIP(hipMalloc(&dX.p, bytes));
-    SD_HIP(hipMalloc(&dout.p, bytes));
+    SD_HIP(dX.alloc(ctx, bytes));
+    SD_HIP(dout.alloc(ctx, bytes));
     SD_HIP(hipMemcpyAsync(dX.p, Xp, bytes, hipMemcpyHostToDevice, ctx->stream));
     SD_TRY(sd_bcsd_predict_dev(ctx, st, dX.as<double>(), st->C, group_id_p, Tp, dout.as<double>(), st->C, cell_status));
     SD_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));

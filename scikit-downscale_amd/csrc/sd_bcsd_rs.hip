@@ -769,7 +769,7 @@ int launch_koki(sd_ctx* ctx, const Params& p, const char* name) {
     const size_t nsamp = (size_t)(nblocks >> 10) + 1, trace_bytes = nsamp * kW * 16 * sizeof(long long);
     sd_scratch trace;
     if (tracing) {
-        SD_HIP(hipMalloc(&trace.p, trace_bytes));
+        SD_HIP(trace.alloc(ctx, trace_bytes));
         SD_HIP(hipMemsetAsync(trace.p, 0, trace_bytes, ctx->stream));
         q.trace = trace.as<long long>();
     }

@@ -47,6 +47,7 @@ int sd_ctx_create(int device, sd_ctx** out) {
     ctx->cu_count = prop.multiProcessorCount;
     ctx->lds_max = prop.sharedMemPerBlock;
     if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) ctx->lds_max = 160 * 1024;  // CDNA4: 160 KiB LDS per CU
+    ctx->pool_cap = (size_t)prop.totalGlobalMem / 4;
     SD_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     SD_HIP(hipEventCreate(&ctx->t0));
     SD_HIP(hipEventCreate(&ctx->t1));
@@ -65,8 +66,21 @@ int sd_ctx_destroy(sd_ctx* ctx) {
     (void)hipEventDestroy(ctx->p0);
     (void)hipEventDestroy(ctx->p1);
     if (ctx->ws_ptr) (void)hipFree(ctx->ws_ptr);
+    sd_pool_trim(ctx);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return SD_OK;
+}
+
+int sd_ctx_release_cached(sd_ctx* ctx) {
+    SD_CHECK_ARG(ctx, "ctx is NULL");
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_pool_trim(ctx);
+    if (ctx->ws_ptr) {
+        SD_HIP(hipFree(ctx->ws_ptr));
+        ctx->ws_ptr = nullptr;
+        ctx->ws_size = 0;
+    }
     return SD_OK;
 }
 
@@ -175,6 +189,56 @@ int sd_prof_names(sd_ctx* ctx, char* buf, size_t buf_len) {
 }
 
 }  // extern "C"
+
+hipError_t sd_pool_malloc(sd_ctx* ctx, void** p, size_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 8;
+    auto it = ctx->pool_free.find(bytes);
+    if (it != ctx->pool_free.end()) {
+        *p = it->second;
+        ctx->pool_free.erase(it);
+        ctx->pool_cached -= bytes;
+    } else {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipErrorOutOfMemory && !ctx->pool_free.empty()) {  // give the cached blocks back and retry once
+            (void)hipGetLastError();
+            sd_pool_trim(ctx);
+            e = hipMalloc(p, bytes);
+        }
+        if (e != hipSuccess) return e;
+    }
+    ctx->pool_live[*p] = bytes;
+    return hipSuccess;
+}
+
+void sd_pool_release(sd_ctx* ctx, void* p) {
+    if (!p) return;
+    if (!ctx) {
+        (void)hipFree(p);
+        return;
+    }
+    auto it = ctx->pool_live.find(p);
+    if (it == ctx->pool_live.end()) {  // not ours (imported pointer): plain free
+        (void)hipFree(p);
+        return;
+    }
+    const size_t bytes = it->second;
+    ctx->pool_live.erase(it);
+    if (ctx->pool_cached + bytes > ctx->pool_cap) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(p);
+        return;
+    }
+    ctx->pool_free.emplace(bytes, p);
+    ctx->pool_cached += bytes;
+}
+
+void sd_pool_trim(sd_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+    ctx->pool_free.clear();
+    ctx->pool_cached = 0;
+}
 
 int sd_workspace(sd_ctx* ctx, size_t bytes, void** out) {
     if (bytes > ctx->ws_size) {
@@ -292,7 +356,7 @@ extern "C" int sd_synth_fill(sd_ctx* ctx, double* out_dev, int64_t T, int64_t C,
     const uint64_t h0b = stream2 >= 0 ? host_splitmix64(seed ^ host_splitmix64((uint64_t)stream2)) : 0;
     sd_scratch base;
     if (base_host) {
-        SD_HIP(hipMalloc(&base.p, sizeof(double) * T));
+        SD_HIP(base.alloc(ctx, sizeof(double) * T));
         SD_HIP(hipMemcpyAsync(base.p, base_host, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
     }
     const int64_t total = T * C;

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -36,7 +37,19 @@ struct sd_ctx {
     // scratch costs tens of ms per call)
     void* ws_ptr = nullptr;
     size_t ws_size = 0;
+    // size-keyed cache of device blocks released by states / per-call scratch: hipMalloc + hipFree of a GB-sized
+    // block cost tens of milliseconds, a fit -> predict -> destroy cycle would spend more time there than in kernels
+    std::multimap<size_t, void*> pool_free;
+    std::unordered_map<void*, size_t> pool_live;
+    size_t pool_cached = 0, pool_cap = 0;
 };
+
+// Device memory through the context's block cache (exact-size reuse).  Blocks go back with sd_pool_release;
+// the cache is bounded by pool_cap (a quarter of the device memory) and emptied by sd_ctx_release_cached /
+// sd_ctx_destroy or when an allocation fails.
+hipError_t sd_pool_malloc(sd_ctx* ctx, void** p, size_t bytes);
+void sd_pool_release(sd_ctx* ctx, void* p);
+void sd_pool_trim(sd_ctx* ctx);
 
 struct sd_bcsd_state {
     sd_ctx* ctx = nullptr;
@@ -61,6 +74,7 @@ struct sd_analog_state {
     // F == 1 fast path: per cell training values sorted ascending + original indices
     double* xs = nullptr;   // device [C][T]
     int32_t* xi = nullptr;  // device [C][T]
+    double* yx = nullptr;   // device [C][T]: y in the order of xs (analog values of a sorted-x window are contiguous)
 };
 
 int sd_set_error(int code, const char* fmt, ...);
@@ -99,11 +113,16 @@ int sd_prof_end(sd_ctx* ctx, const char* name);
         SD_TRY(sd_prof_end(ctx, name));                                                      \
     } while (0)
 
-// RAII device scratch buffer (freed asynchronously on the context stream order by hipFree sync).
+// RAII device scratch buffer from the context's block cache (callers synchronise the stream before returning).
 struct sd_scratch {
     void* p = nullptr;
+    sd_ctx* owner = nullptr;
+    hipError_t alloc(sd_ctx* ctx, size_t bytes) {
+        owner = ctx;
+        return sd_pool_malloc(ctx, &p, bytes);
+    }
     ~sd_scratch() {
-        if (p) (void)hipFree(p);
+        if (p) sd_pool_release(owner, p);
     }
     template <typename T>
     T* as() { return static_cast<T*>(p); }

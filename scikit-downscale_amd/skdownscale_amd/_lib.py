@@ -32,6 +32,7 @@ SIGNATURES = {
     "sd_ctx_create": [_int, C.POINTER(_p)],
     "sd_ctx_destroy": [_p],
     "sd_ctx_synchronize": [_p],
+    "sd_ctx_release_cached": [_p],
     "sd_ctx_device_info": [_p, C.c_char_p, C.c_size_t, C.POINTER(_int), C.POINTER(_i64)],
     "sd_dev_alloc": [_p, C.c_size_t, C.POINTER(_p)],
     "sd_dev_free": [_p, _p],

@@ -137,6 +137,10 @@ class Context:
     def synchronize(self):
         check(self.lib.sd_ctx_synchronize(self.handle))
 
+    def release_cached(self):
+        """Give the context's cached device blocks (recycled state / scratch buffers) back to the driver."""
+        check(self.lib.sd_ctx_release_cached(self.handle))
+
     def timer_start(self):
         check(self.lib.sd_timer_start(self.handle))
 
