@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "sd_internal.h"
+#include "sd_sortnet.h"
 
 namespace {
 
@@ -123,6 +124,93 @@ __global__ void __launch_bounds__(1024) analog_sort_kernel(const double* __restr
         }
         __syncthreads();
     }
+}
+
+// F == 1, fast form of the same result: two workgroup-level merge sorts of plain float64 keys (sd_sortnet.h).
+//   1. sort x                       -> xs
+//   2. every training sample finds lb = first position of its value in xs (binary search); the keys
+//      lb * 65536 + index are distinct integers < 2^32 (exact in float64) whose order is exactly the
+//      lexicographic (x, index) order; sorting them yields xi, and yx = y[xi].
+// One 1024-thread workgroup per cell, K consecutive samples per thread, T <= 1024 * K.
+template <int K>
+__global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __restrict__ Xc, const double* __restrict__ yc,
+                                                            int64_t T, int64_t C, double* __restrict__ xs,
+                                                            int32_t* __restrict__ xi, double* __restrict__ yx) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x;
+    const int np = (n + K - 1) / K * K;
+    double* buf = reinterpret_cast<double*>(smem_raw);     // np + 1 doubles
+    int* xch = reinterpret_cast<int*>(buf + np + 1);        // nthr + 1 ints
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const double* x = Xc + c * T;
+        __syncthreads();
+        for (int i = tid; i <= np; i += nthr) buf[i] = i < n ? x[i] : inf;  // coalesced load, blocked read below
+        __syncthreads();
+        double v[K], orig[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int j = K * tid + i;
+            v[i] = buf[j < np ? j : np];  // lane stride K is odd: conflict-free
+            orig[i] = v[i];
+        }
+        __syncthreads();
+        sdsort::block_merge_sort<K>(v, buf, np, xch, tid, nthr);
+        for (int i = tid; i < n; i += nthr) xs[c * T + i] = buf[i];
+        // lb = number of sorted values < x (branch-free binary search; strides that are multiples of 16
+        // doubles are shortened by one: see the rank search in sd_bcsd_rs.hip)
+        double key2[K];
+        {
+            int pos[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) pos[i] = -1;  // index of the last element known to be < x
+#pragma unroll 1
+            for (int len = n; len > 1;) {
+                int half = len >> 1;
+                if ((half & 15) == 0) --half;
+                len -= half;
+#pragma unroll
+                for (int i = 0; i < K; ++i) pos[i] += buf[pos[i] + half] < orig[i] ? half : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = K * tid + i;
+                const int lb = pos[i] + 1 + (buf[pos[i] + 1] < orig[i] ? 1 : 0);
+                key2[i] = j < n ? (double)lb * 65536.0 + (double)j : inf;
+            }
+        }
+        __syncthreads();
+        sdsort::block_merge_sort<K>(key2, buf, np, xch, tid, nthr);
+        const double* yy = yc + c * T;
+        for (int i = tid; i < n; i += nthr) {
+            const unsigned kk = (unsigned)buf[i];
+            const int idx = (int)(kk & 0xffffu);
+            xi[c * T + i] = idx;
+            yx[c * T + i] = yy[idx];
+        }
+    }
+}
+
+template <int K>
+int launch_sort2(sd_ctx* ctx, sd_analog_state* st) {
+    const int np = (int)((st->T + K - 1) / K * K);
+    const size_t lds = sizeof(double) * (size_t)(np + 1) + sizeof(int) * 1025;
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort2_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    const int nb = (int)std::min<int64_t>(st->C, (int64_t)ctx->cu_count * 4);
+    SD_LAUNCH(ctx, "analog_sort2_kernel", analog_sort2_kernel<K>, dim3(nb), dim3(1024), lds, (const double*)st->X,
+              (const double*)st->y, st->T, st->C, st->xs, st->xi, st->yx);
+    return SD_OK;
+}
+
+// widths instantiated for the fast sort: T <= 1024 * K and the keys must fit the LDS
+int sort2_width(int64_t T, size_t lds_max) {
+    const int widths[] = {5, 9, 13, 15, 17, 19};
+    for (int K : widths) {
+        const int64_t np = (T + K - 1) / K * K;
+        if (T <= (int64_t)1024 * K && T <= 65535 && sizeof(double) * (size_t)(np + 1) + sizeof(int) * 1025 <= lds_max) return K;
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -435,6 +523,9 @@ __device__ void f1_walk_query(int mode, const PredictArgs& pa, int n, int64_t T,
     finish_query(mode, pa, 1, T, c, tq, &q, Xc_cell, yc_cell, sd, si, nthr, true);
 }
 
+constexpr int kWinQ = 2;      // queries a thread answers together (independent dependency chains)
+constexpr int kWinBatch = 8;  // analog values requested together per query (one memory latency per batch)
+
 __global__ void __launch_bounds__(1024) analog_f1_window_kernel(const double* __restrict__ Xq, int64_t ld, int64_t Tq,
                                                                 int64_t T, int64_t C, const double* __restrict__ xs_all,
                                                                 const int32_t* __restrict__ xi_all,
@@ -443,12 +534,14 @@ __global__ void __launch_bounds__(1024) analog_f1_window_kernel(const double* __
                                                                 const int32_t* __restrict__ fit_status, int32_t* status,
                                                                 double* scratch_d, int32_t* scratch_i, PredictArgs pa) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* xs = reinterpret_cast<double*>(smem_raw);
+    double* xs = reinterpret_cast<double*>(smem_raw);  // n sorted values + one +inf sentinel
     const int nthr = blockDim.x, tid = threadIdx.x;
     const int n = (int)T, k = pa.k;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     double* sd = scratch_d + (int64_t)blockIdx.x * k * nthr;
     int32_t* si = scratch_i + (int64_t)blockIdx.x * k * nthr;
+    int nsteps = 0;  // fixed trip count of the window search: every lane and query runs the same loop
+    while ((1 << nsteps) < n - k + 1) ++nsteps;
     int64_t step, end;
     for (int64_t c = first_cell(C, &step, &end); c < end; c += step) {
         const bool active = fit_status[c] == 0;
@@ -457,95 +550,128 @@ __global__ void __launch_bounds__(1024) analog_f1_window_kernel(const double* __
         __syncthreads();
         if (active)
             for (int i = tid; i < n; i += nthr) xs[i] = xs_all[c * T + i];
+        if (tid == 0) xs[n] = __longlong_as_double(0x7ff0000000000000ll);
         __syncthreads();
-        for (int64_t tq = tid; tq < Tq; tq += nthr) {
-            const double q = Xq[tq * ld + c];
-            bool ok = active;
-            if (active && !sd_finite(q)) {
-                atomicOr(&status[c], SDI_NONFINITE);
-                ok = false;
+        for (int64_t tq0 = tid; tq0 < Tq; tq0 += (int64_t)nthr * kWinQ) {
+            double q[kWinQ];
+            bool has[kWinQ], ok[kWinQ];
+#pragma unroll
+            for (int j = 0; j < kWinQ; ++j) {
+                const int64_t tq = tq0 + (int64_t)j * nthr;
+                has[j] = tq < Tq;
+                q[j] = has[j] ? Xq[tq * ld + c] : 0.0;
             }
-            double pred = nan, prob = nan, err = nan;
-            if (ok) {
-                // window start: smallest L with rdist(L) <= rdist(L + k) (rdist is unimodal along the sorted view)
-                int lo = 0, hi = n - k;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (sq_dist(q, xs[mid]) > sq_dist(q, xs[mid + k])) lo = mid + 1; else hi = mid;
+#pragma unroll
+            for (int j = 0; j < kWinQ; ++j) {
+                ok[j] = active && has[j];
+                if (ok[j] && !sd_finite(q[j])) {
+                    atomicOr(&status[c], SDI_NONFINITE);
+                    ok[j] = false;
                 }
-                const int L = lo;
-                const double dL = sq_dist(q, xs[L]), dR = sq_dist(q, xs[L + k - 1]);
+                if (!ok[j]) q[j] = 0.0;
+            }
+            // window start: smallest L with rdist(L) <= rdist(L + k) (rdist is unimodal along the sorted view)
+            int lo[kWinQ], hi[kWinQ];
+#pragma unroll
+            for (int j = 0; j < kWinQ; ++j) {
+                lo[j] = 0;
+                hi[j] = n - k;
+            }
+#pragma unroll 1
+            for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+                for (int j = 0; j < kWinQ; ++j) {
+                    const int mid = (lo[j] + hi[j]) >> 1;
+                    const bool act = lo[j] < hi[j];
+                    const bool right = sq_dist(q[j], xs[mid]) > sq_dist(q[j], xs[mid + k]);
+                    lo[j] = (act && right) ? mid + 1 : lo[j];
+                    hi[j] = (act && !right) ? mid : hi[j];
+                }
+            }
+            bool unique[kWinQ];
+            double a0[kWinQ], s1[kWinQ], s2[kWinQ], wsum[kWinQ], awsum[kWinQ], best_d[kWinQ], best_a[kWinQ];
+            int nexc[kWinQ], nbest[kWinQ];
+#pragma unroll
+            for (int j = 0; j < kWinQ; ++j) {
+                const int L = lo[j];
+                const double dL = sq_dist(q[j], xs[L]), dR = sq_dist(q[j], xs[L + k - 1]);
                 const double worst = dL > dR ? dL : dR;
-                const bool sep_l = L == 0 || sq_dist(q, xs[L - 1]) > worst;
-                const bool sep_r = L + k == n || sq_dist(q, xs[L + k]) > worst;
-                // 'best' needs a unique nearest element as well
-                bool unique = sep_l && sep_r;
-                if (unique) {
-                    const double* a = yx + L;
-                    const double a0 = a[0];
-                    double s1 = 0.0, s2 = 0.0, wsum = 0.0, awsum = 0.0, best_d = dL, best_a = a0;
-                    int nexc = 0, nbest = 0;
-                    constexpr int kBatch = 8;  // analog values are requested kBatch at a time (one latency per batch)
-                    for (int i0 = 0; i0 < k; i0 += kBatch) {
-                        double av[kBatch];
+                const bool sep_l = L == 0 || sq_dist(q[j], xs[L - 1]) > worst;
+                const bool sep_r = L + k == n || sq_dist(q[j], xs[L + k]) > worst;
+                unique[j] = sep_l && sep_r;
+                s1[j] = s2[j] = wsum[j] = awsum[j] = 0.0;
+                best_d[j] = dL;
+                nexc[j] = nbest[j] = 0;
+                a0[j] = best_a[j] = yx[L];
+            }
+            for (int i0 = 0; i0 < k; i0 += kWinBatch) {
+                double av[kWinQ][kWinBatch];
 #pragma unroll
-                        for (int j = 0; j < kBatch; ++j) av[j] = a[i0 + j < k ? i0 + j : k - 1];
+                for (int j = 0; j < kWinQ; ++j)
 #pragma unroll
-                        for (int j = 0; j < kBatch; ++j) {
-                            const int i = i0 + j;
-                            if (i >= k) break;
-                            const double ai = av[j];
-                            const double e = ai - a0;
-                            s1 += e;
-                            s2 += e * e;
-                            nexc += (!pa.has_thresh || ai > pa.thresh) ? 1 : 0;  // gard.py:307
+                    for (int b = 0; b < kWinBatch; ++b) av[j][b] = yx[lo[j] + (i0 + b < k ? i0 + b : k - 1)];
+#pragma unroll
+                for (int j = 0; j < kWinQ; ++j)
+#pragma unroll
+                    for (int b = 0; b < kWinBatch; ++b) {
+                        const int i = i0 + b;
+                        if (i < k) {
+                            const double ai = av[j][b];
+                            const double e = ai - a0[j];
+                            s1[j] += e;
+                            s2[j] += e * e;
+                            nexc[j] += (!pa.has_thresh || ai > pa.thresh) ? 1 : 0;  // gard.py:307
                             if (pa.kind != SD_ANALOG_MEAN) {
-                                const double rd = sq_dist(q, xs[L + i]);
+                                const double rd = sq_dist(q[j], xs[lo[j] + i]);
                                 if (pa.kind == SD_ANALOG_WEIGHT) {
                                     const double d = sqrt(rd);
                                     const double w = 1.0 / (d == 0.0 ? 1e-20 : d);  // gard.py:322-323
-                                    wsum += w;
-                                    awsum += ai * w;
-                                } else {
-                                    if (rd < best_d || i == 0) { best_d = rd; best_a = ai; nbest = 1; }
-                                    else if (rd == best_d) ++nbest;
+                                    wsum[j] += w;
+                                    awsum[j] += ai * w;
+                                } else if (rd < best_d[j] || i == 0) {
+                                    best_d[j] = rd;
+                                    best_a[j] = ai;
+                                    nbest[j] = 1;
+                                } else if (rd == best_d[j]) {
+                                    ++nbest[j];
                                 }
                             }
                         }
                     }
-                    if (pa.kind == SD_ANALOG_BEST && nbest != 1) unique = false;  // two nearest at one distance: index order decides
-                    if (unique) {
-                        const bool any_masked = nexc != k;
-                        const double kk = (double)k;
-                        const double mean = a0 + s1 / kk;
-                        double p;
-                        if (pa.kind == SD_ANALOG_BEST) p = best_a;                                  // gard.py:311
-                        else if (pa.kind == SD_ANALOG_WEIGHT) p = any_masked ? nan : awsum / wsum;  // gard.py:319-327
-                        else p = any_masked ? nan : mean;                                           // gard.py:329-333
-                        if (pa.has_thresh) {
-                            p = nan_to_num(p);        // gard.py:341
-                            prob = (double)nexc / kk;  // gard.py:343
-                        } else {
-                            prob = 1.0;  // gard.py:346
-                        }
-                        if (any_masked) {
-                            err = nan;  // gard.py:342
-                        } else {
-                            const double m1 = s1 / kk;
-                            const double var = s2 / kk - m1 * m1;  // shifted by the first analog: no cancellation
-                            err = sqrt(var > 0.0 ? var : 0.0);     // ddof = 0 (gard.py:342,345)
-                        }
-                        pred = p;
+            }
+#pragma unroll
+            for (int j = 0; j < kWinQ; ++j) {
+                if (!has[j]) continue;
+                const int64_t tq = tq0 + (int64_t)j * nthr;
+                double pred = nan, prob = nan, err = nan;
+                if (ok[j]) {
+                    // 'best' also needs a single nearest element; otherwise the training index decides
+                    if (pa.kind == SD_ANALOG_BEST && nbest[j] != 1) unique[j] = false;
+                    if (!unique[j]) {
+                        f1_walk_query(0, pa, n, T, c, tq, q[j], xs, xi, Xc + c * T, yc + c * T, sd, si, nthr);
+                        continue;
+                    }
+                    const bool any_masked = nexc[j] != k;
+                    const double kk = (double)k;
+                    const double m1 = s1[j] / kk;
+                    if (pa.kind == SD_ANALOG_BEST) pred = best_a[j];                                        // gard.py:311
+                    else if (pa.kind == SD_ANALOG_WEIGHT) pred = any_masked ? nan : awsum[j] / wsum[j];     // gard.py:319-327
+                    else pred = any_masked ? nan : a0[j] + m1;                                              // gard.py:329-333
+                    if (pa.has_thresh) {
+                        pred = nan_to_num(pred);       // gard.py:341
+                        prob = (double)nexc[j] / kk;    // gard.py:343
+                    } else {
+                        prob = 1.0;  // gard.py:346
+                    }
+                    if (!any_masked) {
+                        const double var = s2[j] / kk - m1 * m1;  // sums are shifted by the first analog: no cancellation
+                        err = sqrt(var > 0.0 ? var : 0.0);        // ddof = 0 (gard.py:342,345)
                     }
                 }
-                if (!unique) {
-                    f1_walk_query(0, pa, n, T, c, tq, q, xs, xi, Xc + c * T, yc + c * T, sd, si, nthr);
-                    continue;
-                }
+                pa.out[(tq * 3 + 0) * pa.ld_out + c] = pred;
+                pa.out[(tq * 3 + 1) * pa.ld_out + c] = prob;
+                pa.out[(tq * 3 + 2) * pa.ld_out + c] = err;
             }
-            pa.out[(tq * 3 + 0) * pa.ld_out + c] = pred;
-            pa.out[(tq * 3 + 1) * pa.ld_out + c] = prob;
-            pa.out[(tq * 3 + 2) * pa.ld_out + c] = err;
         }
     }
 }
@@ -700,7 +826,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
     const bool window = f1 && mode == 0 && kind != SD_ANALOG_SAMPLE && !inds && !dist && st->yx != nullptr &&
                         getenv("SD_ANALOG_WALK") == nullptr;
     if (window) {
-        const size_t lds = sizeof(double) * T;
+        const size_t lds = sizeof(double) * (T + 1);
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_window_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         SD_LAUNCH(ctx, "analog_f1_window_kernel", analog_f1_window_kernel, dim3(nb), dim3(nthr), lds, Xq, ld, Tq, T, C,
@@ -811,16 +937,28 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
         SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, grid, dim3(256), 0, y_dev, ld, T, 1, 0, C,
                   st->y, st->status, 0);
         const size_t lds = (size_t)T * (sizeof(double) + sizeof(uint16_t));
-        if (F == 1 && T <= 65535 && lds <= ctx->lds_max) {
+        if (F == 1 && T <= 65535 && (lds <= ctx->lds_max || sort2_width(T, ctx->lds_max) != 0) &&
+            sizeof(double) * (size_t)(T + 1) <= ctx->lds_max) {
             // sorted view for the 1-D fast path: values, original indices, and y in the same order
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->xs, sizeof(double) * (size_t)T * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->xi, sizeof(int32_t) * (size_t)T * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->yx, sizeof(double) * (size_t)T * C));
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            int nb = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 4);
-            SD_LAUNCH(ctx, "analog_sort_kernel", analog_sort_kernel, dim3(nb), dim3(1024), lds, (const double*)st->X,
-                      (const double*)st->y, T, C, st->xs, st->xi, st->yx);
+            const int K2 = getenv("SD_ANALOG_SORT1") ? 0 : sort2_width(T, ctx->lds_max);
+            switch (K2) {
+                case 5: SD_TRY(launch_sort2<5>(ctx, st)); break;
+                case 9: SD_TRY(launch_sort2<9>(ctx, st)); break;
+                case 13: SD_TRY(launch_sort2<13>(ctx, st)); break;
+                case 15: SD_TRY(launch_sort2<15>(ctx, st)); break;
+                case 17: SD_TRY(launch_sort2<17>(ctx, st)); break;
+                case 19: SD_TRY(launch_sort2<19>(ctx, st)); break;
+                default: {
+                    int nb = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 4);
+                    SD_LAUNCH(ctx, "analog_sort_kernel", analog_sort_kernel, dim3(nb), dim3(1024), lds, (const double*)st->X,
+                              (const double*)st->y, T, C, st->xs, st->xi, st->yx);
+                }
+            }
             SD_HIP(hipStreamSynchronize(ctx->stream));
         }
         SD_HIP(hipStreamSynchronize(ctx->stream));

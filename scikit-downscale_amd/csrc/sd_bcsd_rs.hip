@@ -25,8 +25,11 @@
 #include <cstdlib>
 
 #include "sd_bcsd_rs.h"
+#include "sd_sortnet.h"
 
 namespace sdrs {
+
+using namespace sdsort;
 
 constexpr int kWave = 64;
 constexpr int kW = 8;          // cells per workgroup
@@ -43,96 +46,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 // Lanes of one wave exchange data through LDS inside the sort.  The hardware serves a wave's LDS
 // requests in order; for the compiler the exchange needs a wavefront-scope fence plus the wave barrier.
-// min/max straight to the hardware instructions: __builtin_fmin/fmax make the compiler canonicalise every
-// freshly loaded operand first (one extra v_max_f64 x,x per element and merge round).  NaNs never reach the
-// sort of a cell whose result is kept (such cells are flagged non-finite and overwritten with NaN).
-__device__ __forceinline__ double vmin(double a, double b) {
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double vmax(double a, double b) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-
-// ---- Batcher odd-even merge sort network for K registers (built at compile time) ----------------
-template <int K>
-struct Net {
-    static constexpr int N = K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : 64;
-    static constexpr int kMax = 600;
-    int n = 0;
-    unsigned char a[kMax] = {}, b[kMax] = {};
-    constexpr Net() {
-        for (int p = 1; p < N; p <<= 1)
-            for (int k = p; k >= 1; k >>= 1)
-                for (int j = k % p; j + k < N; j += 2 * k)
-                    for (int i = 0; i < k; ++i) {
-                        const int lo = i + j, hi = i + j + k;
-                        if (hi < N && lo / (2 * p) == hi / (2 * p) && hi < K) {  // comparators touching the +inf padding are no-ops
-                            a[n] = (unsigned char)lo;
-                            b[n] = (unsigned char)hi;
-                            ++n;
-                        }
-                    }
-    }
-};
-
-template <int K>
-__device__ __forceinline__ void sort_registers(double (&v)[K]) {
-    constexpr Net<K> net{};
-#pragma unroll
-    for (int c = 0; c < net.n; ++c) {
-        const double lo = vmin(v[net.a[c]], v[net.b[c]]);
-        const double hi = vmax(v[net.a[c]], v[net.b[c]]);
-        v[net.a[c]] = lo;
-        v[net.b[c]] = hi;
-    }
-}
-
-constexpr int ceil_log2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
-
-// ---- bitonic merger for K registers (built at compile time) --------------------------------------
-// A lane's merge window is loaded as [A ascending | +inf filler | B descending] into w[0..K): a bitonic
-// sequence.  Conceptually it is padded with -inf up to the next power of two N and pushed through the
-// standard N-input bitonic merger; comparators against a known -inf are resolved at compile time
-// (pure register renaming), so only ~2K real comparators remain.  out[s] names the register that
-// holds the s-th smallest value afterwards.
-template <int K>
-struct MergeNet {
-    static constexpr int N = K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : 64;
-    int n = 0;
-    unsigned char a[200] = {}, b[200] = {}, out[K] = {};
-    constexpr MergeNet() {
-        int reg[N] = {};
-        bool ninf[N] = {};
-        for (int s = 0; s < N; ++s) {
-            reg[s] = s < K ? s : 0;
-            ninf[s] = s >= K;
-        }
-        for (int h = N / 2; h >= 1; h >>= 1)
-            for (int i = 0; i < N; ++i) {
-                if (i & h) continue;
-                const int j = i + h;
-                if (ninf[i]) continue;  // min(-inf, x) stays put
-                if (ninf[j]) {          // (x, -inf) -> (-inf, x): rename
-                    reg[j] = reg[i];
-                    ninf[j] = false;
-                    ninf[i] = true;
-                    continue;
-                }
-                a[n] = (unsigned char)reg[i];
-                b[n] = (unsigned char)reg[j];
-                ++n;
-            }
-        for (int s = 0; s < K; ++s) out[s] = (unsigned char)reg[N - K + s];
-    }
-};
 
 // ---- wave-level merge sort of row[0..n): runs of K per lane -> fully sorted, in place ------------
 // Round r merges pairs of runs of length K << r.  Every lane owns K consecutive output positions of
