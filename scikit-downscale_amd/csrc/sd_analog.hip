@@ -71,6 +71,23 @@ __global__ void __launch_bounds__(256) analog_transpose_kernel(const double* __r
     }
 }
 
+// cell-major staging [C][3][Tq] -> output field [Tq, 3, ld] through a 32x33 LDS tile (grid: cells/32, Tq/32, 3)
+__global__ void __launch_bounds__(256) analog_untranspose_kernel(const double* __restrict__ oc, int64_t Tq, int64_t C,
+                                                                 double* __restrict__ out, int64_t ld) {
+    __shared__ double tile[32][33];
+    const int64_t c0 = (int64_t)blockIdx.x * 32, t0 = (int64_t)blockIdx.y * 32;
+    const int j = blockIdx.z, tx = threadIdx.x % 32, ty = threadIdx.x / 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t c = c0 + r, t = t0 + tx;
+        tile[r][tx] = (c < C && t < Tq) ? oc[(c * 3 + j) * Tq + t] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t t = t0 + r, c = c0 + tx;
+        if (t < Tq && c < C) out[(t * 3 + j) * ld + c] = tile[tx][r];
+    }
+}
+
 // F == 1: per-cell sort of (x, index) ascending, lexicographic.  One workgroup per cell, keys and
 // 16-bit indices in LDS, truncated standard-form bitonic network (see sd_bcsd.hip).
 __global__ void __launch_bounds__(1024) analog_sort_kernel(const double* __restrict__ Xc, const double* __restrict__ yc,
@@ -216,16 +233,33 @@ int sort2_width(int64_t T, size_t lds_max) {
 // ------------------------------------------------------------------------------------------------
 // epilogues (run by the thread that owns the query; lists are [k][nthr] in scratch)
 // ------------------------------------------------------------------------------------------------
+struct PredictArgs;
+__device__ __forceinline__ void put_out(const PredictArgs& pa, int64_t tq, int64_t c, double pred, double prob, double err);
+
 struct PredictArgs {
     int k, kind, has_thresh;
     double thresh;
     const int32_t* sample;  // device [Tq, ld_s] or null
     int64_t ld_s;
-    double* out;            // [Tq,3,ld_out]
+    double* out;            // [Tq,3,ld_out]; windowed path: cell-major staging [C][3][Tq] (oc_Tq > 0)
     int64_t ld_out;
+    int64_t oc_Tq;          // > 0: out is the cell-major staging buffer of a Tq-long query series
     int64_t* inds;          // [Tq,k,ld_out] or null
     double* dist;           // [Tq,k,ld_out] or null
 };
+
+__device__ __forceinline__ void put_out(const PredictArgs& pa, int64_t tq, int64_t c, double pred, double prob, double err) {
+    if (pa.oc_Tq > 0) {  // consecutive queries of a cell are consecutive in memory: coalesced across the workgroup
+        double* o = pa.out + c * 3 * pa.oc_Tq + tq;
+        o[0] = pred;
+        o[pa.oc_Tq] = prob;
+        o[2 * pa.oc_Tq] = err;
+    } else {
+        pa.out[(tq * 3 + 0) * pa.ld_out + c] = pred;
+        pa.out[(tq * 3 + 1) * pa.ld_out + c] = prob;
+        pa.out[(tq * 3 + 2) * pa.ld_out + c] = err;
+    }
+}
 
 __device__ __forceinline__ double nan_to_num(double v) {
     if (v != v) return 0.0;
@@ -375,9 +409,7 @@ __device__ void finish_query(int mode, const PredictArgs& pa, int F, int64_t T, 
             k, F, [&](int i, int f) { return Xc_cell[(int64_t)f * T + si[(int64_t)i * nthr + tid]]; },
             [&](int i) { return yc_cell[si[(int64_t)i * nthr + tid]]; }, q, &pred, &err);
     }
-    pa.out[(tq * 3 + 0) * pa.ld_out + c] = pred;
-    pa.out[(tq * 3 + 1) * pa.ld_out + c] = prob;
-    pa.out[(tq * 3 + 2) * pa.ld_out + c] = err;
+    put_out(pa, tq, c, pred, prob, err);
     if (cell_active && pa.inds)
         for (int i = 0; i < k; ++i) pa.inds[(tq * k + i) * pa.ld_out + c] = si[(int64_t)i * nthr + tid];
     if (cell_active && pa.dist)
@@ -524,153 +556,172 @@ __device__ void f1_walk_query(int mode, const PredictArgs& pa, int n, int64_t T,
 }
 
 constexpr int kWinQ = 2;      // queries a thread answers together (independent dependency chains)
-constexpr int kWinBatch = 8;  // analog values requested together per query (one memory latency per batch)
+constexpr int kWinBatch = 8;  // analog values read together per query
 
+// The sorted view of a cell is processed in `npass` value ranges so that both xs and yx of a range (plus k
+// entries of margin on either side) sit in LDS: the window search and the k analog values of a query are LDS
+// reads, HBM/L2 only see the query and the three outputs.  A query belongs to the range that holds its value;
+// its k nearest neighbours are at most k positions away from there.
 __global__ void __launch_bounds__(1024) analog_f1_window_kernel(const double* __restrict__ Xq, int64_t ld, int64_t Tq,
-                                                                int64_t T, int64_t C, const double* __restrict__ xs_all,
+                                                                int64_t T, int64_t C, int npass,
+                                                                const double* __restrict__ xs_all,
                                                                 const int32_t* __restrict__ xi_all,
                                                                 const double* __restrict__ yx_all,
                                                                 const double* __restrict__ Xc, const double* __restrict__ yc,
                                                                 const int32_t* __restrict__ fit_status, int32_t* status,
                                                                 double* scratch_d, int32_t* scratch_i, PredictArgs pa) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* xs = reinterpret_cast<double*>(smem_raw);  // n sorted values + one +inf sentinel
     const int nthr = blockDim.x, tid = threadIdx.x;
     const int n = (int)T, k = pa.k;
+    const int seg = (n + npass - 1) / npass;
+    const int cap = seg + 2 * k + 1;                        // local entries per pass (upper bound)
+    double* xs = reinterpret_cast<double*>(smem_raw);       // cap + 1 doubles (sentinel)
+    double* yl = xs + cap + 1;                              // cap doubles
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
     double* sd = scratch_d + (int64_t)blockIdx.x * k * nthr;
     int32_t* si = scratch_i + (int64_t)blockIdx.x * k * nthr;
-    int nsteps = 0;  // fixed trip count of the window search: every lane and query runs the same loop
-    while ((1 << nsteps) < n - k + 1) ++nsteps;
     int64_t step, end;
     for (int64_t c = first_cell(C, &step, &end); c < end; c += step) {
         const bool active = fit_status[c] == 0;
         const int32_t* xi = xi_all + c * T;
+        const double* xg = xs_all + c * T;
         const double* yx = yx_all + c * T;
-        __syncthreads();
-        if (active)
-            for (int i = tid; i < n; i += nthr) xs[i] = xs_all[c * T + i];
-        if (tid == 0) xs[n] = __longlong_as_double(0x7ff0000000000000ll);
-        __syncthreads();
-        for (int64_t tq0 = tid; tq0 < Tq; tq0 += (int64_t)nthr * kWinQ) {
-            double q[kWinQ];
-            bool has[kWinQ], ok[kWinQ];
-#pragma unroll
-            for (int j = 0; j < kWinQ; ++j) {
-                const int64_t tq = tq0 + (int64_t)j * nthr;
-                has[j] = tq < Tq;
-                q[j] = has[j] ? Xq[tq * ld + c] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < kWinQ; ++j) {
-                ok[j] = active && has[j];
-                if (ok[j] && !sd_finite(q[j])) {
-                    atomicOr(&status[c], SDI_NONFINITE);
-                    ok[j] = false;
+        for (int p = 0; p < npass; ++p) {
+            const int b0 = p * seg < n ? p * seg : n, b1 = (p + 1) * seg < n ? (p + 1) * seg : n;
+            if (b0 >= b1) break;
+            const int g0 = b0 - k > 0 ? b0 - k : 0, g1 = b1 + k < n ? b1 + k : n;  // global range held in LDS
+            const int nl = g1 - g0;
+            // value range of this pass: [vlo, vhi), open-ended at the ends of the sorted view
+            const double vlo = (p == 0 || !active) ? -inf : xg[b0];
+            const double vhi = (b1 >= n || !active) ? inf : xg[b1];
+            __syncthreads();
+            if (active)
+                for (int i = tid; i < nl; i += nthr) {
+                    xs[i] = xg[g0 + i];
+                    yl[i] = yx[g0 + i];
                 }
-                if (!ok[j]) q[j] = 0.0;
-            }
-            // window start: smallest L with rdist(L) <= rdist(L + k) (rdist is unimodal along the sorted view)
-            int lo[kWinQ], hi[kWinQ];
-#pragma unroll
-            for (int j = 0; j < kWinQ; ++j) {
-                lo[j] = 0;
-                hi[j] = n - k;
-            }
-#pragma unroll 1
-            for (int s = 0; s < nsteps; ++s) {
+            if (tid == 0) xs[nl] = inf;
+            __syncthreads();
+            int nsteps = 0;  // fixed trip count of the window search: every lane and query runs the same loop
+            while ((1 << nsteps) < nl - k + 1) ++nsteps;
+            for (int64_t tq0 = tid; tq0 < Tq; tq0 += (int64_t)nthr * kWinQ) {
+                double q[kWinQ];
+                bool has[kWinQ], ok[kWinQ], mine[kWinQ];
 #pragma unroll
                 for (int j = 0; j < kWinQ; ++j) {
-                    const int mid = (lo[j] + hi[j]) >> 1;
-                    const bool act = lo[j] < hi[j];
-                    const bool right = sq_dist(q[j], xs[mid]) > sq_dist(q[j], xs[mid + k]);
-                    lo[j] = (act && right) ? mid + 1 : lo[j];
-                    hi[j] = (act && !right) ? mid : hi[j];
+                    const int64_t tq = tq0 + (int64_t)j * nthr;
+                    has[j] = tq < Tq;
+                    q[j] = has[j] ? Xq[c * ld + tq] : 0.0;  // cell-major copy of the queries (ld = Tq)
                 }
-            }
-            bool unique[kWinQ];
-            double a0[kWinQ], s1[kWinQ], s2[kWinQ], wsum[kWinQ], awsum[kWinQ], best_d[kWinQ], best_a[kWinQ];
-            int nexc[kWinQ], nbest[kWinQ];
+                bool any = false;
 #pragma unroll
-            for (int j = 0; j < kWinQ; ++j) {
-                const int L = lo[j];
-                const double dL = sq_dist(q[j], xs[L]), dR = sq_dist(q[j], xs[L + k - 1]);
-                const double worst = dL > dR ? dL : dR;
-                const bool sep_l = L == 0 || sq_dist(q[j], xs[L - 1]) > worst;
-                const bool sep_r = L + k == n || sq_dist(q[j], xs[L + k]) > worst;
-                unique[j] = sep_l && sep_r;
-                s1[j] = s2[j] = wsum[j] = awsum[j] = 0.0;
-                best_d[j] = dL;
-                nexc[j] = nbest[j] = 0;
-                a0[j] = best_a[j] = yx[L];
-            }
-            for (int i0 = 0; i0 < k; i0 += kWinBatch) {
-                double av[kWinQ][kWinBatch];
+                for (int j = 0; j < kWinQ; ++j) {
+                    ok[j] = active && has[j] && sd_finite(q[j]);
+                    // inactive cells and non-finite queries are reported (NaN outputs) in the first pass
+                    mine[j] = has[j] && (ok[j] ? (q[j] >= vlo && q[j] < vhi) || (q[j] == inf) : p == 0);
+                    if (mine[j] && active && !ok[j]) atomicOr(&status[c], SDI_NONFINITE);
+                    if (!ok[j]) q[j] = 0.0;
+                    any |= mine[j];
+                }
+                if (!any) continue;
+                // window start: smallest L with rdist(L) <= rdist(L + k) (rdist is unimodal along the sorted view)
+                int lo[kWinQ], hi[kWinQ];
 #pragma unroll
-                for (int j = 0; j < kWinQ; ++j)
+                for (int j = 0; j < kWinQ; ++j) {
+                    lo[j] = 0;
+                    hi[j] = nl - k;
+                }
+#pragma unroll 1
+                for (int s = 0; s < nsteps; ++s) {
 #pragma unroll
-                    for (int b = 0; b < kWinBatch; ++b) av[j][b] = yx[lo[j] + (i0 + b < k ? i0 + b : k - 1)];
+                    for (int j = 0; j < kWinQ; ++j) {
+                        const int mid = (lo[j] + hi[j]) >> 1;
+                        const bool act = lo[j] < hi[j];
+                        const bool right = sq_dist(q[j], xs[mid]) > sq_dist(q[j], xs[mid + k]);
+                        lo[j] = (act && right) ? mid + 1 : lo[j];
+                        hi[j] = (act && !right) ? mid : hi[j];
+                    }
+                }
+                bool unique[kWinQ];
+                double a0[kWinQ], s1[kWinQ], s2[kWinQ], wsum[kWinQ], awsum[kWinQ], best_d[kWinQ], best_a[kWinQ];
+                int nexc[kWinQ], nbest[kWinQ];
 #pragma unroll
-                for (int j = 0; j < kWinQ; ++j)
+                for (int j = 0; j < kWinQ; ++j) {
+                    const int L = lo[j];
+                    const double dL = sq_dist(q[j], xs[L]), dR = sq_dist(q[j], xs[L + k - 1]);
+                    const double worst = dL > dR ? dL : dR;
+                    // the outside neighbours must be strictly farther; at an edge of the LDS range that is not an
+                    // edge of the sorted view the neighbour is unknown -> exact walk
+                    const bool sep_l = L == 0 ? g0 == 0 : sq_dist(q[j], xs[L - 1]) > worst;
+                    const bool sep_r = L + k == nl ? g1 == n : sq_dist(q[j], xs[L + k]) > worst;
+                    unique[j] = sep_l && sep_r;
+                    s1[j] = s2[j] = wsum[j] = awsum[j] = 0.0;
+                    best_d[j] = dL;
+                    nexc[j] = nbest[j] = 0;
+                    a0[j] = best_a[j] = yl[L];
+                }
+                for (int i0 = 0; i0 < k; i0 += kWinBatch) {
 #pragma unroll
-                    for (int b = 0; b < kWinBatch; ++b) {
-                        const int i = i0 + b;
-                        if (i < k) {
-                            const double ai = av[j][b];
-                            const double e = ai - a0[j];
-                            s1[j] += e;
-                            s2[j] += e * e;
-                            nexc[j] += (!pa.has_thresh || ai > pa.thresh) ? 1 : 0;  // gard.py:307
-                            if (pa.kind != SD_ANALOG_MEAN) {
-                                const double rd = sq_dist(q[j], xs[lo[j] + i]);
-                                if (pa.kind == SD_ANALOG_WEIGHT) {
-                                    const double d = sqrt(rd);
-                                    const double w = 1.0 / (d == 0.0 ? 1e-20 : d);  // gard.py:322-323
-                                    wsum[j] += w;
-                                    awsum[j] += ai * w;
-                                } else if (rd < best_d[j] || i == 0) {
-                                    best_d[j] = rd;
-                                    best_a[j] = ai;
-                                    nbest[j] = 1;
-                                } else if (rd == best_d[j]) {
-                                    ++nbest[j];
+                    for (int j = 0; j < kWinQ; ++j)
+#pragma unroll
+                        for (int b = 0; b < kWinBatch; ++b) {
+                            const int i = i0 + b;
+                            if (i < k) {
+                                const double ai = yl[lo[j] + i];
+                                const double e = ai - a0[j];
+                                s1[j] += e;
+                                s2[j] += e * e;
+                                nexc[j] += (!pa.has_thresh || ai > pa.thresh) ? 1 : 0;  // gard.py:307
+                                if (pa.kind != SD_ANALOG_MEAN) {
+                                    const double rd = sq_dist(q[j], xs[lo[j] + i]);
+                                    if (pa.kind == SD_ANALOG_WEIGHT) {
+                                        const double d = sqrt(rd);
+                                        const double w = 1.0 / (d == 0.0 ? 1e-20 : d);  // gard.py:322-323
+                                        wsum[j] += w;
+                                        awsum[j] += ai * w;
+                                    } else if (rd < best_d[j] || i == 0) {
+                                        best_d[j] = rd;
+                                        best_a[j] = ai;
+                                        nbest[j] = 1;
+                                    } else if (rd == best_d[j]) {
+                                        ++nbest[j];
+                                    }
                                 }
                             }
                         }
-                    }
-            }
-#pragma unroll
-            for (int j = 0; j < kWinQ; ++j) {
-                if (!has[j]) continue;
-                const int64_t tq = tq0 + (int64_t)j * nthr;
-                double pred = nan, prob = nan, err = nan;
-                if (ok[j]) {
-                    // 'best' also needs a single nearest element; otherwise the training index decides
-                    if (pa.kind == SD_ANALOG_BEST && nbest[j] != 1) unique[j] = false;
-                    if (!unique[j]) {
-                        f1_walk_query(0, pa, n, T, c, tq, q[j], xs, xi, Xc + c * T, yc + c * T, sd, si, nthr);
-                        continue;
-                    }
-                    const bool any_masked = nexc[j] != k;
-                    const double kk = (double)k;
-                    const double m1 = s1[j] / kk;
-                    if (pa.kind == SD_ANALOG_BEST) pred = best_a[j];                                        // gard.py:311
-                    else if (pa.kind == SD_ANALOG_WEIGHT) pred = any_masked ? nan : awsum[j] / wsum[j];     // gard.py:319-327
-                    else pred = any_masked ? nan : a0[j] + m1;                                              // gard.py:329-333
-                    if (pa.has_thresh) {
-                        pred = nan_to_num(pred);       // gard.py:341
-                        prob = (double)nexc[j] / kk;    // gard.py:343
-                    } else {
-                        prob = 1.0;  // gard.py:346
-                    }
-                    if (!any_masked) {
-                        const double var = s2[j] / kk - m1 * m1;  // sums are shifted by the first analog: no cancellation
-                        err = sqrt(var > 0.0 ? var : 0.0);        // ddof = 0 (gard.py:342,345)
-                    }
                 }
-                pa.out[(tq * 3 + 0) * pa.ld_out + c] = pred;
-                pa.out[(tq * 3 + 1) * pa.ld_out + c] = prob;
-                pa.out[(tq * 3 + 2) * pa.ld_out + c] = err;
+#pragma unroll
+                for (int j = 0; j < kWinQ; ++j) {
+                    if (!mine[j]) continue;
+                    const int64_t tq = tq0 + (int64_t)j * nthr;
+                    double pred = nan, prob = nan, err = nan;
+                    if (ok[j]) {
+                        // 'best' also needs a single nearest element; otherwise the training index decides
+                        if (pa.kind == SD_ANALOG_BEST && nbest[j] != 1) unique[j] = false;
+                        if (!unique[j]) {
+                            f1_walk_query(0, pa, n, T, c, tq, q[j], xg, xi, Xc + c * T, yc + c * T, sd, si, nthr);
+                            continue;
+                        }
+                        const bool any_masked = nexc[j] != k;
+                        const double kk = (double)k;
+                        const double m1 = s1[j] / kk;
+                        if (pa.kind == SD_ANALOG_BEST) pred = best_a[j];                                      // gard.py:311
+                        else if (pa.kind == SD_ANALOG_WEIGHT) pred = any_masked ? nan : awsum[j] / wsum[j];   // gard.py:319-327
+                        else pred = any_masked ? nan : a0[j] + m1;                                            // gard.py:329-333
+                        if (pa.has_thresh) {
+                            pred = nan_to_num(pred);      // gard.py:341
+                            prob = (double)nexc[j] / kk;   // gard.py:343
+                        } else {
+                            prob = 1.0;  // gard.py:346
+                        }
+                        if (!any_masked) {
+                            const double var = s2[j] / kk - m1 * m1;  // sums are shifted by the first analog: no cancellation
+                            err = sqrt(var > 0.0 ? var : 0.0);        // ddof = 0 (gard.py:342,345)
+                        }
+                    }
+                    put_out(pa, tq, c, pred, prob, err);
+                }
             }
         }
     }
@@ -812,6 +863,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
     pa.ld_out = ld_out;
     pa.inds = inds;
     pa.dist = dist;
+    pa.oc_Tq = 0;
     sd_scratch status_p, sc_d, sc_i, status_pub;
     SD_HIP(status_p.alloc(ctx, sizeof(int32_t) * C));
     SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
@@ -826,13 +878,36 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
     const bool window = f1 && mode == 0 && kind != SD_ANALOG_SAMPLE && !inds && !dist && st->yx != nullptr &&
                         getenv("SD_ANALOG_WALK") == nullptr;
     if (window) {
-        const size_t lds = sizeof(double) * (T + 1);
+        // fewest value ranges such that xs and yx of a range (+ k entries of margin each side) fit the LDS
+        int npass = 1;
+        size_t lds = 0;
+        for (;; ++npass) {
+            const size_t cap = (size_t)((T + npass - 1) / npass) + 2 * (size_t)k + 1;
+            lds = sizeof(double) * (2 * cap + 1);
+            if (lds <= ctx->lds_max || npass >= 64) break;
+        }
+        SD_CHECK_ARG(lds <= ctx->lds_max, "sd_analog_predict: k=%d too large for the windowed path", k);
+        // queries and outputs go through cell-major copies: the column accesses of a cell would be 8-byte
+        // requests 8*ld bytes apart (one 64-byte sector each); the tiled transposes stream at HBM speed
+        sd_scratch qc, oc;
+        SD_HIP(qc.alloc(ctx, sizeof(double) * (size_t)Tq * C));
+        SD_HIP(oc.alloc(ctx, sizeof(double) * (size_t)Tq * 3 * C));
+        dim3 tgrid((unsigned)((C + 31) / 32), (unsigned)((Tq + 31) / 32));
+        SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, tgrid, dim3(256), 0, Xq, ld, Tq, 1, 0, C,
+                  qc.as<double>(), status_p.as<int32_t>(), 0);
+        PredictArgs pw = pa;
+        pw.out = oc.as<double>();
+        pw.oc_Tq = Tq;
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_window_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SD_LAUNCH(ctx, "analog_f1_window_kernel", analog_f1_window_kernel, dim3(nb), dim3(nthr), lds, Xq, ld, Tq, T, C,
-                  (const double*)st->xs, (const int32_t*)st->xi, (const double*)st->yx, (const double*)st->X,
-                  (const double*)st->y, (const int32_t*)st->status, status_p.as<int32_t>(), sc_d.as<double>(),
-                  sc_i.as<int32_t>(), pa);
+        SD_LAUNCH(ctx, "analog_f1_window_kernel", analog_f1_window_kernel, dim3(nb), dim3(nthr), lds, (const double*)qc.p,
+                  Tq, Tq, T, C, npass, (const double*)st->xs, (const int32_t*)st->xi, (const double*)st->yx,
+                  (const double*)st->X, (const double*)st->y, (const int32_t*)st->status, status_p.as<int32_t>(),
+                  sc_d.as<double>(), sc_i.as<int32_t>(), pw);
+        SD_LAUNCH(ctx, "analog_untranspose_kernel", analog_untranspose_kernel,
+                  dim3((unsigned)((C + 31) / 32), (unsigned)((Tq + 31) / 32), 3), dim3(256), 0, (const double*)oc.p, Tq, C, out,
+                  ld_out);
+        SD_HIP(hipStreamSynchronize(ctx->stream));  // qc / oc go back to the block cache at scope exit
     } else if (f1) {
         const size_t lds = sizeof(double) * T;
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_predict_kernel),
