@@ -562,8 +562,8 @@ constexpr int kWinBatch = 8;  // analog values read together per query
 // entries of margin on either side) sit in LDS: the window search and the k analog values of a query are LDS
 // reads, HBM/L2 only see the query and the three outputs.  A query belongs to the range that holds its value;
 // its k nearest neighbours are at most k positions away from there.
-__global__ void __launch_bounds__(1024) analog_f1_window_kernel(const double* __restrict__ Xq, int64_t ld, int64_t Tq,
-                                                                int64_t T, int64_t C, int npass,
+__global__ void __launch_bounds__(1024) analog_f1_window_kernel(int mode, const double* __restrict__ Xq, int64_t ld,
+                                                                int64_t Tq, int64_t T, int64_t C, int npass,
                                                                 const double* __restrict__ xs_all,
                                                                 const int32_t* __restrict__ xi_all,
                                                                 const double* __restrict__ yx_all,
@@ -644,8 +644,10 @@ __global__ void __launch_bounds__(1024) analog_f1_window_kernel(const double* __
                     }
                 }
                 bool unique[kWinQ];
-                double a0[kWinQ], s1[kWinQ], s2[kWinQ], wsum[kWinQ], awsum[kWinQ], best_d[kWinQ], best_a[kWinQ];
-                int nexc[kWinQ], nbest[kWinQ];
+                // sums over the window, shifted by its first element (x0, a0) so that no cancellation occurs;
+                // PureAnalog: s1 = sum(a), s2 = sum(a^2), weights; AnalogRegression: wsum/awsum/sxx hold sum(x), sum(x*a), sum(x^2)
+                double x0[kWinQ], a0[kWinQ], s1[kWinQ], s2[kWinQ], wsum[kWinQ], awsum[kWinQ], sxx[kWinQ];
+                int nexc[kWinQ];
 #pragma unroll
                 for (int j = 0; j < kWinQ; ++j) {
                     const int L = lo[j];
@@ -656,11 +658,12 @@ __global__ void __launch_bounds__(1024) analog_f1_window_kernel(const double* __
                     const bool sep_l = L == 0 ? g0 == 0 : sq_dist(q[j], xs[L - 1]) > worst;
                     const bool sep_r = L + k == nl ? g1 == n : sq_dist(q[j], xs[L + k]) > worst;
                     unique[j] = sep_l && sep_r;
-                    s1[j] = s2[j] = wsum[j] = awsum[j] = 0.0;
-                    best_d[j] = dL;
-                    nexc[j] = nbest[j] = 0;
-                    a0[j] = best_a[j] = yl[L];
+                    s1[j] = s2[j] = wsum[j] = awsum[j] = sxx[j] = 0.0;
+                    nexc[j] = 0;
+                    x0[j] = xs[L];
+                    a0[j] = yl[L];
                 }
+                const bool need_x = mode == 1 || pa.kind == SD_ANALOG_WEIGHT;
                 for (int i0 = 0; i0 < k; i0 += kWinBatch) {
 #pragma unroll
                     for (int j = 0; j < kWinQ; ++j)
@@ -673,19 +676,23 @@ __global__ void __launch_bounds__(1024) analog_f1_window_kernel(const double* __
                                 s1[j] += e;
                                 s2[j] += e * e;
                                 nexc[j] += (!pa.has_thresh || ai > pa.thresh) ? 1 : 0;  // gard.py:307
-                                if (pa.kind != SD_ANALOG_MEAN) {
-                                    const double rd = sq_dist(q[j], xs[lo[j] + i]);
-                                    if (pa.kind == SD_ANALOG_WEIGHT) {
-                                        const double d = sqrt(rd);
-                                        const double w = 1.0 / (d == 0.0 ? 1e-20 : d);  // gard.py:322-323
-                                        wsum[j] += w;
-                                        awsum[j] += ai * w;
-                                    } else if (rd < best_d[j] || i == 0) {
-                                        best_d[j] = rd;
-                                        best_a[j] = ai;
-                                        nbest[j] = 1;
-                                    } else if (rd == best_d[j]) {
-                                        ++nbest[j];
+                                if (need_x) {
+                                    const double xv = xs[lo[j] + i];
+                                    if (mode == 1) {
+                                        const double dx = xv - x0[j];
+                                        wsum[j] += dx;
+                                        awsum[j] += dx * e;
+                                        sxx[j] += dx * dx;
+                                    } else {
+                                        // w = 1 / distance (gard.py:322-323); sqrt((q-x)^2) == |q-x| in IEEE arithmetic.
+                                        // Reciprocal by v_rcp_f64 + two Newton steps (< 1 ulp; the tolerance is 1e-6).
+                                        double d = __builtin_fabs(q[j] - xv);
+                                        d = d == 0.0 ? 1e-20 : d;
+                                        double r = __builtin_amdgcn_rcp(d);
+                                        r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+                                        r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+                                        wsum[j] += r;
+                                        awsum[j] += ai * r;
                                     }
                                 }
                             }
@@ -697,27 +704,60 @@ __global__ void __launch_bounds__(1024) analog_f1_window_kernel(const double* __
                     const int64_t tq = tq0 + (int64_t)j * nthr;
                     double pred = nan, prob = nan, err = nan;
                     if (ok[j]) {
-                        // 'best' also needs a single nearest element; otherwise the training index decides
-                        if (pa.kind == SD_ANALOG_BEST && nbest[j] != 1) unique[j] = false;
+                        const int L = lo[j];
+                        double best_a = a0[j];
+                        if (mode == 0 && pa.kind == SD_ANALOG_BEST && unique[j]) {
+                            // nearest element = one of the two around the insertion point of q inside the window;
+                            // equal distances or equal values there leave the choice to the training index -> walk
+                            int m = 0;  // first window entry with x >= q
+                            for (int len = k; len > 0;) {
+                                const int half = len >> 1;
+                                if (xs[L + m + half] < q[j]) { m += half + 1; len -= half + 1; } else len = half;
+                            }
+                            const double dl = m > 0 ? sq_dist(q[j], xs[L + m - 1]) : inf;
+                            const double dr = m < k ? sq_dist(q[j], xs[L + m]) : inf;
+                            if (dl == dr) unique[j] = false;
+                            const int b = dl < dr ? m - 1 : m;
+                            if (dl < dr ? (b > 0 && xs[L + b - 1] == xs[L + b]) : (b + 1 < k && xs[L + b + 1] == xs[L + b]))
+                                unique[j] = false;
+                            best_a = yl[L + (b < k ? b : k - 1)];
+                        }
                         if (!unique[j]) {
-                            f1_walk_query(0, pa, n, T, c, tq, q[j], xg, xi, Xc + c * T, yc + c * T, sd, si, nthr);
+                            f1_walk_query(mode, pa, n, T, c, tq, q[j], xg, xi, Xc + c * T, yc + c * T, sd, si, nthr);
                             continue;
                         }
                         const bool any_masked = nexc[j] != k;
                         const double kk = (double)k;
                         const double m1 = s1[j] / kk;
-                        if (pa.kind == SD_ANALOG_BEST) pred = best_a[j];                                      // gard.py:311
-                        else if (pa.kind == SD_ANALOG_WEIGHT) pred = any_masked ? nan : awsum[j] / wsum[j];   // gard.py:319-327
-                        else pred = any_masked ? nan : a0[j] + m1;                                            // gard.py:329-333
-                        if (pa.has_thresh) {
-                            pred = nan_to_num(pred);      // gard.py:341
-                            prob = (double)nexc[j] / kk;   // gard.py:343
+                        if (mode == 1) {
+                            // one-feature OLS on the k analogs (gard.py:194-224): centred sums, slope 0 when all x are equal
+                            const double mx = wsum[j] / kk;
+                            const double vxx = sxx[j] - kk * mx * mx, vxy = awsum[j] - kk * mx * m1;
+                            const double slope = vxx > 0.0 ? vxy / vxx : 0.0;
+                            const double xm = x0[j] + mx, ym = a0[j] + m1;
+                            const double icpt = ym - xm * slope;
+                            pred = icpt + q[j] * slope;
+                            double ss = 0.0;
+                            for (int i = 0; i < k; ++i) {
+                                const double r = yl[L + i] - (icpt + xs[L + i] * slope);
+                                ss += r * r;
+                            }
+                            prob = 1.0;
+                            err = sqrt(ss / kk);  // root_mean_squared_error (gard.py:218-219)
                         } else {
-                            prob = 1.0;  // gard.py:346
-                        }
-                        if (!any_masked) {
-                            const double var = s2[j] / kk - m1 * m1;  // sums are shifted by the first analog: no cancellation
-                            err = sqrt(var > 0.0 ? var : 0.0);        // ddof = 0 (gard.py:342,345)
+                            if (pa.kind == SD_ANALOG_BEST) pred = best_a;                                         // gard.py:311
+                            else if (pa.kind == SD_ANALOG_WEIGHT) pred = any_masked ? nan : awsum[j] / wsum[j];   // gard.py:319-327
+                            else pred = any_masked ? nan : a0[j] + m1;                                            // gard.py:329-333
+                            if (pa.has_thresh) {
+                                pred = nan_to_num(pred);      // gard.py:341
+                                prob = (double)nexc[j] / kk;   // gard.py:343
+                            } else {
+                                prob = 1.0;  // gard.py:346
+                            }
+                            if (!any_masked) {
+                                const double var = s2[j] / kk - m1 * m1;
+                                err = sqrt(var > 0.0 ? var : 0.0);  // ddof = 0 (gard.py:342,345)
+                            }
                         }
                     }
                     put_out(pa, tq, c, pred, prob, err);
@@ -875,7 +915,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
     if ((int64_t)nb > ((C + 7) / 8) * 8) nb = (int)(((C + 7) / 8) * 8);
     SD_HIP(sc_d.alloc(ctx, sizeof(double) * (size_t)nb * k * nthr));
     SD_HIP(sc_i.alloc(ctx, sizeof(int32_t) * (size_t)nb * k * nthr));
-    const bool window = f1 && mode == 0 && kind != SD_ANALOG_SAMPLE && !inds && !dist && st->yx != nullptr &&
+    const bool window = f1 && (mode == 1 || kind != SD_ANALOG_SAMPLE) && !inds && !dist && st->yx != nullptr &&
                         getenv("SD_ANALOG_WALK") == nullptr;
     if (window) {
         // fewest value ranges such that xs and yx of a range (+ k entries of margin each side) fit the LDS
@@ -900,8 +940,8 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
         pw.oc_Tq = Tq;
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_window_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SD_LAUNCH(ctx, "analog_f1_window_kernel", analog_f1_window_kernel, dim3(nb), dim3(nthr), lds, (const double*)qc.p,
-                  Tq, Tq, T, C, npass, (const double*)st->xs, (const int32_t*)st->xi, (const double*)st->yx,
+        SD_LAUNCH(ctx, "analog_f1_window_kernel", analog_f1_window_kernel, dim3(nb), dim3(nthr), lds, mode,
+                  (const double*)qc.p, Tq, Tq, T, C, npass, (const double*)st->xs, (const int32_t*)st->xi, (const double*)st->yx,
                   (const double*)st->X, (const double*)st->y, (const int32_t*)st->status, status_p.as<int32_t>(),
                   sc_d.as<double>(), sc_i.as<int32_t>(), pw);
         SD_LAUNCH(ctx, "analog_untranspose_kernel", analog_untranspose_kernel,
