@@ -75,6 +75,34 @@ def test_vs_oracle_edge_sizes_and_ties(ctx, F, T, Tq, C, k):
     assert_close(out, exp, what="ties weight")
 
 
+@pytest.mark.parametrize("data", ["continuous", "zero_inflated", "quantized"])
+def test_window_path_full_length_series(ctx, data):
+    """F=1 without neighbour outputs takes the windowed kernel: T=14600 needs two LDS value ranges; zero-inflated
+    and quantized predictors put exact ties on window boundaries and range pivots (those queries fall back to the
+    (rdist, index)-ordered walk).  Every kind, with and without a threshold, and AnalogRegression vs the oracle."""
+    rng = np.random.default_rng(5)
+    T, Tq, C, k = 14600, 1500, 3, 30
+    if data == "continuous":
+        X, Xq = rng.standard_normal((T, 1, C)), 1.3 * rng.standard_normal((Tq, 1, C))
+    elif data == "zero_inflated":
+        X = rng.gamma(0.7, 4.0, (T, 1, C)) * (rng.random((T, 1, C)) > 0.55)
+        Xq = rng.gamma(0.7, 4.0, (Tq, 1, C)) * (rng.random((Tq, 1, C)) > 0.55)
+    else:
+        X, Xq = np.round(rng.standard_normal((T, 1, C)), 1), np.round(rng.standard_normal((Tq, 1, C)), 1)
+    y = 0.5 * X[:, 0, :] + rng.standard_normal((T, C))
+    st = ctx.analog_fit(X, y)
+    for kind in ("best_analog", "weight_analogs", "mean_analogs"):
+        for thresh in (None, 0.1):
+            kk = 1 if kind == "best_analog" else k  # gard.py:291-296: best_analog queries a single neighbour
+            out, status = ctx.analog_predict(st, Xq, kk, KINDS[kind], thresh)
+            exp = ao.pointwise_analog(X, y, Xq, kk, KINDS[kind], thresh)
+            assert (status == 0).all()
+            assert_close(out, exp, what=f"window {data} {kind} thresh={thresh}")
+    out, _ = ctx.analogreg_predict(st, Xq, k)
+    exp = ao.pointwise_analog(X, y, Xq[:250], k, ao.KIND_MEAN, regression=True)  # (the oracle solves one lstsq per query)
+    assert_close(out[:250], exp, what=f"window {data} regression")
+
+
 def test_masked_cells_and_nan_query(ctx):
     g = load("g5_analog_F1")
     X, y, Xq = analog_inputs(g)
