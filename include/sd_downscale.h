@@ -78,7 +78,7 @@ int sd_device_count(int* count);
 int sd_ctx_create(int device, sd_ctx** out);
 int sd_ctx_destroy(sd_ctx* ctx);
 int sd_ctx_synchronize(sd_ctx* ctx);
-/* States and per-call scratch recycle device blocks through a per-context cache (at most 1/4 of the HBM);
+/* States and per-call scratch recycle device blocks through a per-context cache (at most 1/2 of the HBM, given back when an allocation fails);
  * this returns the cached blocks and the rank workspace to the driver. */
 int sd_ctx_release_cached(sd_ctx* ctx);
 int sd_ctx_device_info(sd_ctx* ctx, char* name, size_t name_len, int* compute_units, int64_t* hbm_bytes);

@@ -928,25 +928,33 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
         }
         SD_CHECK_ARG(lds <= ctx->lds_max, "sd_analog_predict: k=%d too large for the windowed path", k);
         // queries and outputs go through cell-major copies: the column accesses of a cell would be 8-byte
-        // requests 8*ld bytes apart (one 64-byte sector each); the tiled transposes stream at HBM speed
+        // requests 8*ld bytes apart (one 64-byte sector each); the tiled transposes stream at HBM speed.
+        // Cells are processed in chunks so that the staging buffers stay small (and cache-resident).
+        const int64_t chunk = 16384;
+        const int64_t cc_max = C < chunk ? C : chunk;
         sd_scratch qc, oc;
-        SD_HIP(qc.alloc(ctx, sizeof(double) * (size_t)Tq * C));
-        SD_HIP(oc.alloc(ctx, sizeof(double) * (size_t)Tq * 3 * C));
-        dim3 tgrid((unsigned)((C + 31) / 32), (unsigned)((Tq + 31) / 32));
-        SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, tgrid, dim3(256), 0, Xq, ld, Tq, 1, 0, C,
-                  qc.as<double>(), status_p.as<int32_t>(), 0);
-        PredictArgs pw = pa;
-        pw.out = oc.as<double>();
-        pw.oc_Tq = Tq;
+        SD_HIP(qc.alloc(ctx, sizeof(double) * (size_t)Tq * cc_max));
+        SD_HIP(oc.alloc(ctx, sizeof(double) * (size_t)Tq * 3 * cc_max));
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_window_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SD_LAUNCH(ctx, "analog_f1_window_kernel", analog_f1_window_kernel, dim3(nb), dim3(nthr), lds, mode,
-                  (const double*)qc.p, Tq, Tq, T, C, npass, (const double*)st->xs, (const int32_t*)st->xi, (const double*)st->yx,
-                  (const double*)st->X, (const double*)st->y, (const int32_t*)st->status, status_p.as<int32_t>(),
-                  sc_d.as<double>(), sc_i.as<int32_t>(), pw);
-        SD_LAUNCH(ctx, "analog_untranspose_kernel", analog_untranspose_kernel,
-                  dim3((unsigned)((C + 31) / 32), (unsigned)((Tq + 31) / 32), 3), dim3(256), 0, (const double*)oc.p, Tq, C, out,
-                  ld_out);
+        for (int64_t cb = 0; cb < C; cb += chunk) {
+            const int64_t cc = C - cb < chunk ? C - cb : chunk;
+            dim3 tgrid((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32));
+            SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, tgrid, dim3(256), 0, Xq + cb, ld, Tq, 1, 0, cc,
+                      qc.as<double>(), status_p.as<int32_t>() + cb, 0);
+            PredictArgs pw = pa;
+            pw.out = oc.as<double>();
+            pw.oc_Tq = Tq;
+            int nbc = nb;
+            if ((int64_t)nbc > ((cc + 7) / 8) * 8) nbc = (int)(((cc + 7) / 8) * 8);
+            SD_LAUNCH(ctx, "analog_f1_window_kernel", analog_f1_window_kernel, dim3(nbc), dim3(nthr), lds, mode,
+                      (const double*)qc.p, Tq, Tq, T, cc, npass, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
+                      (const double*)st->yx + cb * T, (const double*)st->X + cb * T, (const double*)st->y + cb * T,
+                      (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb, sc_d.as<double>(), sc_i.as<int32_t>(), pw);
+            SD_LAUNCH(ctx, "analog_untranspose_kernel", analog_untranspose_kernel,
+                      dim3((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32), 3), dim3(256), 0, (const double*)oc.p, Tq, cc,
+                      out + cb, ld_out);
+        }
         SD_HIP(hipStreamSynchronize(ctx->stream));  // qc / oc go back to the block cache at scope exit
     } else if (f1) {
         const size_t lds = sizeof(double) * T;

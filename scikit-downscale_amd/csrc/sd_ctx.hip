@@ -47,7 +47,7 @@ int sd_ctx_create(int device, sd_ctx** out) {
     ctx->cu_count = prop.multiProcessorCount;
     ctx->lds_max = prop.sharedMemPerBlock;
     if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) ctx->lds_max = 160 * 1024;  // CDNA4: 160 KiB LDS per CU
-    ctx->pool_cap = (size_t)prop.totalGlobalMem / 4;
+    ctx->pool_cap = (size_t)prop.totalGlobalMem / 2;  // released on demand: sd_pool_malloc trims the cache when hipMalloc fails
     SD_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     SD_HIP(hipEventCreate(&ctx->t0));
     SD_HIP(hipEventCreate(&ctx->t1));

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--k", type=int, default=30)
     ap.add_argument("--kind", default="mean_analogs")
+    ap.add_argument("--out", default=None, help="append the JSON line to this file")
     args = ap.parse_args()
     ctx = Context(0)
     T, C = args.times, args.cells
@@ -78,9 +79,13 @@ def main():
     prof = {k: v["ms"] / args.steps for k, v in ctx.prof().items()}
     kms = sum(prof.values())
     achieved = C * bytes_per_cell / (kms * 1e-3) / 1e9
-    print(json.dumps({"workload": name, "cells_per_s": C / dt, "ms_per_step": dt * 1e3, "kernel_ms_per_step": prof,
+    line = json.dumps({"workload": name, "cells_per_s": C / dt, "ms_per_step": dt * 1e3, "kernel_ms_per_step": prof,
                       "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                                   "algorithmic_bytes_per_cell": bytes_per_cell}}))
+                                   "algorithmic_bytes_per_cell": bytes_per_cell}})
+    print(line)
+    if args.out:
+        with open(args.out, "a") as f:
+            f.write(line + "\n")
 
 
 if __name__ == "__main__":
