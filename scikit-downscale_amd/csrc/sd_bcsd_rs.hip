@@ -736,6 +736,10 @@ int launch_ko(sd_ctx* ctx, const Params& p, const char* name) {
 
 template <int K, int MODE>
 int launch_k(sd_ctx* ctx, const Params& p, const char* name) {
+    if constexpr (K == 13) {  // development: 80-VGPR build (6 waves/SIMD, three workgroups per CU when the rows fit)
+        if (const char* e = getenv("SD_RS_OCC"))
+            if (atoi(e) == 6) return launch_ko<K, MODE, 6>(ctx, p, name);
+    }
     return launch_ko<K, MODE, (K > 21 ? 2 : 4)>(ctx, p, name);
 }
 
