@@ -95,8 +95,19 @@ struct MergeNet {
 // ---- workgroup-level merge sort: runs of K per thread -> buf[0..np) fully sorted ---------------------
 // Same scheme as the wave-level sort of sd_bcsd_rs.hip (co-rank by binary search, windows merged in registers
 // by the pruned bitonic merger), but the merge groups grow past one wave, so rounds are separated by
-// workgroup barriers and a thread learns its neighbour's co-rank through `xch` (LDS, nthr + 1 ints).
+// workgroup barriers and a thread learns its neighbour's co-rank through `xch` (LDS, nthr + 1 ints).  While a merge
+// group still fits one wave (rounds 0..5) the hardware's in-order LDS service per wave makes a wavefront-scope
+// fence sufficient.
 // np = slots being sorted, a multiple of K (pads = +inf are ordinary elements); v[] = the thread's run.
+__device__ __forceinline__ void group_sync(bool within_wave) {
+    if (within_wave) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
 template <int K>
 __device__ __forceinline__ void block_merge_sort(double (&v)[K], double* buf, int np, int* xch, int tid, int nthr) {
     constexpr MergeNet<K> net{};
@@ -106,10 +117,12 @@ __device__ __forceinline__ void block_merge_sort(double (&v)[K], double* buf, in
 #pragma unroll
         for (int i = 0; i < K; ++i) dst[i] = v[i];
     }
-    __syncthreads();
+    group_sync(true);  // round 0 reads only the two runs of a lane pair
 #pragma unroll 1
     for (int r = 0; (K << r) < np; ++r) {
         const int L = K << r;
+        const bool in_wave = (2 << r) <= 64;      // this round's merge groups do not cross a wave
+        const bool next_in_wave = (4 << r) <= 64;  // ... nor do the next round's
         const int gl = tid & ((2 << r) - 1);  // thread within its merge group
         const int base = (tid - gl) * K;
         const int a0 = base < np ? base : np;
@@ -132,7 +145,7 @@ __device__ __forceinline__ void block_merge_sort(double (&v)[K], double* buf, in
             hi = le ? hi : mid;
         }
         xch[tid] = lo;
-        __syncthreads();
+        group_sync(in_wave);
         const int inext = xch[tid + 1 < nthr ? tid + 1 : tid];
         const int ihi = (d + K >= LA + LB) ? LA : inext;  // co-rank of the end of this thread's window
         const int acnt = ihi - lo;                         // elements taken from A; K - acnt from B
@@ -153,14 +166,15 @@ __device__ __forceinline__ void block_merge_sort(double (&v)[K], double* buf, in
                 w[net.b[c]] = mx;
             }
         }
-        __syncthreads();
+        group_sync(in_wave);
         if (busy) {
             double* dst = buf + a0 + d;
 #pragma unroll
             for (int s = 0; s < K; ++s) dst[s] = w[net.out[s]];
         }
-        __syncthreads();
+        group_sync(next_in_wave);
     }
+    __syncthreads();
 }
 
 }  // namespace sdsort
