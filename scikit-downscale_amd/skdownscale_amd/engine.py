@@ -14,11 +14,13 @@ from ._lib import check, ptr
 class DeviceArray:
     """A float64/int field resident in HBM (owned by the library's allocator, not torch)."""
 
-    def __init__(self, ctx, shape, dtype=np.float64, dptr=None, owner=True):
+    def __init__(self, ctx, shape, dtype=np.float64, dptr=None, owner=True, ld=None, base=None):
         self.ctx = ctx
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.ld = self.shape[-1] if ld is None else int(ld)  # elements between consecutive rows (>= cells)
+        self._base = base  # keeps the parent of a view alive
         self._owner = owner
         if dptr is None:
             p = C.c_void_p()
@@ -41,7 +43,22 @@ class DeviceArray:
     def vptr(self):
         return C.c_void_p(self.ptr)
 
+    def cells(self, c0, c1):
+        """View of the cell range [c0, c1) of a [..., C] field: same rows, leading dimension of the parent
+        (how a cell shard of a resident grid is handed to the engine without a copy)."""
+        assert 0 <= c0 < c1 <= self.shape[-1]
+        return DeviceArray(self.ctx, self.shape[:-1] + (c1 - c0,), self.dtype, dptr=self.ptr + c0 * self.dtype.itemsize,
+                           owner=False, ld=self.ld, base=self)
+
     def to_host(self):
+        if self.ld != self.shape[-1]:  # strided view: copy the parent's rows and slice on the host
+            rows = int(np.prod(self.shape[:-1], dtype=np.int64))
+            nbytes = ((rows - 1) * self.ld + self.shape[-1]) * self.dtype.itemsize
+            flat = np.empty(nbytes // self.dtype.itemsize, dtype=self.dtype)
+            check(self.ctx.lib.sd_memcpy_d2h(self.ctx.handle, ptr(flat), self.vptr, nbytes))
+            full = np.zeros(rows * self.ld, dtype=self.dtype)
+            full[:flat.size] = flat
+            return full.reshape(rows, self.ld)[:, :self.shape[-1]].reshape(self.shape).copy()
         out = np.empty(self.shape, dtype=self.dtype)
         check(self.ctx.lib.sd_memcpy_d2h(self.ctx.handle, ptr(out), self.vptr, self.nbytes))
         return out
@@ -193,7 +210,8 @@ class Context:
         h = C.c_void_p()
         if isinstance(y, DeviceArray):
             T, Cc = y.shape
-            check(self.lib.sd_bcsd_fit_dev(self.handle, kind, None if X is None else X.vptr, y.vptr, Cc, ptr(gid), G, T, Cc,
+            assert X is None or X.ld == y.ld
+            check(self.lib.sd_bcsd_fit_dev(self.handle, kind, None if X is None else X.vptr, y.vptr, y.ld, ptr(gid), G, T, Cc,
                                            int(return_anoms), C.byref(h)))
         else:
             y = _lib.as_f64(y)
@@ -209,7 +227,7 @@ class Context:
         if isinstance(Xp, DeviceArray):
             Tp = Xp.shape[0]
             out = self.empty((Tp, Cc)) if out is None else out
-            check(self.lib.sd_bcsd_predict_dev(self.handle, state.vptr, Xp.vptr, Cc, ptr(gid_p), Tp, out.vptr, Cc, ptr(status)))
+            check(self.lib.sd_bcsd_predict_dev(self.handle, state.vptr, Xp.vptr, Xp.ld, ptr(gid_p), Tp, out.vptr, out.ld, ptr(status)))
         else:
             Xp = _lib.as_f64(Xp)
             Tp = Xp.shape[0]
@@ -224,8 +242,10 @@ class Context:
         Tp = Xp.shape[0]
         out = self.empty((Tp, Cc)) if out is None else out
         status = np.empty(Cc, dtype=np.int32)
-        check(self.lib.sd_bcsd_fit_predict_dev(self.handle, kind, None if X is None else X.vptr, y.vptr, Cc, ptr(gid), G, T,
-                                               Cc, int(return_anoms), Xp.vptr, Cc, ptr(gid_p), Tp, out.vptr, Cc, ptr(status)))
+        assert X is None or X.ld == y.ld
+        check(self.lib.sd_bcsd_fit_predict_dev(self.handle, kind, None if X is None else X.vptr, y.vptr, y.ld, ptr(gid), G, T,
+                                               Cc, int(return_anoms), Xp.vptr, Xp.ld, ptr(gid_p), Tp, out.vptr, out.ld,
+                                               ptr(status)))
         return out, status
 
     def bcsd_import(self, exported):
@@ -243,7 +263,8 @@ class Context:
         h = C.c_void_p()
         if isinstance(X, DeviceArray):
             T, F, Cc = X.shape
-            check(self.lib.sd_analog_fit_dev(self.handle, X.vptr, y.vptr, Cc, T, F, Cc, C.byref(h)))
+            assert X.ld == y.ld
+            check(self.lib.sd_analog_fit_dev(self.handle, X.vptr, y.vptr, y.ld, T, F, Cc, C.byref(h)))
         else:
             X, y = _lib.as_f64(X), _lib.as_f64(y)
             T, F, Cc = X.shape
@@ -261,8 +282,9 @@ class Context:
             samp = None if sample_inds is None else (sample_inds if isinstance(sample_inds, DeviceArray) else self.to_device(sample_inds, np.int32))
             inds = self.empty((Tq, k, Cc), np.int64) if want_neighbors else None
             dist = self.empty((Tq, k, Cc)) if want_neighbors else None
-            check(self.lib.sd_analog_predict_dev(self.handle, state.vptr, Xq.vptr, Cc, Tq, k, kind, has_t, tv,
-                                                 None if samp is None else samp.vptr, out.vptr, Cc,
+            assert not want_neighbors or out.ld == Cc
+            check(self.lib.sd_analog_predict_dev(self.handle, state.vptr, Xq.vptr, Xq.ld, Tq, k, kind, has_t, tv,
+                                                 None if samp is None else samp.vptr, out.vptr, out.ld,
                                                  None if inds is None else inds.vptr, None if dist is None else dist.vptr, ptr(status)))
         else:
             Xq = _lib.as_f64(Xq)
@@ -281,7 +303,7 @@ class Context:
         if isinstance(Xq, DeviceArray):
             Tq = Xq.shape[0]
             out = self.empty((Tq, 3, Cc)) if out is None else out
-            check(self.lib.sd_analogreg_predict_dev(self.handle, state.vptr, Xq.vptr, Cc, Tq, k, out.vptr, Cc, ptr(status)))
+            check(self.lib.sd_analogreg_predict_dev(self.handle, state.vptr, Xq.vptr, Xq.ld, Tq, k, out.vptr, out.ld, ptr(status)))
         else:
             Xq = _lib.as_f64(Xq)
             Tq = Xq.shape[0]

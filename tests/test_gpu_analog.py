@@ -103,6 +103,27 @@ def test_window_path_full_length_series(ctx, data):
     assert_close(out[:250], exp, what=f"window {data} regression")
 
 
+def test_cell_shard_views(ctx):
+    """Cell ranges of resident fields by pointer + leading dimension (odd offset, odd leading dimension)."""
+    rng = np.random.default_rng(9)
+    T, Tq, Ct, c0, C, k = 900, 300, 21, 5, 11, 30
+    X, y, Xq = rng.standard_normal((T, 1, Ct)), rng.standard_normal((T, Ct)), rng.standard_normal((Tq, 1, Ct))
+    dX, dy, dXq = ctx.to_device(X), ctx.to_device(y), ctx.to_device(Xq)
+    st = ctx.analog_fit(dX.cells(c0, c0 + C), dy.cells(c0, c0 + C))
+    big = ctx.to_device(np.full((Tq, 3, Ct), -777.0))
+    for kind in (3, 2):
+        out, status = ctx.analog_predict(st, dXq.cells(c0, c0 + C), k, kind, out=big.cells(c0, c0 + C))
+        got = big.to_host()
+        exp = ao.pointwise_analog(X[:, :, c0:c0 + C], y[:, c0:c0 + C], Xq[:, :, c0:c0 + C], k, kind)
+        assert (status == 0).all()
+        assert_close(got[:, :, c0:c0 + C], exp, what=f"analog view kind {kind}")
+        assert (np.delete(got, np.s_[c0:c0 + C], axis=2) == -777.0).all()
+    _, _, inds, _ = ctx.analog_predict(st, dXq.cells(c0, c0 + C), k, 3, want_neighbors=True)
+    for c in range(C):
+        _, i = ao.knn(X[:, :, c0 + c], Xq[:, :, c0 + c], k)
+        assert np.array_equal(inds.to_host()[:, :, c], i)
+
+
 def test_masked_cells_and_nan_query(ctx):
     g = load("g5_analog_F1")
     X, y, Xq = analog_inputs(g)

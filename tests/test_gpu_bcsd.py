@@ -154,6 +154,38 @@ def test_shift_slab_handoff_is_bit_identical(ctx, monkeypatch):
     monkeypatch.delenv("SD_RS_SHIFT", raising=False)
 
 
+@pytest.mark.parametrize("Ct,c0", [(37, 3), (40, 4), (40, 7)])
+def test_cell_shard_views_of_a_resident_grid(ctx, Ct, c0):
+    """A cell range of a resident [T, C_total] field is passed as pointer + leading dimension (no copy): odd
+    leading dimensions and odd cell offsets take the 8-byte load/store paths, even ones the 16-byte paths; the
+    output is written into a view of a larger field without touching its other cells."""
+    rng = np.random.default_rng(Ct + c0)
+    T, Tp, C = 1461, 1461, 19
+    index = pd.date_range("1990-01-01", periods=T, freq="D")
+    gid = month_gid(index)
+    full = {k: 15 + 8 * rng.standard_normal((T, Ct)) for k in ("X", "y", "Xp")}
+    dev = {k: ctx.to_device(v) for k, v in full.items()}
+    sl = slice(c0, c0 + C)
+    for kind in (0, 1):
+        host = {k: (np.abs(v[:, sl]) if kind else v[:, sl]).copy() for k, v in full.items()}
+        if kind:
+            dev = {k: ctx.to_device(np.abs(v)) for k, v in full.items()}
+        ref, st_ref = ctx.bcsd_fit_predict(kind, ctx.to_device(host["X"]), ctx.to_device(host["y"]), gid, 12,
+                                           ctx.to_device(host["Xp"]), gid)
+        big = ctx.to_device(np.full((Tp, Ct), -777.0))
+        out, st = ctx.bcsd_fit_predict(kind, dev["X"].cells(c0, c0 + C), dev["y"].cells(c0, c0 + C), gid, 12,
+                                       dev["Xp"].cells(c0, c0 + C), gid, out=big.cells(c0, c0 + C))
+        got = big.to_host()
+        assert np.array_equal(st, st_ref)
+        assert np.array_equal(got[:, sl], ref.to_host()), (kind, Ct, c0)
+        assert (np.delete(got, np.s_[c0:c0 + C], axis=1) == -777.0).all()  # neighbours of the shard untouched
+        state = ctx.bcsd_fit(kind, dev["X"].cells(c0, c0 + C), dev["y"].cells(c0, c0 + C), gid, 12, True)
+        out2, _ = ctx.bcsd_predict(state, dev["Xp"].cells(c0, c0 + C), gid)
+        exp, _ = bo.pointwise_fit_predict(kind, host["X"], host["y"], host["Xp"], gid, gid)
+        assert_close(out2.to_host(), exp, what=f"view split {kind}")
+        assert_close(got[:, sl], exp, what=f"view fused {kind}")
+
+
 def test_generic_lds_kernels_still_agree(ctx, monkeypatch):
     """SD_BCSD_PATH=v1 forces the generic LDS-bitonic kernels (fallback for segments > 2 112 samples)."""
     monkeypatch.setenv("SD_BCSD_PATH", "v1")
