@@ -390,9 +390,10 @@ __device__ void analog_regression(int k, int F, XV xv /* (i,f) */, YV yv /* (i) 
 }
 
 // mode 0 = PureAnalog, 1 = AnalogRegression.  Lists in scratch: sd[i*nthr + tid], si[...].
+template <typename IT>
 __device__ void finish_query(int mode, const PredictArgs& pa, int F, int64_t T, int64_t c, int64_t tq, const double* q,
                              const double* __restrict__ Xc_cell, const double* __restrict__ yc_cell,
-                             const double* sd, const int32_t* si, int nthr, bool cell_active) {
+                             const double* sd, const IT* si, int nthr, bool cell_active) {
     const int tid = threadIdx.x;
     const int k = pa.k;
     double pred, prob = 1.0, err;
@@ -872,6 +873,115 @@ __global__ void __launch_bounds__(kBfThreads) analog_bf_predict_kernel(int mode,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// general F predict, second form: one wave per (cell, 64 queries).  Every lane owns one query and keeps its
+// k best (rdist, index) pairs sorted in LDS ([k][64]: lane-contiguous, conflict-free).  The training set is
+// scanned in chunks of 64 points whose coordinates are wave-uniform (scalar loads, no LDS staging, no
+// barriers); a chunk first yields a 64-bit mask of points closer than the lane's current k-th distance,
+// then only the flagged points are inserted.  After the first few chunks the mask is almost always empty,
+// so the steady state is 3F+3 vector instructions per (query, training point).
+// ------------------------------------------------------------------------------------------------
+template <int F, typename IT>
+__global__ void __launch_bounds__(64) analog_bf2_predict_kernel(int mode, const double* __restrict__ Xq, int64_t ld,
+                                                                int64_t Tq, int64_t T, int64_t C, int nbatch,
+                                                                const double* __restrict__ Xc, const double* __restrict__ yc,
+                                                                const int32_t* __restrict__ fit_status, int32_t* status,
+                                                                PredictArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int k = pa.k, lane = threadIdx.x;
+    double* sd = reinterpret_cast<double*>(smem_raw);           // [k][64]
+    IT* si = reinterpret_cast<IT*>(sd + (size_t)k * 64);  // [k][64]; 16-bit indices when T <= 65535 (more waves per CU)
+    const int64_t c = blockIdx.x / nbatch;
+    const int64_t tq = (int64_t)(blockIdx.x % nbatch) * 64 + lane;
+    const bool active = fit_status[c] == 0, has_q = tq < Tq;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double q[F];
+    bool ok = active && has_q;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        q[f] = has_q ? Xq[(tq * F + f) * ld + c] : 0.0;
+        if (active && has_q && !sd_finite(q[f])) {
+            atomicOr(&status[c], SDI_NONFINITE);
+            ok = false;
+        }
+    }
+    for (int i = 0; i < k; ++i) {
+        sd[i * 64 + lane] = inf;
+        si[i * 64 + lane] = (IT)0;
+    }
+    const double* __restrict__ Xcell = Xc + c * F * T;  // [F][T]
+    double tau = ok ? inf : -1.0;  // k-th best distance so far; a lane without a query never flags a point
+    for (int64_t j0 = 0; j0 < T; j0 += 64) {
+        const int nj = (int)(T - j0 < 64 ? T - j0 : 64);
+        unsigned long long mask = 0ull;
+        if (nj == 64) {
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) {
+                double d = 0.0;
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const double df = q[f] - Xcell[(int64_t)f * T + j0 + j];  // wave-uniform address: scalar load
+                    d += df * df;
+                }
+                mask |= d < tau ? (1ull << j) : 0ull;
+            }
+        } else {
+            for (int j = 0; j < nj; ++j) {
+                double d = 0.0;
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const double df = q[f] - Xcell[(int64_t)f * T + j0 + j];
+                    d += df * df;
+                }
+                mask |= d < tau ? (1ull << j) : 0ull;
+            }
+        }
+        while (mask) {  // ascending index: an equal distance with a larger index never displaces
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            double d = 0.0;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const double df = q[f] - Xcell[(int64_t)f * T + j0 + j];
+                d += df * df;
+            }
+            if (d < tau) {  // tau may have tightened since the mask was built
+                int pos = k - 1;
+                while (pos > 0 && sd[(pos - 1) * 64 + lane] > d) {
+                    sd[pos * 64 + lane] = sd[(pos - 1) * 64 + lane];
+                    si[pos * 64 + lane] = si[(pos - 1) * 64 + lane];
+                    --pos;
+                }
+                sd[pos * 64 + lane] = d;
+                si[pos * 64 + lane] = (IT)(j0 + j);
+                tau = sd[(k - 1) * 64 + lane];
+            }
+        }
+    }
+    if (has_q) finish_query(mode, pa, F, T, c, tq, q, Xcell, yc + c * T, sd, si, 64, ok);
+}
+
+template <int F, typename IT>
+int launch_bf2i(sd_ctx* ctx, int mode, const sd_analog_state* st, const double* Xq, int64_t ld, int64_t Tq, int32_t* status_p,
+                const PredictArgs& pa) {
+    const size_t lds = (size_t)pa.k * 64 * (sizeof(double) + sizeof(IT));
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_bf2_predict_kernel<F, IT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t nbatch = (Tq + 63) / 64, nblocks = st->C * nbatch;
+    SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "sd_analog_predict: too many (cell, query batch) pairs for one launch");
+    SD_LAUNCH(ctx, "analog_bf2_predict_kernel", (analog_bf2_predict_kernel<F, IT>), dim3((unsigned)nblocks), dim3(64), lds, mode,
+              Xq, ld, Tq, st->T, st->C, (int)nbatch, (const double*)st->X, (const double*)st->y, (const int32_t*)st->status,
+              status_p, pa);
+    return SD_OK;
+}
+
+template <int F>
+int launch_bf2(sd_ctx* ctx, int mode, const sd_analog_state* st, const double* Xq, int64_t ld, int64_t Tq, int32_t* status_p,
+               const PredictArgs& pa) {
+    if (st->T <= 65535) return launch_bf2i<F, uint16_t>(ctx, mode, st, Xq, ld, Tq, status_p, pa);
+    return launch_bf2i<F, int32_t>(ctx, mode, st, Xq, ld, Tq, status_p, pa);
+}
+
 __global__ void __launch_bounds__(256) analog_status_public_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b,
                                                                    int64_t C, int32_t* __restrict__ outp) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -963,6 +1073,18 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
         SD_LAUNCH(ctx, "analog_f1_predict_kernel", analog_f1_predict_kernel, dim3(nb), dim3(nthr), lds, mode, Xq, ld, Tq,
                   T, C, (const double*)st->xs, (const int32_t*)st->xi, (const double*)st->X, (const double*)st->y,
                   (const int32_t*)st->status, status_p.as<int32_t>(), sc_d.as<double>(), sc_i.as<int32_t>(), pa);
+    } else if ((size_t)k * 64 * 12 <= ctx->lds_max && getenv("SD_ANALOG_BF1") == nullptr) {
+        int32_t* sp = status_p.as<int32_t>();
+        switch (F) {
+            case 1: SD_TRY(launch_bf2<1>(ctx, mode, st, Xq, ld, Tq, sp, pa)); break;
+            case 2: SD_TRY(launch_bf2<2>(ctx, mode, st, Xq, ld, Tq, sp, pa)); break;
+            case 3: SD_TRY(launch_bf2<3>(ctx, mode, st, Xq, ld, Tq, sp, pa)); break;
+            case 4: SD_TRY(launch_bf2<4>(ctx, mode, st, Xq, ld, Tq, sp, pa)); break;
+            case 5: SD_TRY(launch_bf2<5>(ctx, mode, st, Xq, ld, Tq, sp, pa)); break;
+            case 6: SD_TRY(launch_bf2<6>(ctx, mode, st, Xq, ld, Tq, sp, pa)); break;
+            case 7: SD_TRY(launch_bf2<7>(ctx, mode, st, Xq, ld, Tq, sp, pa)); break;
+            default: SD_TRY(launch_bf2<8>(ctx, mode, st, Xq, ld, Tq, sp, pa)); break;
+        }
     } else {
         const size_t lds = sizeof(double) * F * kBfChunk;
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_bf_predict_kernel),

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--k", type=int, default=30)
     ap.add_argument("--kind", default="mean_analogs")
+    ap.add_argument("--features", type=int, default=1)
     ap.add_argument("--out", default=None, help="append the JSON line to this file")
     args = ap.parse_args()
     ctx = Context(0)
@@ -48,11 +49,12 @@ def main():
         bytes_per_cell = 8 * (T + 2 * T)  # y_obs, X_fut, out (X_hist is only validated: + 8*T actually read)
         name = f"BcsdPrecipitation zero-inflated, {C} cells x {T} steps"
     else:
-        X = field(synth.GAUSS, 20)
+        F = args.features
         y = field(synth.GAUSS, 20, amp=2.0, stream2=21, amp2=1.0)
-        Xq = field(synth.GAUSS, 22)
-        X3 = ctx.wrap(X.ptr, (T, 1, C))
-        Xq3 = ctx.wrap(Xq.ptr, (T, 1, C))
+        X3, Xq3 = ctx.empty((T, F, C)), ctx.empty((T, F, C))
+        for name, arr, s0 in (("X", X3, 20), ("Xq", Xq3, 22)):  # [T, F, C]: feature f of time t is row t*F + f
+            rows = ctx.wrap(arr.ptr, (T * F, C))
+            ctx.synth_fill(rows, synth.GAUSS, 0, s0, c_full=C)
         out = ctx.empty((T, 3, C))
         kinds = {"best_analog": 0, "sample_analogs": 1, "weight_analogs": 2, "mean_analogs": 3}
 
@@ -64,8 +66,8 @@ def main():
                 r = ctx.analogreg_predict(st, Xq3, args.k, out=out)
             st.close()
             return r
-        bytes_per_cell = 8 * (T + T + T + 3 * T)
-        name = f"{'PureAnalog ' + args.kind if args.workload == 'analog' else 'AnalogRegression'} k={args.k} F=1, {C} cells x {T} steps"
+        bytes_per_cell = 8 * (F * T + T + F * T + 3 * T)
+        name = f"{'PureAnalog ' + args.kind if args.workload == 'analog' else 'AnalogRegression'} k={args.k} F={args.features}, {C} cells x {T} steps"
     step()
     ctx.synchronize()
     ctx.prof_reset()
