@@ -881,6 +881,39 @@ __global__ void __launch_bounds__(kBfThreads) analog_bf_predict_kernel(int mode,
 // then only the flagged points are inserted.  After the first few chunks the mask is almost always empty,
 // so the steady state is 3F+3 vector instructions per (query, training point).
 // ------------------------------------------------------------------------------------------------
+// (d, idx) pairs of one lane as a binary max-heap in LDS ([k][64]): the root is the worst of the k best.
+template <typename IT>
+__device__ __forceinline__ bool pair_gt(double da, IT ia, double db, IT ib) { return da > db || (da == db && ia > ib); }
+
+// place (d, idx) at the root and sift it down within the first `n` entries
+template <typename IT>
+__device__ __forceinline__ void heap_replace_root(double* sd, IT* si, int lane, int n, double d, IT idx) {
+    int pos = 0;
+    for (;;) {
+        const int l = 2 * pos + 1;
+        if (l >= n) break;
+        const int r = l + 1;
+        double dc = sd[l * 64 + lane];
+        IT ic = si[l * 64 + lane];
+        int ch = l;
+        if (r < n) {
+            const double dr = sd[r * 64 + lane];
+            const IT ir = si[r * 64 + lane];
+            if (pair_gt<IT>(dr, ir, dc, ic)) {
+                dc = dr;
+                ic = ir;
+                ch = r;
+            }
+        }
+        if (!pair_gt<IT>(dc, ic, d, idx)) break;
+        sd[pos * 64 + lane] = dc;
+        si[pos * 64 + lane] = ic;
+        pos = ch;
+    }
+    sd[pos * 64 + lane] = d;
+    si[pos * 64 + lane] = idx;
+}
+
 template <int F, typename IT>
 __global__ void __launch_bounds__(64) analog_bf2_predict_kernel(int mode, const double* __restrict__ Xq, int64_t ld,
                                                                 int64_t Tq, int64_t T, int64_t C, int nbatch,
@@ -889,7 +922,7 @@ __global__ void __launch_bounds__(64) analog_bf2_predict_kernel(int mode, const 
                                                                 PredictArgs pa) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int k = pa.k, lane = threadIdx.x;
-    double* sd = reinterpret_cast<double*>(smem_raw);           // [k][64]
+    double* sd = reinterpret_cast<double*>(smem_raw);  // [k][64]
     IT* si = reinterpret_cast<IT*>(sd + (size_t)k * 64);  // [k][64]; 16-bit indices when T <= 65535 (more waves per CU)
     const int64_t c = blockIdx.x / nbatch;
     const int64_t tq = (int64_t)(blockIdx.x % nbatch) * 64 + lane;
@@ -907,23 +940,43 @@ __global__ void __launch_bounds__(64) analog_bf2_predict_kernel(int mode, const 
     }
     for (int i = 0; i < k; ++i) {
         sd[i * 64 + lane] = inf;
-        si[i * 64 + lane] = (IT)0;
+        si[i * 64 + lane] = (IT)~(IT)0 >> 1;  // larger than any training index
     }
     const double* __restrict__ Xcell = Xc + c * F * T;  // [F][T]
     double tau = ok ? inf : -1.0;  // k-th best distance so far; a lane without a query never flags a point
+    constexpr int G = 8;           // training points per group: their coordinates are wave-uniform (scalar loads)
+    const int64_t Tfull = T / 64 * 64;
+    double cur[F][G], nxt[F][G];
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int g = 0; g < G; ++g) cur[f][g] = Tfull > 0 ? Xcell[(int64_t)f * T + g] : 0.0;
     for (int64_t j0 = 0; j0 < T; j0 += 64) {
         const int nj = (int)(T - j0 < 64 ? T - j0 : 64);
         unsigned long long mask = 0ull;
-        if (nj == 64) {
-#pragma unroll 8
-            for (int j = 0; j < 64; ++j) {
-                double d = 0.0;
+        if (j0 < Tfull) {
 #pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    const double df = q[f] - Xcell[(int64_t)f * T + j0 + j];  // wave-uniform address: scalar load
-                    d += df * df;
+            for (int jg = 0; jg < 64; jg += G) {
+                // the next group is requested before this one is used: its latency hides behind 8 x (3F+3) instructions
+                const int64_t jn = j0 + jg + 2 * G <= T ? j0 + jg + G : 0;  // one uniform clamp: contiguous scalar loads
+#pragma unroll
+                for (int f = 0; f < F; ++f)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) nxt[f][g] = Xcell[(int64_t)f * T + jn + g];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    double d = 0.0;
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        const double df = q[f] - cur[f][g];
+                        d += df * df;
+                    }
+                    mask |= d < tau ? (1ull << (jg + g)) : 0ull;
                 }
-                mask |= d < tau ? (1ull << j) : 0ull;
+#pragma unroll
+                for (int f = 0; f < F; ++f)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) cur[f][g] = nxt[f][g];
             }
         } else {
             for (int j = 0; j < nj; ++j) {
@@ -946,17 +999,18 @@ __global__ void __launch_bounds__(64) analog_bf2_predict_kernel(int mode, const 
                 d += df * df;
             }
             if (d < tau) {  // tau may have tightened since the mask was built
-                int pos = k - 1;
-                while (pos > 0 && sd[(pos - 1) * 64 + lane] > d) {
-                    sd[pos * 64 + lane] = sd[(pos - 1) * 64 + lane];
-                    si[pos * 64 + lane] = si[(pos - 1) * 64 + lane];
-                    --pos;
-                }
-                sd[pos * 64 + lane] = d;
-                si[pos * 64 + lane] = (IT)(j0 + j);
-                tau = sd[(k - 1) * 64 + lane];
+                heap_replace_root<IT>(sd, si, lane, k, d, (IT)(j0 + j));
+                tau = sd[lane];
             }
         }
+    }
+    // heap -> ascending (rdist, index): move the root behind the shrinking heap, k - 1 times
+    for (int n = k - 1; n > 0; --n) {
+        const double dl = sd[n * 64 + lane];
+        const IT il = si[n * 64 + lane];
+        sd[n * 64 + lane] = sd[lane];
+        si[n * 64 + lane] = si[lane];
+        heap_replace_root<IT>(sd, si, lane, n, dl, il);
     }
     if (has_q) finish_query(mode, pa, F, T, c, tq, q, Xcell, yc + c * T, sd, si, 64, ok);
 }
