@@ -145,8 +145,9 @@ __global__ void __launch_bounds__(1024) analog_sort_kernel(const double* __restr
 
 // F == 1, fast form of the same result: two workgroup-level merge sorts of plain float64 keys (sd_sortnet.h).
 //   1. sort x                       -> xs
-//   2. every training sample finds lb = first position of its value in xs (binary search); the keys
-//      lb * 65536 + index are distinct integers < 2^32 (exact in float64) whose order is exactly the
+//   2. every training sample finds lb = first position of its value in xs (binary search).  Without equal
+//      values in the cell lb is the sorted position: y and the index are scattered through LDS.  Otherwise the
+//      keys lb * 65536 + index are distinct integers < 2^32 (exact in float64) whose order is exactly the
 //      lexicographic (x, index) order; sorting them yields xi, and yx = y[xi].
 // One 1024-thread workgroup per cell, K consecutive samples per thread, T <= 1024 * K.
 template <int K>
@@ -174,9 +175,17 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
         __syncthreads();
         sdsort::block_merge_sort<K>(v, buf, np, xch, tid, nthr);
         for (int i = tid; i < n; i += nthr) xs[c * T + i] = buf[i];
+        // any two equal training values in this cell?  (then the order inside a tie run needs the second sort)
+        bool tie = false;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int j = K * tid + i;
+            tie |= j + 1 < n && buf[j] == buf[j + 1];
+        }
+        const bool ties = __syncthreads_or(tie) != 0;
         // lb = number of sorted values < x (branch-free binary search; strides that are multiples of 16
         // doubles are shortened by one: see the rank search in sd_bcsd_rs.hip)
-        double key2[K];
+        int lb[K];
         {
             int pos[K];
 #pragma unroll
@@ -190,15 +199,37 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
                 for (int i = 0; i < K; ++i) pos[i] += buf[pos[i] + half] < orig[i] ? half : 0;
             }
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const int j = K * tid + i;
-                const int lb = pos[i] + 1 + (buf[pos[i] + 1] < orig[i] ? 1 : 0);
-                key2[i] = j < n ? (double)lb * 65536.0 + (double)j : inf;
-            }
+            for (int i = 0; i < K; ++i) lb[i] = pos[i] + 1 + (buf[pos[i] + 1] < orig[i] ? 1 : 0);
         }
         __syncthreads();
-        sdsort::block_merge_sort<K>(key2, buf, np, xch, tid, nthr);
         const double* yy = yc + c * T;
+        if (!ties) {
+            // distinct values: lb is the sorted position itself -> scatter y and the index through LDS
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = K * tid + i;
+                if (j < n) buf[lb[i]] = yy[j];
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += nthr) yx[c * T + i] = buf[i];
+            __syncthreads();
+            int* ibuf = reinterpret_cast<int*>(buf);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = K * tid + i;
+                if (j < n) ibuf[lb[i]] = j;
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += nthr) xi[c * T + i] = ibuf[i];
+            continue;
+        }
+        double key2[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int j = K * tid + i;
+            key2[i] = j < n ? (double)lb[i] * 65536.0 + (double)j : inf;
+        }
+        sdsort::block_merge_sort<K>(key2, buf, np, xch, tid, nthr);
         for (int i = tid; i < n; i += nthr) {
             const unsigned kk = (unsigned)buf[i];
             const int idx = (int)(kk & 0xffffu);
