@@ -6,7 +6,9 @@ namespace sdrs {
 
 // MODE_RANK + MODE_APPLY = fit+predict (or predict from a state) as two kernels: RANK ranks every x_fut sample
 // within its shifted segment, APPLY sorts y_obs (or reads the fitted state), maps the ranks and restores the shift.
-enum { MODE_FIT = 0, MODE_RANK = 3, MODE_APPLY = 4 };
+// MODE_BOTH = RANK then APPLY of the same segment inside one workgroup: the ranks stay in registers and the second
+// read of the x_fut tile comes from L2 / Infinity Cache (the workgroup fetched it microseconds earlier).
+enum { MODE_FIT = 0, MODE_BOTH = 2, MODE_RANK = 3, MODE_APPLY = 4 };
 
 struct Params {
     int kind, G, return_anoms, RS;

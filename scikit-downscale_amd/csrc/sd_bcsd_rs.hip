@@ -36,6 +36,15 @@ constexpr int kW = 8;          // cells per workgroup
 constexpr int kThreads = 512;  // 8 waves
 constexpr int kRowsPerPass = kThreads / 4;  // 4 lanes (16 B each) cover the 8 cells of one row
 
+// The thread index behind an opaque barrier (see SD_DERIVE in segment_body).
+__device__ __forceinline__ int tid_now() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+// The kernel reads its Params straight from the kernarg segment (scalar loads on demand, re-loadable).
+typedef const Params __attribute__((address_space(4)))* ParamsPtr;
+
 __device__ __forceinline__ bool finite64(double v) {
     return (__double_as_longlong(v) & 0x7ff0000000000000ll) != 0x7ff0000000000000ll;
 }
@@ -146,7 +155,8 @@ struct TileRegs {
 template <int RPT>
 __device__ __forceinline__ void tile_issue(const double* __restrict__ src, int64_t ld, const int32_t* __restrict__ ord,
                                            int nrows, int64_t c0, int64_t C, bool vec_ok, TileRegs<RPT>& t, int rmask = -1) {
-    const int cp = threadIdx.x & 3, rr = threadIdx.x >> 2;
+    const int tid = tid_now();
+    const int cp = tid & 3, rr = tid >> 2;
     const int64_t c = c0 + 2 * cp;
     const bool full = vec_ok && c + 1 < C;
     int ti[RPT];
@@ -175,7 +185,8 @@ __device__ __forceinline__ void tile_issue(const double* __restrict__ src, int64
 template <int RPT>
 __device__ __forceinline__ void tile_commit(const TileRegs<RPT>& t, int nrows, int64_t c0, int64_t C, double* tile, int RS,
                                             int32_t* status) {
-    const int cp = threadIdx.x & 3, rr = threadIdx.x >> 2;
+    const int tid = tid_now();
+    const int cp = tid & 3, rr = tid >> 2;
     const int64_t c = c0 + 2 * cp;
     double* d0 = tile + (2 * cp) * RS;
     double* d1 = d0 + RS;
@@ -205,7 +216,8 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ src, int64_
 
 __device__ __forceinline__ void store_tile(double* __restrict__ dst, int64_t ld, const int32_t* __restrict__ ord,
                                            int nrows, int64_t c0, int64_t C, bool vec_ok, const double* tile, int RS) {
-    const int cp = threadIdx.x & 3, rr = threadIdx.x >> 2;
+    const int tid = tid_now();
+    const int cp = tid & 3, rr = tid >> 2;
     const int64_t c = c0 + 2 * cp;
     const double* s0 = tile + (2 * cp) * RS;
     const double* s1 = s0 + RS;
@@ -226,7 +238,8 @@ __device__ __forceinline__ void store_tile(double* __restrict__ dst, int64_t ld,
 template <int RPT>
 __device__ __forceinline__ double tile_reduce_mean(const TileRegs<RPT>& t, int nrows, int64_t c0, int64_t C, double* scratch,
                                                    int32_t* status, int wave, int lane) {
-    const int cp = threadIdx.x & 3, rr = threadIdx.x >> 2;
+    const int tid = tid_now();
+    const int cp = tid & 3, rr = tid >> 2;
     const int64_t c = c0 + 2 * cp;
     double s0 = 0.0, s1 = 0.0;
     bool bad0 = false, bad1 = false;
@@ -354,43 +367,57 @@ __device__ __forceinline__ unsigned lds_addr(const void* generic_ptr_into_lds) {
 #ifdef SD_RS_TRACING
 #define SD_TR(i)                                                                                         \
     do {                                                                                                 \
-        if (p.trace != nullptr && lane == 0 && (blockIdx.x & 1023) == 7)                                 \
-            p.trace[((int64_t)(blockIdx.x >> 10) * kW + wave) * 16 + (i)] = wall_clock64();              \
+        if (p->trace != nullptr && lane == 0 && (blockIdx.x & 1023) == 7)                                \
+            p->trace[((int64_t)(blockIdx.x >> 10) * kW + wave) * 16 + (i)] = wall_clock64();              \
     } while (0)
 #else
 #define SD_TR(i) do { } while (0)
 #endif
 
 template <int K, int MODE, int KIND, bool IDENT, bool SLAB>
-__device__ __forceinline__ void segment_body(const Params& p, const int64_t tile_id, const int g, char* smem_raw) {
-    static_assert(MODE == MODE_FIT || MODE == MODE_RANK || MODE == MODE_APPLY, "unknown mode");
+__device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g, char* smem_raw) {
+    static_assert(MODE == MODE_FIT || MODE == MODE_RANK || MODE == MODE_APPLY || MODE == MODE_BOTH, "unknown mode");
+    constexpr bool kRank = MODE == MODE_RANK || MODE == MODE_BOTH;    // ranks of the x_fut samples are computed here
+    constexpr bool kApply = MODE == MODE_APPLY || MODE == MODE_BOTH;  // ... and mapped through the y CDF here
     constexpr bool kTas = KIND == SD_BCSD_TAS;
     constexpr int CH = Chunk<K>::CH;
     constexpr int NR = (K + 1) / 2;
-    double* tile = reinterpret_cast<double*>(smem_raw);
-    const int RS = p.RS;
-    double* scratch = tile + kW * RS;  // 64 doubles
-    const double* rcp = scratch + 64;  // 16 doubles: correctly rounded 1/c, c = 1..9
-    const int64_t c0 = tile_id * kW;
-    const int64_t c0l = (p.ablate & 128) ? 0 : c0;  // dev: every tile loads the cells of tile 0 (cache-resident inputs)
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int64_t c = c0 + wave;
-    const bool cell_ok = c < p.C;
-    double* row = tile + wave * RS;
-    const int64_t seg = c * p.G + g;
-
-    const int begf = p.off_f[g], n = p.off_f[g + 1] - begf;
-    int begp = 0, m = 0;
-    if (MODE != MODE_FIT) {
-        begp = p.off_p[g];
-        m = p.off_p[g + 1] - begp;
-        if (m == 0) return;
-    } else if (n == 0) {
-        return;
-    }
-    const bool vec_f = (p.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
-                       (p.X == nullptr || (reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
-    const bool vec_p = MODE != MODE_FIT && (p.ld_p % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.Xp) & 15) == 0);
+    // per-segment quantities derived from (p, tile_id, g, thread id); MODE_BOTH derives them a second time from
+    // laundered inputs between its two halves so that nothing but the ranks and x_climo stays live across them
+    double *tile, *scratch, *row;
+    const double* rcp;
+    int RS, wave, lane, begf, n, begp, m;
+    int64_t c0, c0l, c, seg;
+    bool cell_ok, vec_f, vec_p;
+#define SD_DERIVE()                                                                                              \
+    do {                                                                                                         \
+        tile = reinterpret_cast<double*>(smem_raw);                                                              \
+        RS = p->RS;                                                                                              \
+        scratch = tile + kW * RS; /* 64 doubles */                                                               \
+        rcp = scratch + 64;       /* 16 doubles: correctly rounded 1/c, c = 1..9 */                              \
+        c0 = tile_id * kW;                                                                                       \
+        c0l = (p->ablate & 128) ? 0 : c0; /* dev: every tile loads the cells of tile 0 (cache-resident inputs) */ \
+        const int t_ = tid_now();                                                                                \
+        wave = t_ / kWave;                                                                                       \
+        lane = t_ % kWave;                                                                                       \
+        c = c0 + wave;                                                                                           \
+        cell_ok = c < p->C;                                                                                      \
+        row = tile + wave * RS;                                                                                  \
+        seg = c * p->G + g;                                                                                      \
+        begf = p->off_f[g];                                                                                      \
+        n = p->off_f[g + 1] - begf;                                                                              \
+        begp = 0;                                                                                                \
+        m = 0;                                                                                                   \
+        if (MODE != MODE_FIT) {                                                                                  \
+            begp = p->off_p[g];                                                                                  \
+            m = p->off_p[g + 1] - begp;                                                                          \
+        }                                                                                                        \
+        vec_f = (p->ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->y) & 15) == 0) &&                          \
+                (p->X == nullptr || (reinterpret_cast<uintptr_t>(p->X) & 15) == 0);                             \
+        vec_p = MODE != MODE_FIT && (p->ld_p % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->Xp) & 15) == 0);     \
+    } while (0)
+    SD_DERIVE();
+    if (MODE != MODE_FIT ? m == 0 : n == 0) return;
 
     SD_TR(0);
     // ---- x climatology (bcsd.py:222); PR only validates X ------------------------------------------
@@ -398,30 +425,31 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
     // column sums are reduced while the tile is still in flight: one exposed memory latency instead of two.
     double xc = 0.0;
     TileRegs<NR> xf;
-    const bool dual = MODE == MODE_RANK && !(p.ablate & 16);
-    if (MODE == MODE_APPLY || (MODE == MODE_RANK && p.from_state)) {
-        if (kTas && cell_ok) xc = p.x_climo[seg];
-        if (dual) tile_issue<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0l, p.C, vec_p, xf, (p.ablate & 256) ? 63 : -1);
-    } else if (p.X != nullptr && n > 0 && !(p.ablate & 32)) {
+    const bool dual = kRank && !(p->ablate & 16);
+    if (MODE == MODE_APPLY || (kRank && p->from_state)) {
+        if (kTas && cell_ok) xc = p->x_climo[seg];
+        if (dual) tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0l, p->C, vec_p, xf, (p->ablate & 256) ? 63 : -1);
+    } else if (p->X != nullptr && n > 0 && !(p->ablate & 32)) {
         TileRegs<NR> xh;
-        tile_issue<NR>(p.X, p.ld, p.ord_f + begf, n, c0l, p.C, vec_f, xh, (p.ablate & 256) ? 63 : -1);
-        if (dual) tile_issue<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0l, p.C, vec_p, xf, (p.ablate & 256) ? 63 : -1);
-        xc = tile_reduce_mean<NR>(xh, n, c0, p.C, scratch, p.status_fit, wave, lane);
-        if (kTas && lane == 0 && cell_ok) p.x_climo[seg] = xc;
+        tile_issue<NR>(p->X, p->ld, p->ord_f + begf, n, c0l, p->C, vec_f, xh, (p->ablate & 256) ? 63 : -1);
+        if (dual) tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0l, p->C, vec_p, xf, (p->ablate & 256) ? 63 : -1);
+        xc = tile_reduce_mean<NR>(xh, n, c0, p->C, scratch, p->status_fit, wave, lane);
+        if (kTas && lane == 0 && cell_ok) p->x_climo[seg] = xc;
     } else if (dual) {
-        tile_issue<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0l, p.C, vec_p, xf, (p.ablate & 256) ? 63 : -1);
+        tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0l, p->C, vec_p, xf, (p->ablate & 256) ? 63 : -1);
     }
 
     SD_TR(1);
-    if (MODE == MODE_RANK) {
+    unsigned rank2[NR];  // two 16-bit ranks per register (segments are < 65536 samples)
+    if (kRank) {
         // ---- x_fut segment -> shifted series u -> rank of every sample in sort(u) --------------------
-        if (!dual) tile_issue<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0l, p.C, vec_p, xf, (p.ablate & 256) ? 63 : -1);
-        tile_commit<NR>(xf, m, c0, p.C, tile + kPadFront, RS, p.status_p);
+        if (!dual) tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0l, p->C, vec_p, xf, (p->ablate & 256) ? 63 : -1);
+        tile_commit<NR>(xf, m, c0, p->C, tile + kPadFront, RS, p->status_p);
         if (kTas) zero_pads(row, m, lane, CH + 4);
         __syncthreads();
         SD_TR(2);
         double u[K];  // u = X - (rolling mean - x_climo) (bcsd.py:247-256); PR maps raw X (bcsd.py:167)
-        double* sh = (kTas && p.shift != nullptr && cell_ok) ? p.shift + (seg * K) * kWave + lane : nullptr;
+        double* sh = (kTas && p->shift != nullptr && cell_ok) ? p->shift + (seg * K) * kWave + lane : nullptr;
 #pragma unroll
         for (int cbeg = 0; cbeg < K; cbeg += CH) {
             double mean[CH], xv[CH];
@@ -449,7 +477,7 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
         }
         wave_fence();
         SD_TR(3);
-        if (!(p.ablate & 1)) {
+        if (!(p->ablate & 1)) {
             double s[K];
 #pragma unroll
             for (int i = 0; i < K; ++i) s[i] = u[i];
@@ -461,7 +489,6 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
         // CH independent chains at a time; positions are kept as LDS byte addresses (add, compare, select per
         // step).  A stride that is a multiple of 16 doubles would put the probes of all lanes on one or two
         // banks (the 2^k candidates of step k are whole strides apart): such strides are shortened by one.
-        unsigned rank2[NR];  // two 16-bit ranks per register (segments are < 65536 samples)
 #pragma unroll
         for (int i = 0; i < NR; ++i) rank2[i] = 0u;
         const unsigned rowb = lds_addr(row);
@@ -471,7 +498,7 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
 #pragma unroll
             for (int ii = 0; ii < CH; ++ii) pb[ii] = rowb - 8u;
 #pragma unroll 1
-            for (int len = (p.ablate & 2) ? 1 : m; len > 1;) {
+            for (int len = (p->ablate & 2) ? 1 : m; len > 1;) {
                 int half = len >> 1;
                 if ((half & 15) == 0) --half;
                 len -= half;
@@ -496,27 +523,37 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
             __builtin_amdgcn_sched_barrier(0);
         }
         SD_TR(5);
-        if (cell_ok) {
-            uint32_t* rk = p.ranks + (seg * NR) * kWave + lane;
+        if (MODE == MODE_RANK) {
+            if (cell_ok) {
+                uint32_t* rk = p->ranks + (seg * NR) * kWave + lane;
 #pragma unroll
-            for (int i = 0; i < NR; ++i) rk[i * kWave] = rank2[i];
+                for (int i = 0; i < NR; ++i) rk[i * kWave] = rank2[i];
+            }
+            SD_TR(6);
+            return;
         }
-        SD_TR(6);
-        return;
+        __syncthreads();  // MODE_BOTH: every wave is done with its sorted x row, the tile is reused for y
+        // pin the ranks (and x_climo) into registers here: otherwise the scheduler sinks the last search step behind
+        // the y phase and keeps the searched values alive across it (200 bytes/lane of scratch)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) asm volatile("" : "+v"(rank2[i]));
+        asm volatile("" : "+v"(xc));
+        asm volatile("" : "+s"(p), "+s"(tile_id), "+s"(g));
+        SD_DERIVE();
     }
+#undef SD_DERIVE
 
-    unsigned rank2[NR];
     if (MODE == MODE_APPLY) {  // issued first: the loads fly while y is sorted
-        const uint32_t* rk = p.ranks + (seg * NR) * kWave + lane;
+        const uint32_t* rk = p->ranks + (seg * NR) * kWave + lane;
 #pragma unroll
         for (int i = 0; i < NR; ++i) rank2[i] = cell_ok ? rk[i * kWave] : 0u;
     }
 
     // ---- y: climatology + sorted segment in the wave's row ------------------------------------------
     double yc = 0.0;
-    if (!(MODE == MODE_APPLY && p.from_state)) {
+    if (!(kApply && p->from_state)) {
         if (n > 0) {
-            load_tile<NR>(p.y, p.ld, p.ord_f + begf, n, c0l, p.C, vec_f, tile, RS, p.status_fit);
+            load_tile<NR>(p->y, p->ld, p->ord_f + begf, n, c0l, p->C, vec_f, tile, RS, p->status_fit);
             __syncthreads();
             SD_TR(2);
             double v[K];
@@ -526,35 +563,35 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
             for (int i = 0; i < K; ++i) s += v[i];
             yc = wave_sum(s) / (double)n;  // bcsd.py:223 / 138
             if (lane == 0 && cell_ok) {
-                if (MODE == MODE_FIT) p.y_climo[seg] = yc;
-                if (!kTas && p.return_anoms && yc <= 0.0) atomicOr(&p.status_fit[c], SDI_BAD_CLIMO);  // bcsd.py:140-141
+                if (MODE == MODE_FIT) p->y_climo[seg] = yc;
+                if (!kTas && p->return_anoms && yc <= 0.0) atomicOr(&p->status_fit[c], SDI_BAD_CLIMO);  // bcsd.py:140-141
             }
 #pragma unroll
             for (int i = 0; i < K; ++i) v[i] = K * lane + i < n ? v[i] : __builtin_inf();
             wave_fence();
             SD_TR(3);
-            if (!(p.ablate & 4)) sort_segment<K>(v, row, n, lane);  // quantile.py:462 np.sort
+            if (!(p->ablate & 4)) sort_segment<K>(v, row, n, lane);  // quantile.py:462 np.sort
             if (MODE == MODE_FIT && cell_ok) {
-                double* dst = p.ys + c * p.Tf + begf;
+                double* dst = p->ys + c * p->Tf + begf;
                 for (int i = lane; i < n; i += kWave) dst[i] = row[i];
             }
         }
     } else {
         if (cell_ok) {
-            yc = p.y_climo[seg];
-            const double* src = p.ys + c * p.Tf + begf;
+            yc = p->y_climo[seg];
+            const double* src = p->ys + c * p->Tf + begf;
             for (int i = lane; i < n; i += kWave) row[i] = src[i];
         }
         wave_fence();
     }
     SD_TR(4);
-    if (MODE == MODE_FIT) return;
+    if (!kApply) return;
 
     // No shift slab: the x_fut tile is read a second time (its RANK twin fetched it moments ago: L2 / Infinity
     // Cache) to recompute the rolling mean; the loads are issued here and fly during the lookups.
     constexpr bool reload = kTas && !SLAB;
     TileRegs<NR> xf2;
-    if (reload) tile_issue<NR>(p.Xp, p.ld_p, p.ord_p + begp, m, c0l, p.C, vec_p, xf2);
+    if (reload) tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0l, p->C, vec_p, xf2);
 
     // ---- map ranks through the fitted inverse CDF (quantile.py:523-545) ------------------------------
     double q[K];
@@ -573,13 +610,13 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
             ols_line(row, n - e, e, dn, &shi, &ihi);
         }
         const double nan = __longlong_as_double(0x7ff8000000000000ll);
-        const int32_t* qi = p.qidx + begp;
-        const double* qv = p.qval + begp;
+        const int32_t* qi = p->qidx + begp;
+        const double* qv = p->qval + begp;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             const int r = (int)((i & 1) ? (rank2[i >> 1] >> 16) : (rank2[i >> 1] & 0xffffu));
-            const int idx = (p.ablate & 8) ? 0 : qi[r];
-            const double w = (p.ablate & 8) ? 0.0 : qv[r];
+            const int idx = (p->ablate & 8) ? 0 : qi[r];
+            const double w = (p->ablate & 8) ? 0.0 : qv[r];
             double t;
             if (idx >= 0) {
                 const double y0 = row[idx];
@@ -602,17 +639,17 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
     if (kTas) {
         if (SLAB) {
             if (cell_ok) {
-                const double* sh = p.shift + (seg * K) * kWave + lane;
+                const double* sh = p->shift + (seg * K) * kWave + lane;
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
                     double res = sh[i * kWave] + q[i];   // bcsd.py:253,263
-                    if (p.return_anoms) res = res - yc;  // bcsd.py:266-267
+                    if (p->return_anoms) res = res - yc;  // bcsd.py:266-267
                     q[i] = res;
                 }
             }
         } else {
             __syncthreads();  // all lookups done: rows are free again
-            tile_commit<NR>(xf2, m, c0, p.C, tile + kPadFront, RS, p.status_p);
+            tile_commit<NR>(xf2, m, c0, p->C, tile + kPadFront, RS, p->status_p);
             zero_pads(row, m, lane, CH + 4);
             __syncthreads();
             SD_TR(6);
@@ -625,7 +662,7 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
                     const int i = cbeg + ii;
                     if (i < K) {
                         double res = (mean[ii] - xc) + q[i];  // bcsd.py:253,263
-                        if (p.return_anoms) res = res - yc;   // bcsd.py:266-267
+                        if (p->return_anoms) res = res - yc;   // bcsd.py:266-267
                         q[i] = res;
                     }
                 }
@@ -634,7 +671,7 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < K; ++i) q[i] = p.return_anoms ? q[i] / yc : q[i];  // bcsd.py:170-185
+        for (int i = 0; i < K; ++i) q[i] = p->return_anoms ? q[i] / yc : q[i];  // bcsd.py:170-185
     }
     SD_TR(7);
     wave_fence();  // the wave's own row is rewritten in time order
@@ -645,16 +682,17 @@ __device__ __forceinline__ void segment_body(const Params& p, const int64_t tile
     }
     __syncthreads();
     SD_TR(8);
-    const bool vec_o = (p.ld_out % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
-    if (!(p.ablate & 64)) store_tile(p.out, p.ld_out, p.ord_p + begp, m, c0, p.C, vec_o, tile, RS);
+    const bool vec_o = (p->ld_out % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->out) & 15) == 0);
+    if (!(p->ablate & 64)) store_tile(p->out, p->ld_out, p->ord_p + begp, m, c0, p->C, vec_o, tile, RS);
     SD_TR(9);
 }
 
 template <int K, int MODE, int OCC, int KIND, bool IDENT, bool SLAB>
-__global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) {
+__global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();  // Params is the only kernel argument
     {
-        double* rcp = reinterpret_cast<double*>(smem_raw) + kW * p.RS + 64;
+        double* rcp = reinterpret_cast<double*>(smem_raw) + kW * p->RS + 64;
         if (threadIdx.x < 16) {
             const double tab[16] = {0.0, 1.0, 0.5, 1.0 / 3.0, 0.25, 0.2, 1.0 / 6.0, 1.0 / 7.0, 0.125, 1.0 / 9.0, 0, 0, 0, 0, 0, 0};
             rcp[threadIdx.x] = tab[threadIdx.x];
@@ -663,12 +701,12 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params p) 
     // XCD-aware workgroup -> (tile, group): workgroup b runs on XCD b % 8; XCD x owns tiles [x*tx, (x+1)*tx)
     // and walks them tile-fastest, so the two 64-byte halves of a 128-byte line are fetched by workgroups
     // that are adjacent in time on the same L2.
-    const int64_t tx = (p.ntiles + 7) / 8;
+    const int64_t tx = (p->ntiles + 7) / 8;
     const int xcd = blockIdx.x & 7;
     const int64_t jb = blockIdx.x >> 3;
     const int64_t tile_id = xcd * tx + jb % tx;
     const int g = (int)(jb / tx);
-    if (tile_id >= p.ntiles || g >= p.G) return;
+    if (tile_id >= p->ntiles || g >= p->G) return;
     segment_body<K, MODE, KIND, IDENT, SLAB>(p, tile_id, g, smem_raw);
 }
 
@@ -717,8 +755,8 @@ int launch_koki(sd_ctx* ctx, const Params& p, const char* name) {
 template <int K, int MODE, int OCC, int KIND>
 int launch_kok(sd_ctx* ctx, const Params& p, const char* name) {
     // IDENT and SLAB only change MODE_APPLY code (RANK tests p.shift at run time: one store per sample)
-    if constexpr (MODE == MODE_APPLY) {
-        if constexpr (KIND == SD_BCSD_TAS) {
+    if constexpr (MODE == MODE_APPLY || MODE == MODE_BOTH) {
+        if constexpr (KIND == SD_BCSD_TAS && MODE == MODE_APPLY) {
             if (p.shift != nullptr)
                 return p.identity ? launch_koki<K, MODE, OCC, KIND, true, true>(ctx, p, name)
                                   : launch_koki<K, MODE, OCC, KIND, false, true>(ctx, p, name);
@@ -780,6 +818,7 @@ int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax) {
         case sdrs::MODE_FIT: return sdrs::launch_mode<sdrs::MODE_FIT>(ctx, p, nmax, "bcsd_rs_fit_kernel");
         case sdrs::MODE_RANK: return sdrs::launch_mode<sdrs::MODE_RANK>(ctx, p, nmax, "bcsd_rs_rank_kernel");
         case sdrs::MODE_APPLY: return sdrs::launch_mode<sdrs::MODE_APPLY>(ctx, p, nmax, "bcsd_rs_apply_kernel");
+        case sdrs::MODE_BOTH: return sdrs::launch_mode<sdrs::MODE_BOTH>(ctx, p, nmax, "bcsd_rs_rank_apply_kernel");
         default: return sd_set_error(SD_ERR_INVALID, "unknown register-sort mode %d", mode);
     }
 }

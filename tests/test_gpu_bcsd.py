@@ -151,6 +151,14 @@ def test_shift_slab_handoff_is_bit_identical(ctx, monkeypatch):
         b1, _ = ctx.bcsd_predict(st, dXp, gid_p)
         assert np.array_equal(a.to_host(), a1.to_host()), (T, Tp)
         assert np.array_equal(b.to_host(), b1.to_host()), (T, Tp)
+        monkeypatch.delenv("SD_RS_SHIFT", raising=False)
+        # SD_RS_ONE_KERNEL=1: RANK and APPLY of a segment in one workgroup, ranks in registers
+        monkeypatch.setenv("SD_RS_ONE_KERNEL", "1")
+        a2, _ = ctx.bcsd_fit_predict(0, dX, dy, gid, 12, dXp, gid_p)
+        b2, _ = ctx.bcsd_predict(st, dXp, gid_p)
+        assert np.array_equal(a.to_host(), a2.to_host()), (T, Tp)
+        assert np.array_equal(b.to_host(), b2.to_host()), (T, Tp)
+        monkeypatch.delenv("SD_RS_ONE_KERNEL", raising=False)
     monkeypatch.delenv("SD_RS_SHIFT", raising=False)
 
 
