@@ -63,6 +63,11 @@ extern "C" {
 #define SD_ANALOG_WEIGHT 2
 #define SD_ANALOG_MEAN 3
 
+/* quantile-mapping regressors (quantile.py:160-395, 556-636) */
+#define SD_QM_REGRESSOR 0        /* QuantileMappingReressor */
+#define SD_QM_EDCDF_DIFFERENCE 1 /* EquidistantCdfMatcher(kind='difference') */
+#define SD_QM_EDCDF_RATIO 2      /* EquidistantCdfMatcher(kind='ratio') */
+
 /* synthetic field kinds (sd_synth_fill) */
 #define SD_SYNTH_GAUSS 0
 #define SD_SYNTH_PRECIP 1
@@ -70,6 +75,7 @@ extern "C" {
 typedef struct sd_ctx sd_ctx;
 typedef struct sd_bcsd_state sd_bcsd_state;
 typedef struct sd_analog_state sd_analog_state;
+typedef struct sd_qm_state sd_qm_state;
 
 /* ---- library / context ---------------------------------------------------------------------- */
 int sd_version(void);
@@ -152,6 +158,23 @@ int sd_analogreg_predict_dev(sd_ctx* ctx, const sd_analog_state* st, const doubl
                              int k, double* out_dev, int64_t ld_out, int32_t* cell_status);
 int sd_analog_state_info(const sd_analog_state* st, int64_t* T, int* F, int64_t* C);
 int sd_analog_state_destroy(sd_analog_state* st);
+
+/* ---- quantile-mapping regressors ----------------------------------------------------------------
+ * Replace core.py:86-96 / 137-141 looping QuantileMappingReressor (quantile.py:160-395) or
+ * EquidistantCdfMatcher (quantile.py:556-636) per cell, for extrapolate in {None, '1to1'}
+ * (one_to_one = 0 / 1).  X, y: [T, C] float64, cells contiguous; the whole series is one segment.
+ * model: SD_QM_REGRESSOR / SD_QM_EDCDF_DIFFERENCE / SD_QM_EDCDF_RATIO.  Series up to 19 456 samples. */
+int sd_qm_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int64_t C, sd_qm_state** out);
+int sd_qm_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t ld, int64_t T, int64_t C,
+                  sd_qm_state** out);
+int sd_qm_predict(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_one, const double* Xp, int64_t Tp,
+                  double* out, int32_t* cell_status);
+int sd_qm_predict_dev(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_one, const double* Xp_dev,
+                      int64_t ld, int64_t Tp, double* out_dev, int64_t ld_out, int32_t* cell_status);
+int sd_qm_state_info(const sd_qm_state* st, int64_t* T, int64_t* C);
+/* sorted fit series [C][T] (cell-major) and per-cell status; any pointer may be NULL */
+int sd_qm_state_export(const sd_qm_state* st, double* x_sorted, double* y_sorted, int32_t* cell_status);
+int sd_qm_state_destroy(sd_qm_state* st);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@ from .bcsd import BcsdGridModel, BcsdPrecipitation, BcsdTemperature
 from .core import GridArray, GridDataset, PointWiseDownscaler
 from .gard import AnalogGridModel, AnalogRegression, PureAnalog
 from .groupers import DAY_GROUPER, MONTH_GROUPER
+from .quantile import EquidistantCdfMatcher, QmGridModel, QuantileMappingReressor
 
 __all__ = [
     "AnalogRegression",
@@ -20,5 +21,8 @@ __all__ = [
     "GridDataset",
     "BcsdGridModel",
     "AnalogGridModel",
+    "QuantileMappingReressor",
+    "EquidistantCdfMatcher",
+    "QmGridModel",
 ]
 __version__ = "0.1.0"

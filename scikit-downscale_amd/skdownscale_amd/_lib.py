@@ -18,6 +18,7 @@ SD_OK = 0
 BCSD_TAS, BCSD_PR = 0, 1
 CELL_OK, CELL_MASKED, CELL_NONFINITE, CELL_BAD_CLIMO = 0, 1, 2, 3
 ANALOG_BEST, ANALOG_SAMPLE, ANALOG_WEIGHT, ANALOG_MEAN = 0, 1, 2, 3
+QM_REGRESSOR, QM_EDCDF_DIFFERENCE, QM_EDCDF_RATIO = 0, 1, 2
 SYNTH_GAUSS, SYNTH_PRECIP = 0, 1
 
 _p = C.c_void_p
@@ -65,6 +66,13 @@ SIGNATURES = {
     "sd_analogreg_predict_dev": [_p, _p, _p, _i64, _i64, _int, _p, _i64, _p],
     "sd_analog_state_info": [_p, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_i64)],
     "sd_analog_state_destroy": [_p],
+    "sd_qm_fit": [_p, _p, _p, _i64, _i64, C.POINTER(_p)],
+    "sd_qm_fit_dev": [_p, _p, _p, _i64, _i64, _i64, C.POINTER(_p)],
+    "sd_qm_predict": [_p, _p, _int, _int, _p, _i64, _p, _p],
+    "sd_qm_predict_dev": [_p, _p, _int, _int, _p, _i64, _i64, _p, _i64, _p],
+    "sd_qm_state_info": [_p, C.POINTER(_i64), C.POINTER(_i64)],
+    "sd_qm_state_export": [_p, _p, _p, _p],
+    "sd_qm_state_destroy": [_p],
 }
 
 _lib = None

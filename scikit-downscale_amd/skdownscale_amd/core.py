@@ -19,6 +19,7 @@ import pandas as pd
 from . import _lib
 from .bcsd import BcsdBase, BcsdGridModel, check_supported
 from .gard import AnalogBase, AnalogGridModel, AnalogRegression, PureAnalog
+from .quantile import QmGridModel, QuantileMappingReressor, check_extrapolate
 
 DEFAULT_FEATURE_DIM = "variable"
 
@@ -163,6 +164,10 @@ class PointWiseDownscaler:
             if isinstance(m, AnalogRegression) and (m.thresh is not None or m.lr_kwargs):
                 raise NotImplementedError("AnalogRegression(thresh=... / lr_kwargs) is not supported on the HIP engine")
             return "analog"
+        if isinstance(m, QuantileMappingReressor):
+            check_extrapolate(m.extrapolate)
+            m._engine_code()
+            return "qm"
         return None
 
     # ------------------------------------------------------------------------------------------
@@ -199,6 +204,15 @@ class PointWiseDownscaler:
                 raise ValueError(msg.format(F))
             gm = BcsdGridModel(m._kind, m.return_anoms, m.time_grouper)
             gm.fit(Xv[:, 0, :], yv, index)
+            self._raise_for_status(gm.status_, Xv[:, 0, :], yv)
+        elif kind == "qm":
+            if F != 1:
+                raise ValueError(f"Found array with {F} features (shape=({T}, {F})) while a maximum of 1 is required")
+            if T < 2 * m.n_endpoints + 1:
+                raise ValueError(f"Found array with {T} sample(s) (shape=({T}, 1)) while a minimum of {2 * m.n_endpoints + 1} is required.")
+            gm = QmGridModel(m._engine_code(), m.extrapolate)
+            gm.fit(Xv[:, 0, :], yv)
+            gm.status_ = gm.state.export()["status"]
             self._raise_for_status(gm.status_, Xv[:, 0, :], yv)
         else:
             gm = AnalogGridModel(m.n_analogs)
@@ -267,6 +281,11 @@ class PointWiseDownscaler:
         coords = {k: v for k, v in Xg.coords.items() if k != feature_dim}
         if mdl.kind == "bcsd":
             out, status = mdl.grid_model.predict(Xv[:, 0, :], index)
+            self._raise_for_status(status, Xv[:, 0, :], Xv[:, 0, :])
+            vals = out.reshape((T,) + tuple(spatial_shape)).astype(Xg.dtype, copy=False)
+            res = GridArray(vals, (self._dim,) + spatial_dims, coords)
+        elif mdl.kind == "qm":
+            out, status = mdl.grid_model.predict(Xv[:, 0, :])
             self._raise_for_status(status, Xv[:, 0, :], Xv[:, 0, :])
             vals = out.reshape((T,) + tuple(spatial_shape)).astype(Xg.dtype, copy=False)
             res = GridArray(vals, (self._dim,) + spatial_dims, coords)

@@ -123,6 +123,20 @@ class AnalogState(_State):
         return dict(T=T.value, F=F.value, C=Cc.value)
 
 
+class QmState(_State):
+    def info(self):
+        T, Cc = C.c_int64(), C.c_int64()
+        check(self.ctx.lib.sd_qm_state_info(self.vptr, C.byref(T), C.byref(Cc)))
+        return dict(T=T.value, C=Cc.value)
+
+    def export(self):
+        i = self.info()
+        xs, ys = np.empty((i["C"], i["T"])), np.empty((i["C"], i["T"]))
+        status = np.empty(i["C"], dtype=np.int32)
+        check(self.ctx.lib.sd_qm_state_export(self.vptr, ptr(xs), ptr(ys), ptr(status)))
+        return dict(x_sorted=xs, y_sorted=ys, status=status)
+
+
 class Context:
     """One GPU + one HIP stream.  Calls on a context are serialised."""
 
@@ -256,6 +270,36 @@ class Context:
             ptr(_lib.as_f64(exported["x_climo"])), ptr(_lib.as_f64(exported["y_climo"])), ptr(_lib.as_i32(exported["status"])),
             ptr(np.ascontiguousarray(exported["group_offsets"], dtype=np.int64)), C.byref(h)))
         return BcsdState(self, h.value, self.lib.sd_bcsd_state_destroy)
+
+    # ---- quantile-mapping regressors ----
+    def qm_fit(self, X, y):
+        """X, y [T, C] numpy or DeviceArray -> QmState (sorted series per cell)."""
+        h = C.c_void_p()
+        if isinstance(y, DeviceArray):
+            T, Cc = y.shape
+            assert X.ld == y.ld
+            check(self.lib.sd_qm_fit_dev(self.handle, X.vptr, y.vptr, y.ld, T, Cc, C.byref(h)))
+        else:
+            X, y = _lib.as_f64(X), _lib.as_f64(y)
+            T, Cc = y.shape
+            check(self.lib.sd_qm_fit(self.handle, ptr(X), ptr(y), T, Cc, C.byref(h)))
+        return QmState(self, h.value, self.lib.sd_qm_state_destroy)
+
+    def qm_predict(self, state, model, Xp, one_to_one=False, out=None):
+        Cc = state.info()["C"]
+        status = np.empty(Cc, dtype=np.int32)
+        if isinstance(Xp, DeviceArray):
+            Tp = Xp.shape[0]
+            out = self.empty((Tp, Cc)) if out is None else out
+            check(self.lib.sd_qm_predict_dev(self.handle, state.vptr, int(model), int(bool(one_to_one)), Xp.vptr, Xp.ld, Tp,
+                                             out.vptr, out.ld, ptr(status)))
+        else:
+            Xp = _lib.as_f64(Xp)
+            Tp = Xp.shape[0]
+            out = np.empty((Tp, Cc))
+            check(self.lib.sd_qm_predict(self.handle, state.vptr, int(model), int(bool(one_to_one)), ptr(Xp), Tp, ptr(out),
+                                         ptr(status)))
+        return out, status
 
     # ---- analogs ----
     def analog_fit(self, X, y):

@@ -1,0 +1,147 @@
+"""Quantile-mapping regressors with the reference's surface, computed by the HIP engine.
+
+Mirrors ``skdownscale/pointwise_models/quantile.py``: ``QuantileMappingReressor`` (160-395) and
+``EquidistantCdfMatcher`` (556-636).  The arithmetic runs in ``csrc/sd_qm.hip`` through the C ABI for
+``extrapolate`` in ``{None, '1to1'}``.  ``'min'`` / ``'max'`` / ``'both'`` are refused: the reference evaluates
+``np.interp`` across synthetic end points at +-1e20 there (quantile.py:17-18, 338-346), a cancellation that
+leaves ~1e5 of absolute rounding noise in its own outputs, so no parity can be defined for those samples.
+"""
+from __future__ import annotations
+
+import collections
+
+import numpy as np
+from sklearn.base import BaseEstimator, RegressorMixin
+from sklearn.exceptions import NotFittedError
+from sklearn.utils import check_array
+
+from . import _lib
+from .engine import default_context
+
+Cdf = collections.namedtuple("Cdf", ["pp", "vals"])  # quantile.py:20
+
+
+def plotting_positions(n, alpha=0.4, beta=0.4):
+    """quantile.py:23-43."""
+    return (np.arange(1, n + 1) - alpha) / (n + 1.0 - alpha - beta)
+
+
+def check_max_features(array, n=1):
+    """utils.py:10-25."""
+    if array.ndim == 2 and array.shape[1] > n:
+        raise ValueError(f"Found array with {array.shape[1]} features (shape={array.shape}) while a maximum of {n} is required")
+    if array.ndim > 2:
+        raise ValueError(f"Found array with {array.ndim} dimensions")
+    return array
+
+
+def check_extrapolate(extrapolate):
+    if extrapolate not in (None, "1to1", "min", "max", "both"):
+        raise ValueError(f"unknown value for extrapolate: {extrapolate}")  # quantile.py:348-349
+    if extrapolate in ("min", "max", "both"):
+        raise NotImplementedError(
+            f"extrapolate={extrapolate!r}: interpolation across the synthetic +-1e20 end points is ill-conditioned in the "
+            "reference itself; only extrapolate=None and '1to1' run on the HIP engine")
+
+
+class QmGridModel:
+    """Batched quantile-mapping regressor over the cell axis: X, y [T, C], Xp [Tp, C] (numpy or DeviceArray)."""
+
+    def __init__(self, model, extrapolate=None, ctx=None):
+        check_extrapolate(extrapolate)
+        self.model = int(model)
+        self.one_to_one = extrapolate == "1to1"
+        self.ctx = ctx or default_context()
+        self.state = None
+
+    def fit(self, X, y):
+        self.state = self.ctx.qm_fit(X, y)
+        return self
+
+    def predict(self, Xp, out=None):
+        if self.state is None:
+            raise NotFittedError("This quantile-mapping grid model is not fitted yet.")
+        return self.ctx.qm_predict(self.state, self.model, Xp, self.one_to_one, out=out)
+
+
+class QuantileMappingReressor(RegressorMixin, BaseEstimator):
+    """Transform features using quantile mapping (quantile.py:160-395; the class name is the reference's spelling).
+
+    Parameters
+    ----------
+    extrapolate : {None, '1to1'} (the reference's 'min', 'max', 'both' are refused, see the module docstring)
+    n_endpoints : int, kept for the reference's minimum-sample rule (2 * n_endpoints + 1 samples to fit)
+    """
+
+    _fit_attributes = ["_X_cdf", "_y_cdf"]
+    _engine_model = _lib.QM_REGRESSOR
+
+    def __init__(self, extrapolate=None, n_endpoints=10):
+        self.extrapolate = extrapolate
+        self.n_endpoints = n_endpoints
+        if self.n_endpoints < 2:
+            raise ValueError("Invalid number of n_endpoints, must be >= 2")  # quantile.py:189-190
+
+    def _engine_code(self):
+        return self._engine_model
+
+    def fit(self, X, y, **kwargs):
+        X = check_array(X, dtype="numeric", ensure_min_samples=2 * self.n_endpoints + 1, ensure_2d=True)
+        y = check_array(y, dtype="numeric", ensure_min_samples=2 * self.n_endpoints + 1, ensure_2d=False)
+        X = check_max_features(X, n=1)
+        check_extrapolate(self.extrapolate)
+        self._grid = QmGridModel(self._engine_code(), self.extrapolate)
+        self._grid.fit(np.asarray(X, dtype=np.float64).reshape(-1, 1), np.asarray(y, dtype=np.float64).reshape(-1, 1))
+        e = self._grid.state.export()
+        self._X_cdf = self._extended(e["x_sorted"][0])
+        self._y_cdf = self._extended(e["y_sorted"][0])
+        return self
+
+    @staticmethod
+    def _extended(vals):
+        """quantile.py:312-387 for extrapolate in (None, '1to1'): both end points duplicated."""
+        pp = plotting_positions(len(vals))
+        return Cdf(np.concatenate([pp[:1], pp, pp[-1:]]), np.concatenate([vals[:1], vals, vals[-1:]]))
+
+    def predict(self, X, **kwargs):
+        if not hasattr(self, "_X_cdf"):
+            raise NotFittedError(
+                f"This {type(self).__name__} instance is not fitted yet. Call 'fit' with appropriate arguments before using this estimator.")
+        X = check_array(X, ensure_2d=True)
+        if not hasattr(self, "_grid"):
+            self._grid = QmGridModel(self._engine_code(), self.extrapolate)
+            n = len(self._X_cdf.vals) - 2
+            self._grid.fit(self._X_cdf.vals[1:-1].reshape(n, 1), self._y_cdf.vals[1:-1].reshape(n, 1))
+        out, _ = self._grid.predict(np.asarray(X[:, :1], dtype=np.float64))
+        return out[:, 0]
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_grid", None)  # device handle: rebuilt on demand from the fitted CDFs
+        return d
+
+    def __sklearn_tags__(self):
+        from dataclasses import replace
+
+        tags = super().__sklearn_tags__()
+        return replace(tags, _skip_test="QuantileMappingReressor only supports 1 feature")
+
+
+class EquidistantCdfMatcher(QuantileMappingReressor):
+    """Equidistant CDF matching (quantile.py:556-636): quantile mapping that preserves the difference or the ratio
+    between the new and the training X at equal plotting positions."""
+
+    def __init__(self, kind="difference", extrapolate=None, n_endpoints=10, max_ratio=None):
+        if kind not in ["difference", "ratio"]:
+            raise NotImplementedError("kind must be either difference or ratio")
+        self.kind = kind
+        self.extrapolate = extrapolate
+        self.n_endpoints = n_endpoints
+        self.max_ratio = max_ratio
+        if self.n_endpoints < 2:
+            raise ValueError("Invalid number of n_endpoints, must be >= 2")
+
+    def _engine_code(self):
+        if self.max_ratio is not None:  # the reference calls np.min(ratio, max_ratio) (quantile.py:621-622) and fails
+            raise NotImplementedError("EquidistantCdfMatcher(max_ratio=...) is not supported")
+        return _lib.QM_EDCDF_DIFFERENCE if self.kind == "difference" else _lib.QM_EDCDF_RATIO

@@ -1,0 +1,105 @@
+"""GPU parity: quantile-mapping regressors (csrc/sd_qm.hip through the C ABI) vs goldens from the reference and the oracle."""
+import pickle
+
+import numpy as np
+import pytest
+
+import qm_oracle as qo
+from _cases import assert_close, load
+
+pytestmark = pytest.mark.gpu
+MODELS = {"qmr": 0, "ecm_difference": 1, "ecm_ratio": 2}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from skdownscale_amd.engine import default_context
+
+    return default_context()
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+@pytest.mark.parametrize("resident", [False, True])
+def test_goldens_from_the_reference(ctx, case, resident):
+    """g9_qm.npz: QuantileMappingReressor / EquidistantCdfMatcher outputs of the real reference, extrapolate None and
+    '1to1', predict series equal / longer and shifted up / shorter and shifted down (n_endpoints does not enter)."""
+    g = load("g9_qm")
+    X, y, Xp = g[f"X{case}"], g[f"y{case}"], g[f"Xp{case}"]
+    st = ctx.qm_fit(ctx.to_device(X), ctx.to_device(y)) if resident else ctx.qm_fit(X, y)
+    for ex in (None, "1to1"):
+        for name, code in MODELS.items():
+            out, status = ctx.qm_predict(st, code, ctx.to_device(Xp) if resident else Xp, ex == "1to1")
+            out = out.to_host() if resident else out
+            assert (status == 0).all()
+            for ne in (10, 2):
+                assert_close(out, g[f"out{case}_{name}_{ex}_{ne}"], what=f"{name} case {case} extrapolate={ex}")
+
+
+@pytest.mark.parametrize("T,Tp,C", [(21, 21, 1), (365, 400, 5), (3000, 2999, 7), (14600, 14600, 4), (14600, 9000, 3), (5000, 19000, 2)])
+def test_vs_oracle_sizes_and_ties(ctx, T, Tp, C):
+    """Every sort width (1 ... 19 samples per thread), ties in fit and predict series (quantized data: the stable
+    (value, index) order defines the ranks of EquidistantCdfMatcher), values outside the fitted range."""
+    rng = np.random.default_rng(T + Tp)
+    X = np.round(10 + 3 * rng.standard_normal((T, C)), 2)
+    y = np.round(12 + 4 * rng.standard_normal((T, C)), 2) + 20.0
+    Xp = np.round(11 + 4 * rng.standard_normal((Tp, C)), 2) + 20.0 * (np.arange(C) % 2)
+    X = X + 20.0 * (np.arange(C) % 2)
+    st = ctx.qm_fit(X, y)
+    e = st.export()
+    assert np.array_equal(e["x_sorted"], np.sort(X, axis=0).T) and np.array_equal(e["y_sorted"], np.sort(y, axis=0).T)
+    for ex in (None, "1to1"):
+        out, _ = ctx.qm_predict(st, 0, Xp, ex == "1to1")
+        assert_close(out, qo.pointwise_qm("qmr", X, y, Xp, ex), what=f"qmr {ex}")
+        for kind, code in (("difference", 1), ("ratio", 2)):
+            out, _ = ctx.qm_predict(st, code, Xp, ex == "1to1")
+            assert_close(out, qo.pointwise_qm("ecm", X, y, Xp, ex, kind=kind), what=f"ecm {kind} {ex}")
+
+
+def test_masked_and_nonfinite_cells(ctx):
+    rng = np.random.default_rng(2)
+    X, y, Xp = (rng.standard_normal((300, 4)) for _ in range(3))
+    X[0, 1] = np.nan          # masked cell (core.py:35-37)
+    y[17, 2] = np.inf         # non-finite inside an active cell
+    st = ctx.qm_fit(X, y)
+    assert st.export()["status"].tolist() == [0, 1, 2, 0]
+    Xp[5, 3] = np.nan
+    out, status = ctx.qm_predict(st, 0, Xp)
+    assert status.tolist() == [0, 1, 2, 2]
+    assert np.isnan(out[:, 1:]).all() and np.isfinite(out[:, 0]).all()
+
+
+def test_estimators_reference_surface():
+    """test_pointwise_models.py:323-344 (exact), constructor / error behaviour, pickling, PointWiseDownscaler."""
+    import pandas as pd
+
+    from skdownscale_amd import EquidistantCdfMatcher, GridArray, PointWiseDownscaler, QuantileMappingReressor
+
+    x = np.arange(1, 22)
+    for kind, Xt, exp in (("difference", x + 2, x + 3 + 2), ("ratio", x * 2, (x + 3) * 2)):
+        m = EquidistantCdfMatcher(kind=kind).fit(X=pd.DataFrame(x), y=pd.DataFrame(x + 3))
+        assert (m.predict(pd.DataFrame(Xt)).reshape(-1, 1) == exp.reshape(-1, 1)).all()
+        m2 = pickle.loads(pickle.dumps(m))
+        assert np.array_equal(m2.predict(pd.DataFrame(Xt)), m.predict(pd.DataFrame(Xt)))
+    with pytest.raises(ValueError, match="n_endpoints"):
+        QuantileMappingReressor(n_endpoints=1)
+    with pytest.raises(NotImplementedError):
+        EquidistantCdfMatcher(kind="sum")
+    with pytest.raises(NotImplementedError):
+        QuantileMappingReressor(extrapolate="both").fit(np.arange(30.0).reshape(-1, 1), np.arange(30.0))
+    with pytest.raises(ValueError, match="minimum of 21"):
+        QuantileMappingReressor().fit(np.arange(10.0).reshape(-1, 1), np.arange(10.0))
+    rng = np.random.default_rng(4)
+    X, y, Xp = (10 + rng.standard_normal((200, 1)) for _ in range(3))
+    m = QuantileMappingReressor(extrapolate="1to1").fit(X, y[:, 0])
+    assert_close(m.predict(Xp), qo.qmr_predict(qo.qm_fit(X[:, 0], y[:, 0], "1to1"), Xp[:, 0], "1to1"), what="estimator")
+    assert len(m._X_cdf.pp) == 202 and m._X_cdf.vals[0] == X.min()
+    # grid driver: (time, y, x) fields, one masked cell
+    Xg, yg, Xpg = (10 + rng.standard_normal((120, 3, 4)) for _ in range(3))
+    Xg[0, 1, 2] = np.nan
+    pw = PointWiseDownscaler(EquidistantCdfMatcher(kind="difference"))
+    dims = ("time", "y", "x")
+    pw.fit(GridArray(Xg, dims), GridArray(yg, dims))
+    out = pw.predict(GridArray(Xpg, dims))
+    exp = qo.pointwise_qm("ecm", Xg.reshape(120, 12), yg.reshape(120, 12), Xpg.reshape(120, 12)).reshape(120, 3, 4)
+    assert out.dims == dims and np.isnan(out.values[:, 1, 2]).all()
+    assert_close(out.values, exp, what="PointWiseDownscaler ecm")

@@ -124,3 +124,23 @@ def test_analog_regression(F):
     Tr = int(g["Tr"])
     out = ao.pointwise_analog(X, y, Xq[:Tr], 30, None, regression=True)
     assert_close(out, g["out_analogreg_k30"], what="analogreg")
+
+
+def test_quantile_mapping_regressors_match_reference():
+    """QuantileMappingReressor / EquidistantCdfMatcher restatement (oracle/qm_oracle.py) vs g9_qm.npz: every
+    extrapolate mode, n_endpoints 10 / 2, equal / longer / shorter predict series."""
+    import qm_oracle as qo
+
+    g = load("g9_qm")
+    for case in range(3):
+        X, y, Xp = g[f"X{case}"], g[f"y{case}"], g[f"Xp{case}"]
+        for ex in qo.EXTRAPOLATE:
+            for ne in (10, 2):
+                got = qo.pointwise_qm("qmr", X, y, Xp, ex, ne)
+                assert_close(got, g[f"out{case}_qmr_{ex}_{ne}"], what=f"qmr {case} {ex} {ne}")
+                for kind in ("difference", "ratio"):
+                    got = qo.pointwise_qm("ecm", X, y, Xp, ex, ne, kind)
+                    assert_close(got, g[f"out{case}_ecm_{kind}_{ex}_{ne}"], what=f"ecm {kind} {case} {ex} {ne}")
+    x = np.arange(1, 22.0)  # the reference's test_EquidistantCdfMatcher: exact
+    assert np.array_equal(qo.ecm_predict(qo.qm_fit(x, x + 3), x + 2, "difference"), g["reftest_difference"])
+    assert np.array_equal(qo.ecm_predict(qo.qm_fit(x, x + 3), x * 2, "ratio"), g["reftest_ratio"])
