@@ -125,3 +125,34 @@ def test_sharded_gather_world_size_2_gloo(tmp_path):
                           "--master-port", "29617", str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "GATHER_OK" in res.stdout
+
+
+def test_quantile_mapping_estimators_argument_checks():
+    """Constructor / argument behaviour of the quantile-mapping regressors that needs no GPU (quantile.py:181-190, 576-593)."""
+    from skdownscale_amd import EquidistantCdfMatcher, QuantileMappingReressor
+    from skdownscale_amd.quantile import check_extrapolate, plotting_positions
+
+    with pytest.raises(ValueError, match="n_endpoints"):
+        QuantileMappingReressor(n_endpoints=1)
+    with pytest.raises(ValueError, match="n_endpoints"):
+        EquidistantCdfMatcher(n_endpoints=0)
+    with pytest.raises(NotImplementedError, match="difference or ratio"):
+        EquidistantCdfMatcher(kind="sum")
+    for ex in ("min", "max", "both"):
+        with pytest.raises(NotImplementedError, match="ill-conditioned"):
+            check_extrapolate(ex)
+        with pytest.raises(NotImplementedError):
+            QuantileMappingReressor(extrapolate=ex).fit(np.arange(30.0).reshape(-1, 1), np.arange(30.0))
+    with pytest.raises(ValueError, match="unknown value for extrapolate"):
+        check_extrapolate("sideways")
+    with pytest.raises(ValueError, match="minimum of 21"):
+        QuantileMappingReressor().fit(np.arange(10.0).reshape(-1, 1), np.arange(10.0))
+    with pytest.raises(ValueError, match="maximum of 1"):
+        QuantileMappingReressor().fit(np.zeros((30, 2)), np.arange(30.0))
+    with pytest.raises(NotImplementedError, match="max_ratio"):
+        EquidistantCdfMatcher(kind="ratio", max_ratio=5.0)._engine_code()
+    from sklearn.base import clone
+
+    m = clone(EquidistantCdfMatcher(kind="ratio", extrapolate="1to1", n_endpoints=4))
+    assert (m.kind, m.extrapolate, m.n_endpoints, m.max_ratio) == ("ratio", "1to1", 4, None)
+    assert np.allclose(plotting_positions(3), (np.arange(1, 4) - 0.4) / 3.2)

@@ -22,7 +22,7 @@ from skdownscale_amd.engine import Context  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["bcsd_pr", "analog", "analogreg"], default="analog")
+    ap.add_argument("--workload", choices=["bcsd_pr", "analog", "analogreg", "qmr", "ecm"], default="analog")
     ap.add_argument("--cells", type=int, default=8192)
     ap.add_argument("--times", type=int, default=14600)
     ap.add_argument("--steps", type=int, default=2)
@@ -48,6 +48,18 @@ def main():
         step = lambda: ctx.bcsd_fit_predict(_lib.BCSD_PR, f["X_hist"], f["y_obs"], gid, 12, f["X_fut"], gid, True, out=out)  # noqa: E731
         bytes_per_cell = 8 * (T + 2 * T)  # y_obs, X_fut, out (X_hist is only validated: + 8*T actually read)
         name = f"BcsdPrecipitation zero-inflated, {C} cells x {T} steps"
+    elif args.workload in ("qmr", "ecm"):
+        f = {n: field(synth.GAUSS, s0, amp=a) for n, s0, a in (("X", 30, 3.0), ("y", 31, 4.0), ("Xp", 32, 3.5))}
+        out = ctx.empty((T, C))
+        code = 0 if args.workload == "qmr" else 1
+
+        def step():
+            st = ctx.qm_fit(f["X"], f["y"])
+            r = ctx.qm_predict(st, code, f["Xp"], out=out)
+            st.close()
+            return r
+        bytes_per_cell = 8 * (2 * T + 2 * T)  # X, y, Xp read, out written
+        name = f"{'QuantileMappingReressor' if code == 0 else 'EquidistantCdfMatcher difference'} (whole series), {C} cells x {T} steps"
     else:
         F = args.features
         y = field(synth.GAUSS, 20, amp=2.0, stream2=21, amp2=1.0)
