@@ -323,6 +323,41 @@ class PointWiseDownscaler:
         return GridArray(y.reshape((T, n_outputs) + tuple(spatial_shape)), (self._dim, feature_dim) + spatial_dims, coords)
 
     # ------------------------------------------------------------------------------------------
+    def transform(self, X, **kwargs):
+        """Apply the fitted per-cell transformers (core.py:340-371)."""
+        return self._transform(X, "transform", kwargs)
+
+    def inverse_transform(self, X, **kwargs):
+        """Apply the inverse of the fitted per-cell transformers (core.py:373-403)."""
+        return self._transform(X, "inverse_transform", kwargs)
+
+    def _transform(self, X, direction, kwargs):
+        """core.py:146-171 (``_transform_wrapper``): same dims / shape as the feature-normalised X, masked cells NaN."""
+        if self._models is None:
+            raise ValueError("PointWiseDownscaler is not fitted: call fit() first")
+        if self._models.kind != "loop":
+            raise AttributeError(f"{type(self._model).__name__} has no {direction}()")
+        kws = {"feature_dim": DEFAULT_FEATURE_DIM} | kwargs
+        feature_dim = kws.pop("feature_dim")
+        Xg, was_x = self._to_feature_x(X, feature_dim)
+        T, F = Xg.shape[:2]
+        spatial_shape = Xg.shape[2:]
+        C = int(np.prod(spatial_shape, dtype=np.int64)) if spatial_shape else 1
+        if tuple(spatial_shape) != tuple(self._models.spatial_shape):
+            raise ValueError(f"spatial shape {spatial_shape} does not match the fitted grid {self._models.spatial_shape}")
+        Xv = np.asarray(Xg.values).reshape(T, F, C)
+        index = _time_index(Xg, self._dim)
+        columns = list(Xg.coords.get(feature_dim, [f"feature{i}" for i in range(F)]))
+        out = np.full((T, F, C), np.nan, dtype=Xg.dtype)
+        for c in range(C):
+            model = self._models.grid_model[c]
+            if model is None:
+                continue
+            res = getattr(model, direction)(_da_to_df(Xv[:, :, c], index, columns), **kws)
+            out[:, :, c] = np.asarray(res).reshape(T, F)
+        return _from_grid(GridArray(out.reshape(Xg.shape), Xg.dims, dict(Xg.coords)), was_x)
+
+    # ------------------------------------------------------------------------------------------
     def get_attr(self, key, dtype=np.float64, template_output=None):
         """Fitted attribute of every cell (core.py:405-425).  Batched BCSD grids serve ``y_climo_`` /
         ``_x_climo`` as [group, *spatial] fields straight from the engine state."""

@@ -156,3 +156,27 @@ def test_quantile_mapping_estimators_argument_checks():
     m = clone(EquidistantCdfMatcher(kind="ratio", extrapolate="1to1", n_endpoints=4))
     assert (m.kind, m.extrapolate, m.n_endpoints, m.max_ratio) == ("ratio", "1to1", 4, None)
     assert np.allclose(plotting_positions(3), (np.arange(1, 4) - 0.4) / 3.2)
+
+
+def test_pointwise_transform_and_inverse_transform_loop():
+    """core.py:340-403 / 146-171: per-cell transformers through the generic loop (no engine involved)."""
+    from sklearn.preprocessing import StandardScaler
+
+    from skdownscale_amd import GridArray, PointWiseDownscaler
+
+    rng = np.random.default_rng(0)
+    X = 5 + 2 * rng.standard_normal((50, 2, 3))
+    X[0, 1, 1] = np.nan  # masked cell (core.py:35-37)
+    pw = PointWiseDownscaler(StandardScaler())
+    pw.fit(GridArray(X, ("time", "y", "x")))
+    out = pw.transform(GridArray(X, ("time", "y", "x")))
+    assert out.dims == ("time", "variable", "y", "x") and out.shape == (50, 1, 2, 3)
+    v = out.values[:, 0]
+    assert np.isnan(v[:, 1, 1]).all()
+    ok = np.ones((2, 3), bool)
+    ok[1, 1] = False
+    assert np.allclose(v[:, ok].mean(axis=0), 0.0, atol=1e-12) and np.allclose(v[:, ok].std(axis=0), 1.0)
+    back = pw.inverse_transform(out)
+    assert np.allclose(back.values[:, 0][:, ok], X[:, ok])
+    with pytest.raises(ValueError, match="not fitted"):
+        PointWiseDownscaler(StandardScaler()).transform(GridArray(X, ("time", "y", "x")))
