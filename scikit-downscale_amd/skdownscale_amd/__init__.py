@@ -7,7 +7,7 @@ from .bcsd import BcsdGridModel, BcsdPrecipitation, BcsdTemperature
 from .core import GridArray, GridDataset, PointWiseDownscaler
 from .gard import AnalogGridModel, AnalogRegression, PureAnalog
 from .groupers import DAY_GROUPER, MONTH_GROUPER
-from .quantile import EquidistantCdfMatcher, QmGridModel, QuantileMappingReressor
+from .quantile import EquidistantCdfMatcher, QmGridModel, QuantileMapper, QuantileMappingReressor
 
 __all__ = [
     "AnalogRegression",
@@ -22,6 +22,7 @@ __all__ = [
     "BcsdGridModel",
     "AnalogGridModel",
     "QuantileMappingReressor",
+    "QuantileMapper",
     "EquidistantCdfMatcher",
     "QmGridModel",
 ]

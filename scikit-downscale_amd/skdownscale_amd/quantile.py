@@ -11,7 +11,7 @@ from __future__ import annotations
 import collections
 
 import numpy as np
-from sklearn.base import BaseEstimator, RegressorMixin
+from sklearn.base import BaseEstimator, RegressorMixin, TransformerMixin
 from sklearn.exceptions import NotFittedError
 from sklearn.utils import check_array
 
@@ -42,6 +42,65 @@ def check_extrapolate(extrapolate):
         raise NotImplementedError(
             f"extrapolate={extrapolate!r}: interpolation across the synthetic +-1e20 end points is ill-conditioned in the "
             "reference itself; only extrapolate=None and '1to1' run on the HIP engine")
+
+
+FittedCunnane = collections.namedtuple("FittedCunnane", ["cdf_"])
+
+
+class QuantileMapper(TransformerMixin, BaseEstimator):
+    """Transform features using quantile mapping (quantile.py:46-157), ``detrend=False`` and default ``qt_kwargs``:
+    ``transform(X)`` ranks X within itself (Cunnane plotting positions of its own sorted values, np.interp exact-hit
+    rule) and maps the positions through the CDF of the data seen in ``fit`` (10-point OLS tails when X is longer).
+    This is the mapping BCSD applies per month (bcsd.py:59-79); here the whole series is one group."""
+
+    _fit_attributes = ["x_cdf_fit_"]
+
+    def __init__(self, detrend=False, lt_kwargs=None, qt_kwargs=None):
+        self.detrend = detrend
+        self.lt_kwargs = lt_kwargs
+        self.qt_kwargs = qt_kwargs
+
+    def _check(self):
+        if self.detrend:
+            raise NotImplementedError("QuantileMapper(detrend=True) is not supported on the HIP engine")
+        if self.qt_kwargs:
+            raise NotImplementedError("QuantileMapper(qt_kwargs=...): only the CunnaneTransformer defaults run on the HIP engine")
+
+    def fit(self, X, y=None):
+        self._check()
+        X = check_array(X, dtype="numeric", ensure_2d=True)
+        X = check_max_features(X, n=1)
+        Xv = np.asarray(X, dtype=np.float64).reshape(-1, 1)
+        ctx = default_context()
+        self._state = ctx.bcsd_fit(_lib.BCSD_PR, None, Xv, np.zeros(len(Xv), dtype=np.int32), 1, False)
+        vals = self._state.export()["y_sorted"][0]
+        self.x_cdf_fit_ = FittedCunnane(Cdf(plotting_positions(len(vals)), vals))
+        self.n_features_in_ = 1
+        return self
+
+    def transform(self, X):
+        if not hasattr(self, "x_cdf_fit_"):
+            raise NotFittedError(
+                f"This {type(self).__name__} instance is not fitted yet. Call 'fit' with appropriate arguments before using this estimator.")
+        X = check_array(X, dtype="numeric", ensure_2d=True)
+        Xv = np.asarray(X, dtype=np.float64)[:, :1]
+        ctx = default_context()
+        if getattr(self, "_state", None) is None:  # unpickled: rebuild the device state from the fitted CDF
+            n = len(self.x_cdf_fit_.cdf_.vals)
+            self._state = ctx.bcsd_fit(_lib.BCSD_PR, None, self.x_cdf_fit_.cdf_.vals.reshape(n, 1), np.zeros(n, dtype=np.int32), 1, False)
+        out, _ = ctx.bcsd_predict(self._state, np.ascontiguousarray(Xv), np.zeros(len(Xv), dtype=np.int32))
+        return out
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_state", None)
+        return d
+
+    def __sklearn_tags__(self):
+        from dataclasses import replace
+
+        tags = super().__sklearn_tags__()
+        return replace(tags, _skip_test="QuantileMapper only supports 1 feature and has temporal dependencies")
 
 
 class QmGridModel:

@@ -103,3 +103,35 @@ def test_estimators_reference_surface():
     exp = qo.pointwise_qm("ecm", Xg.reshape(120, 12), yg.reshape(120, 12), Xpg.reshape(120, 12)).reshape(120, 3, 4)
     assert out.dims == dims and np.isnan(out.values[:, 1, 2]).all()
     assert_close(out.values, exp, what="PointWiseDownscaler ecm")
+
+
+def test_quantile_mapper_transformer():
+    """The reference's only numeric test of this path (test_pointwise_models.py:81-90) and its golden output; longer /
+    shorter series than the fitted one (tail OLS and table paths) vs the BCSD oracle's mapping; series beyond the
+    register-sort limit; pickling; use inside PointWiseDownscaler.transform."""
+    import bcsd_oracle as bo
+    from skdownscale_amd import GridArray, PointWiseDownscaler, QuantileMapper
+
+    n = 100
+    expected = (np.sin(np.linspace(-10 * np.pi, 10 * np.pi, n)) * 10).reshape(-1, 1)
+    mapper = QuantileMapper().fit(expected)
+    actual = mapper.transform(expected + 2)
+    np.testing.assert_almost_equal(actual, expected)
+    g = load("g8_reference_tests")
+    assert_close(actual, g["qm_actual"], what="test_quantile_mapper golden")
+    assert np.array_equal(mapper.x_cdf_fit_.cdf_.vals, np.sort(expected[:, 0]))
+    rng = np.random.default_rng(8)
+    for nfit, npred in ((500, 500), (500, 800), (800, 300), (3000, 3000)):
+        a, b = rng.standard_normal((nfit, 1)), 0.5 + 1.5 * rng.standard_normal((npred, 1))
+        m = QuantileMapper().fit(a)
+        exp, _ = bo.pointwise_fit_predict(bo.PR, None, a, b, np.zeros(nfit, np.int32), np.zeros(npred, np.int32), G=1,
+                                          return_anoms=False)
+        assert_close(m.transform(b), exp, what=f"quantile mapper {nfit}->{npred}")
+        assert np.array_equal(pickle.loads(pickle.dumps(m)).transform(b), m.transform(b))
+    with pytest.raises(NotImplementedError):
+        QuantileMapper(detrend=True).fit(expected)
+    X = rng.standard_normal((200, 2, 2))
+    pw = PointWiseDownscaler(QuantileMapper())
+    pw.fit(GridArray(X, ("time", "y", "x")))
+    out = pw.transform(GridArray(X + 1.0, ("time", "y", "x")))
+    assert_close(out.values[:, 0], X, what="pointwise quantile mapper")  # the bias is removed
