@@ -53,14 +53,17 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(index, seed, c_full, target_seconds):
-    """The plain-C restatement (oracle/sd_oracle.c, 'port') timed on this host's cores, bounded sample."""
+def cpu_baseline(index, seed, c_full, target_seconds, check=None):
+    """The plain-C restatement (oracle/sd_oracle.c, 'port') timed on this host's cores, bounded sample.
+
+    The first (small) oracle run doubles as the checker of the engine's output: ``check(exp)`` receives the oracle's
+    result for the first cells and returns a parity verdict (outside the timed region)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
     from skdownscale_amd import synth
 
     if not c_oracle.available():
-        return None
+        return None, None
     threads = min(c_oracle.max_threads(), os.cpu_count() or 1)
     gid = (np.asarray(index.month) - 1).astype(np.int32)
 
@@ -74,12 +77,13 @@ def cpu_baseline(index, seed, c_full, target_seconds):
         return time.perf_counter() - t0, out
 
     n0 = 4 * threads
-    dt, _ = run(n0)
+    dt, exp = run(n0)
+    parity = check(exp) if check is not None else None
     rate = n0 / dt
     n = int(max(n0, min(rate * target_seconds, 8192)))
     dt, _ = run(n)
     return {"value": n / dt, "unit": "cells/s", "cores": threads, "kind": "port",
-            "sample": f"{n} cells x {len(index)} steps, oracle/sd_oracle.c (OpenMP, {threads} threads), {dt:.1f} s"}
+            "sample": f"{n} cells x {len(index)} steps, oracle/sd_oracle.c (OpenMP, {threads} threads), {dt:.1f} s"}, parity
 
 
 def main():
@@ -171,29 +175,28 @@ def main():
         except Exception as e:  # noqa: BLE001  (never lose the throughput line over the side measurement)
             gather_ms = f"failed: {e}"
 
-    # ---- parity spot check outside the timed region (first cells of this rank vs the C oracle) ----
+    # ---- parity spot check: part of the cpu_baseline leg (the oracle's first run is compared with the engine's
+    # output for the same cells, outside the timed region) ----
+    def check_parity(exp):
+        import ctypes as Cc
+
+        n = min(args.check_cells, C, exp.shape[1])
+        if n <= 0 or c_off != 0:
+            return None
+        rows = np.unique(np.linspace(0, T - 1, 96).astype(np.int64))  # 96 sampled rows x n cells
+        got = np.empty((len(rows), n))
+        for i, t in enumerate(rows):
+            ctx.lib.sd_memcpy_d2h(ctx.handle, got[i].ctypes.data_as(Cc.c_void_p), Cc.c_void_p(out.ptr + int(t) * C * 8), n * 8)
+        ref = exp[rows][:, :n]
+        err = np.abs(got - ref)
+        tol = 1e-6 * np.std(exp) + 1e-6 * np.abs(ref)
+        return "ok" if bool((err <= tol).all()) and bool((status[:n] == 0).all()) else f"FAILED max_err={err.max():.3e}"
+
     parity = None
-    if rank == 0 and args.check_cells > 0:
+    baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import c_oracle
-
-            n = min(args.check_cells, C)
-            cells = np.arange(c_off, c_off + n)
-            Xh = synth.tas_field("X_hist", args.seed, index, cells, c_full)
-            yh = synth.tas_field("y_obs", args.seed, index, cells, c_full)
-            Xf = synth.tas_field("X_fut", args.seed, index, cells, c_full)
-            exp, _ = c_oracle.bcsd_fit_predict(0, Xh, yh, Xf, gid, gid, nthreads=os.cpu_count() or 1)
-            import ctypes as Cc
-
-            rows = np.unique(np.linspace(0, T - 1, 96).astype(np.int64))  # 96 sampled rows x n cells
-            got = np.empty((len(rows), n))
-            for i, t in enumerate(rows):
-                ctx.lib.sd_memcpy_d2h(ctx.handle, got[i].ctypes.data_as(Cc.c_void_p), Cc.c_void_p(out.ptr + int(t) * C * 8), n * 8)
-            ref = exp[rows]
-            err = np.abs(got - ref)
-            tol = 1e-6 * np.std(exp) + 1e-6 * np.abs(ref)
-            parity = "ok" if bool((err <= tol).all()) and bool((status[:n] == 0).all()) else f"FAILED max_err={err.max():.3e}"
+            baseline, parity = cpu_baseline(index, args.seed, c_full, args.cpu_baseline_seconds, check_parity)
         except Exception as e:  # noqa: BLE001
             parity = f"not run: {e}"
 
@@ -235,8 +238,8 @@ def main():
         "roofline": roofline,
         "parity_check": parity,
     }
-    if not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(index, args.seed, c_full, args.cpu_baseline_seconds)
+    if baseline is not None:  # rank 0 at N = 1 only
+        line["cpu_baseline"] = baseline
     print(json.dumps(line), flush=True)
 
 
