@@ -153,12 +153,14 @@ __global__ void __launch_bounds__(1024) analog_sort_kernel(const double* __restr
 template <int K>
 __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __restrict__ Xc, const double* __restrict__ yc,
                                                             int64_t T, int64_t C, double* __restrict__ xs,
-                                                            int32_t* __restrict__ xi, double* __restrict__ yx) {
+                                                            int32_t* __restrict__ xi, double* __restrict__ yx,
+                                                            double* __restrict__ pq_all, double* __restrict__ ybar_all) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x;
+    const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int np = (n + K - 1) / K * K;
     double* buf = reinterpret_cast<double*>(smem_raw);     // np + 1 doubles
-    int* xch = reinterpret_cast<int*>(buf + np + 1);        // nthr + 1 ints
+    int* xch = reinterpret_cast<int*>(buf + np + 1);        // nthr + 1 ints (also 3 x 16 doubles of reduction scratch)
+    double* red = reinterpret_cast<double*>(xch);
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         const double* x = Xc + c * T;
@@ -204,15 +206,7 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
         __syncthreads();
         const double* yy = yc + c * T;
         if (!ties) {
-            // distinct values: lb is the sorted position itself -> scatter y and the index through LDS
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const int j = K * tid + i;
-                if (j < n) buf[lb[i]] = yy[j];
-            }
-            __syncthreads();
-            for (int i = tid; i < n; i += nthr) yx[c * T + i] = buf[i];
-            __syncthreads();
+            // distinct values: lb is the sorted position itself -> scatter the index, then y, through LDS
             int* ibuf = reinterpret_cast<int*>(buf);
 #pragma unroll
             for (int i = 0; i < K; ++i) {
@@ -221,21 +215,96 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
             }
             __syncthreads();
             for (int i = tid; i < n; i += nthr) xi[c * T + i] = ibuf[i];
-            continue;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = K * tid + i;
+                if (j < n) buf[lb[i]] = yy[j];
+            }
+        } else {
+            double key2[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = K * tid + i;
+                key2[i] = j < n ? (double)lb[i] * 65536.0 + (double)j : inf;
+            }
+            sdsort::block_merge_sort<K>(key2, buf, np, xch, tid, nthr);
+            double ya[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = tid + i * nthr;  // coalesced positions
+                ya[i] = 0.0;
+                if (j < n) {
+                    const int idx = (int)((unsigned)buf[j] & 0xffffu);
+                    xi[c * T + j] = idx;
+                    ya[i] = yy[idx];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = tid + i * nthr;
+                if (j < n) buf[j] = ya[i];
+            }
         }
-        double key2[K];
+        __syncthreads();
+        // buf[0..n) = y in sorted-x order: write it and its centred exclusive prefix sums (see analog_prefix_kernel)
+        for (int i = tid; i < n; i += nthr) yx[c * T + i] = buf[i];
+        double yv[K];
+        double s = 0.0;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             const int j = K * tid + i;
-            key2[i] = j < n ? (double)lb[i] * 65536.0 + (double)j : inf;
+            yv[i] = j < n ? buf[j] : 0.0;
+            s += yv[i];
         }
-        sdsort::block_merge_sort<K>(key2, buf, np, xch, tid, nthr);
-        for (int i = tid; i < n; i += nthr) {
-            const unsigned kk = (unsigned)buf[i];
-            const int idx = (int)(kk & 0xffffu);
-            xi[c * T + i] = idx;
-            yx[c * T + i] = yy[idx];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        __syncthreads();  // (xch is free again)
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += red[w];
+        const double ybar = tot / (double)n;
+        if (tid == 0) ybar_all[c] = ybar;
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int j = K * tid + i;
+            const double d = j < n ? yv[i] - ybar : 0.0;
+            yv[i] = d;
+            a += d;
+            b += d * d;
         }
+        double ia = a, ib = b;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
+            if (lane >= o) {
+                ia += ta;
+                ib += tb;
+            }
+        }
+        __syncthreads();
+        if (lane == 63) {
+            red[16 + wave] = ia;
+            red[32 + wave] = ib;
+        }
+        __syncthreads();
+        double ra = ia - a, rb = ib - b;  // exclusive prefix at this thread's first element
+        for (int w = 0; w < wave; ++w) {
+            ra += red[16 + w];
+            rb += red[32 + w];
+        }
+        double2* pq = reinterpret_cast<double2*>(pq_all) + c * (T + 1);
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int j = K * tid + i;
+            if (j <= n) pq[j] = make_double2(ra, rb);
+            ra += yv[i];
+            rb += yv[i] * yv[i];
+        }
+        if (K * tid + K == n) pq[n] = make_double2(ra, rb);  // n = 1024 * K: no thread starts at position n
     }
 }
 
@@ -247,7 +316,7 @@ int launch_sort2(sd_ctx* ctx, sd_analog_state* st) {
                                (int)lds));
     const int nb = (int)std::min<int64_t>(st->C, (int64_t)ctx->cu_count * 4);
     SD_LAUNCH(ctx, "analog_sort2_kernel", analog_sort2_kernel<K>, dim3(nb), dim3(1024), lds, (const double*)st->X,
-              (const double*)st->y, st->T, st->C, st->xs, st->xi, st->yx);
+              (const double*)st->y, st->T, st->C, st->xs, st->xi, st->yx, st->pq, st->ybar);
     return SD_OK;
 }
 
@@ -259,6 +328,70 @@ int sort2_width(int64_t T, size_t lds_max) {
         if (T <= (int64_t)1024 * K && T <= 65535 && sizeof(double) * (size_t)(np + 1) + sizeof(int) * 1025 <= lds_max) return K;
     }
     return 0;
+}
+
+// F == 1: exclusive prefix sums of the centred analog values in sorted-x order, pq[c][i] = (sum_{j<i} d_j,
+// sum_{j<i} d_j^2) with d = yx - mean(y).  The mean and standard deviation of any window of k consecutive analogs
+// then cost two 16-byte loads (centring keeps the running sums small: no cancellation for the differences).
+// One 1024-thread workgroup per cell: serial partial sums per thread, wave shuffles + LDS for the offsets.
+__global__ void __launch_bounds__(1024) analog_prefix_kernel(const double* __restrict__ yx_all, int64_t T, int64_t C,
+                                                             double* __restrict__ pq_all, double* __restrict__ ybar_all) {
+    __shared__ double wsum[2][16];
+    const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + nthr - 1) / nthr;  // consecutive elements per thread
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const double* yx = yx_all + c * T;
+        double2* pq = reinterpret_cast<double2*>(pq_all) + c * (T + 1);
+        const int beg = tid * per < n ? tid * per : n, end = beg + per < n ? beg + per : n;
+        // mean of y
+        double s = 0.0;
+        for (int i = beg; i < end; ++i) s += yx[i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        __syncthreads();
+        if (lane == 0) wsum[0][wave] = s;
+        __syncthreads();
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += wsum[0][w];
+        const double ybar = tot / (double)n;
+        if (tid == 0) ybar_all[c] = ybar;
+        // per-thread totals of d and d^2, exclusive scan across the workgroup
+        double a = 0.0, b = 0.0;
+        for (int i = beg; i < end; ++i) {
+            const double d = yx[i] - ybar;
+            a += d;
+            b += d * d;
+        }
+        double ia = a, ib = b;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
+            if (lane >= o) {
+                ia += ta;
+                ib += tb;
+            }
+        }
+        __syncthreads();
+        if (lane == 63) {
+            wsum[0][wave] = ia;
+            wsum[1][wave] = ib;
+        }
+        __syncthreads();
+        double oa = 0.0, ob = 0.0;
+        for (int w = 0; w < wave; ++w) {
+            oa += wsum[0][w];
+            ob += wsum[1][w];
+        }
+        double ra = oa + (ia - a), rb = ob + (ib - b);  // exclusive prefix at this thread's first element
+        for (int i = beg; i < end; ++i) {
+            pq[i] = make_double2(ra, rb);
+            const double d = yx[i] - ybar;
+            ra += d;
+            rb += d * d;
+        }
+        if (end == n && beg < n) pq[n] = make_double2(ra, rb);
+        if (n == 0 && tid == 0) pq[0] = make_double2(0.0, 0.0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -799,6 +932,96 @@ __global__ void __launch_bounds__(1024) analog_f1_window_kernel(int mode, const 
     }
 }
 
+// F == 1, PureAnalog 'mean_analogs' without a threshold: the window statistics come from the prefix sums pq
+// (analog_prefix_kernel), so only the sorted training values have to be LDS-resident: a single pass over the
+// queries, the window search plus two 16-byte loads per query.  Tie handling as in analog_f1_window_kernel.
+__global__ void __launch_bounds__(1024) analog_f1_mean_kernel(const double* __restrict__ Xq /* [C][Tq] */, int64_t Tq, int64_t T,
+                                                              int64_t C, const double* __restrict__ xs_all,
+                                                              const int32_t* __restrict__ xi_all,
+                                                              const double* __restrict__ pq_all,
+                                                              const double* __restrict__ ybar_all, const double* __restrict__ Xc,
+                                                              const double* __restrict__ yc,
+                                                              const int32_t* __restrict__ fit_status, int32_t* status,
+                                                              double* scratch_d, int32_t* scratch_i, PredictArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* xs = reinterpret_cast<double*>(smem_raw);  // n sorted values + one +inf sentinel
+    const int nthr = blockDim.x, tid = threadIdx.x;
+    const int n = (int)T, k = pa.k;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double* sd = scratch_d + (int64_t)blockIdx.x * k * nthr;
+    int32_t* si = scratch_i + (int64_t)blockIdx.x * k * nthr;
+    int nsteps = 0;
+    while ((1 << nsteps) < n - k + 1) ++nsteps;
+    const double kk = (double)k;
+    int64_t step, end;
+    for (int64_t c = first_cell(C, &step, &end); c < end; c += step) {
+        const bool active = fit_status[c] == 0;
+        const double* xg = xs_all + c * T;
+        const double2* pq = reinterpret_cast<const double2*>(pq_all) + c * (T + 1);
+        const double ybar = ybar_all[c];
+        __syncthreads();
+        if (active)
+            for (int i = tid; i < n; i += nthr) xs[i] = xg[i];
+        if (tid == 0) xs[n] = inf;
+        __syncthreads();
+        for (int64_t tq0 = tid; tq0 < Tq; tq0 += (int64_t)nthr * kWinQ) {
+            double q[kWinQ];
+            bool has[kWinQ], ok[kWinQ];
+#pragma unroll
+            for (int j = 0; j < kWinQ; ++j) {
+                const int64_t tq = tq0 + (int64_t)j * nthr;
+                has[j] = tq < Tq;
+                q[j] = has[j] ? Xq[c * Tq + tq] : 0.0;
+                ok[j] = active && has[j] && sd_finite(q[j]);
+                if (active && has[j] && !ok[j]) atomicOr(&status[c], SDI_NONFINITE);
+                if (!ok[j]) q[j] = 0.0;
+            }
+            int lo[kWinQ], hi[kWinQ];
+#pragma unroll
+            for (int j = 0; j < kWinQ; ++j) {
+                lo[j] = 0;
+                hi[j] = n - k;
+            }
+#pragma unroll 1
+            for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+                for (int j = 0; j < kWinQ; ++j) {
+                    const int mid = (lo[j] + hi[j]) >> 1;
+                    const bool act = lo[j] < hi[j];
+                    const bool right = sq_dist(q[j], xs[mid]) > sq_dist(q[j], xs[mid + k]);
+                    lo[j] = (act && right) ? mid + 1 : lo[j];
+                    hi[j] = (act && !right) ? mid : hi[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kWinQ; ++j) {
+                if (!has[j]) continue;
+                const int64_t tq = tq0 + (int64_t)j * nthr;
+                double pred = nan, prob = nan, err = nan;
+                if (ok[j]) {
+                    const int L = lo[j];
+                    const double dL = sq_dist(q[j], xs[L]), dR = sq_dist(q[j], xs[L + k - 1]);
+                    const double worst = dL > dR ? dL : dR;
+                    const bool sep_l = L == 0 || sq_dist(q[j], xs[L - 1]) > worst;
+                    const bool sep_r = L + k == n || sq_dist(q[j], xs[L + k]) > worst;
+                    if (!(sep_l && sep_r)) {
+                        f1_walk_query(0, pa, n, T, c, tq, q[j], xg, xi_all + c * T, Xc + c * T, yc + c * T, sd, si, nthr);
+                        continue;
+                    }
+                    const double2 a = pq[L], b = pq[L + k];
+                    const double m1 = (b.x - a.x) / kk;           // mean of the centred analogs
+                    const double var = (b.y - a.y) / kk - m1 * m1;
+                    pred = ybar + m1;                            // gard.py:329-333
+                    prob = 1.0;                                  // gard.py:346
+                    err = sqrt(var > 0.0 ? var : 0.0);           // ddof = 0 (gard.py:345)
+                }
+                put_out(pa, tq, c, pred, prob, err);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // general F predict: brute force, training rows staged through LDS, per-thread top-k in scratch
 // ------------------------------------------------------------------------------------------------
@@ -1132,6 +1355,13 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
         SD_HIP(oc.alloc(ctx, sizeof(double) * (size_t)Tq * 3 * cc_max));
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_window_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // mean_analogs without a threshold: statistics from the prefix sums, one pass with only xs in LDS
+        const size_t lds_mean = sizeof(double) * (size_t)(T + 1);
+        const bool mean_only = mode == 0 && kind == SD_ANALOG_MEAN && !has_thresh && st->pq != nullptr && lds_mean <= ctx->lds_max &&
+                               getenv("SD_ANALOG_NOPREFIX") == nullptr;
+        if (mean_only)
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean));
         for (int64_t cb = 0; cb < C; cb += chunk) {
             const int64_t cc = C - cb < chunk ? C - cb : chunk;
             dim3 tgrid((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32));
@@ -1142,10 +1372,18 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
             pw.oc_Tq = Tq;
             int nbc = nb;
             if ((int64_t)nbc > ((cc + 7) / 8) * 8) nbc = (int)(((cc + 7) / 8) * 8);
-            SD_LAUNCH(ctx, "analog_f1_window_kernel", analog_f1_window_kernel, dim3(nbc), dim3(nthr), lds, mode,
-                      (const double*)qc.p, Tq, Tq, T, cc, npass, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
-                      (const double*)st->yx + cb * T, (const double*)st->X + cb * T, (const double*)st->y + cb * T,
-                      (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb, sc_d.as<double>(), sc_i.as<int32_t>(), pw);
+            if (mean_only) {
+                SD_LAUNCH(ctx, "analog_f1_mean_kernel", analog_f1_mean_kernel, dim3(nbc), dim3(nthr), lds_mean, (const double*)qc.p,
+                          Tq, T, cc, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
+                          (const double*)st->pq + 2 * cb * (T + 1), (const double*)st->ybar + cb, (const double*)st->X + cb * T,
+                          (const double*)st->y + cb * T, (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb,
+                          sc_d.as<double>(), sc_i.as<int32_t>(), pw);
+            } else {
+                SD_LAUNCH(ctx, "analog_f1_window_kernel", analog_f1_window_kernel, dim3(nbc), dim3(nthr), lds, mode,
+                          (const double*)qc.p, Tq, Tq, T, cc, npass, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
+                          (const double*)st->yx + cb * T, (const double*)st->X + cb * T, (const double*)st->y + cb * T,
+                          (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb, sc_d.as<double>(), sc_i.as<int32_t>(), pw);
+            }
             SD_LAUNCH(ctx, "analog_untranspose_kernel", analog_untranspose_kernel,
                       dim3((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32), 3), dim3(256), 0, (const double*)oc.p, Tq, cc,
                       out + cb, ld_out);
@@ -1231,6 +1469,8 @@ int sd_analog_state_destroy(sd_analog_state* st) {
     sd_pool_release(st->ctx, st->xs);
     sd_pool_release(st->ctx, st->xi);
     sd_pool_release(st->ctx, st->yx);
+    sd_pool_release(st->ctx, st->pq);
+    sd_pool_release(st->ctx, st->ybar);
     delete st;
     return SD_OK;
 }
@@ -1273,6 +1513,8 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->xs, sizeof(double) * (size_t)T * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->xi, sizeof(int32_t) * (size_t)T * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->yx, sizeof(double) * (size_t)T * C));
+            SD_HIP(sd_pool_malloc(ctx, (void**)&st->pq, sizeof(double) * 2 * (size_t)(T + 1) * C));
+            SD_HIP(sd_pool_malloc(ctx, (void**)&st->ybar, sizeof(double) * C));
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const int K2 = getenv("SD_ANALOG_SORT1") ? 0 : sort2_width(T, ctx->lds_max);
@@ -1288,6 +1530,11 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
                     SD_LAUNCH(ctx, "analog_sort_kernel", analog_sort_kernel, dim3(nb), dim3(1024), lds, (const double*)st->X,
                               (const double*)st->y, T, C, st->xs, st->xi, st->yx);
                 }
+            }
+            if (K2 == 0) {  // (the fast sort writes the prefix sums itself)
+                const int nbp = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 2);
+                SD_LAUNCH(ctx, "analog_prefix_kernel", analog_prefix_kernel, dim3(nbp), dim3(1024), 0, (const double*)st->yx, T, C,
+                          st->pq, st->ybar);
             }
             SD_HIP(hipStreamSynchronize(ctx->stream));
         }
