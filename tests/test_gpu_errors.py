@@ -1,0 +1,86 @@
+"""GPU: error behaviour of the C ABI (argument checks, limits) as seen through the ctypes layer."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from skdownscale_amd.engine import default_context
+
+    return default_context()
+
+
+def test_bcsd_argument_errors(ctx):
+    rng = np.random.default_rng(0)
+    X, y = rng.standard_normal((100, 3)), rng.standard_normal((100, 3))
+    gid = (np.arange(100) % 12).astype(np.int32)
+    with pytest.raises(ValueError, match="sd_downscale"):
+        ctx.bcsd_fit(7, X, y, gid, 12, True)  # unknown kind
+    bad = gid.copy()
+    bad[5] = 12  # group id out of range
+    with pytest.raises(ValueError, match="sd_downscale"):
+        ctx.bcsd_fit(0, X, y, bad, 12, True)
+    with pytest.raises(ValueError, match="sd_downscale"):
+        ctx.bcsd_fit(0, None, y, gid, 12, True)  # BcsdTemperature needs X
+    st = ctx.bcsd_fit(0, X, y, gid, 12, True)
+    bad_p = np.full(50, -1, dtype=np.int32)
+    with pytest.raises(ValueError, match="sd_downscale"):
+        ctx.bcsd_predict(st, rng.standard_normal((50, 3)), bad_p)
+    # a NULL state / context is an argument error, not a crash
+    rc = ctx.lib.sd_bcsd_state_info(None, None, None, None, None, None)
+    assert rc == 1 and b"NULL" in ctx.lib.sd_last_error() or rc == 1
+    rc = ctx.lib.sd_ctx_synchronize(None)
+    assert rc == 1
+    # an empty month in the predict series is fine (that month simply has no samples)
+    gid_p = np.where(gid == 3, 4, gid).astype(np.int32)
+    out, status = ctx.bcsd_predict(st, rng.standard_normal((100, 3)), gid_p)
+    assert np.isfinite(out).all() and (status == 0).all()
+
+
+def test_analog_argument_errors(ctx):
+    rng = np.random.default_rng(1)
+    X, y, Xq = rng.standard_normal((40, 1, 2)), rng.standard_normal((40, 2)), rng.standard_normal((10, 1, 2))
+    st = ctx.analog_fit(X, y)
+    with pytest.raises(ValueError, match="k=41"):
+        ctx.analog_predict(st, Xq, 41, 3)  # more analogs than training samples
+    with pytest.raises(ValueError, match="bad sizes|k=0"):
+        ctx.analog_predict(st, Xq, 0, 3)
+    with pytest.raises(ValueError, match="unknown kind"):
+        ctx.analog_predict(st, Xq, 5, 9)
+    with pytest.raises(ValueError, match="sample_inds"):
+        ctx.analog_predict(st, Xq, 5, 1)  # sample_analogs without the sampled indices
+    with pytest.raises(ValueError, match="F=9"):
+        ctx.analog_fit(rng.standard_normal((40, 9, 2)), y)  # more features than the engine supports
+    out, status = ctx.analog_predict(st, Xq, 40, 3)  # k == T is allowed
+    assert np.isfinite(out).all()
+
+
+def test_qm_limits(ctx):
+    rng = np.random.default_rng(2)
+    T = 20000  # beyond the workgroup sort (19 456 samples)
+    with pytest.raises(NotImplementedError, match="19456"):
+        ctx.qm_fit(rng.standard_normal((T, 1)), rng.standard_normal((T, 1)))
+    st = ctx.qm_fit(rng.standard_normal((50, 2)), rng.standard_normal((50, 2)))
+    with pytest.raises(ValueError, match="unknown model"):
+        ctx.qm_predict(st, 5, rng.standard_normal((10, 2)))
+    with pytest.raises(NotImplementedError, match="19456"):
+        ctx.qm_predict(st, 1, rng.standard_normal((T, 2)))  # EquidistantCdfMatcher ranks the new series
+    out, _ = ctx.qm_predict(st, 0, rng.standard_normal((T, 2)))  # the regressor itself has no such limit
+    assert np.isfinite(out).all()
+
+
+def test_state_use_after_destroy_and_release_cached(ctx):
+    rng = np.random.default_rng(3)
+    X, y = rng.standard_normal((60, 2)), rng.standard_normal((60, 2))
+    st = ctx.bcsd_fit(0, X, y, (np.arange(60) % 12).astype(np.int32), 12, True)
+    st.close()
+    with pytest.raises(ValueError, match="destroyed"):
+        ctx.bcsd_predict(st, X, (np.arange(60) % 12).astype(np.int32))
+    ctx.release_cached()  # cached blocks back to the driver; the context keeps working
+    st = ctx.bcsd_fit(0, X, y, (np.arange(60) % 12).astype(np.int32), 12, True)
+    out, status = ctx.bcsd_predict(st, X, (np.arange(60) % 12).astype(np.int32))
+    assert np.isfinite(out).all()
