@@ -213,7 +213,7 @@ class Context:
         T, Cc = out.shape
         c_full = Cc if c_full is None else c_full
         b = None if base is None else np.ascontiguousarray(base, dtype=np.float64)
-        check(self.lib.sd_synth_fill(self.handle, out.vptr, T, Cc, Cc, c_offset, c_full, kind, seed, stream, ptr(b), amp,
+        check(self.lib.sd_synth_fill(self.handle, out.vptr, T, Cc, out.ld, c_offset, c_full, kind, seed, stream, ptr(b), amp,
                                      cell_scale, p_dry, -1 if stream2 is None else stream2, amp2))
         return out
 

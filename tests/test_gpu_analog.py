@@ -198,3 +198,33 @@ def test_gard_models_default_and_regression(sample_X_y):
     assert res.dims == ("time", "variable", "y", "x") and res.shape == (T, 3, 2, 2)
     exp, _, _ = ao.pure_analog_predict(X.values, y.values, X.values, 10, ao.KIND_WEIGHT)
     assert_close(res.values[:, :, 1, 1], exp, what="pointwise analog")
+
+
+def test_large_grid_is_consistent(ctx):
+    """16 384 cells x 14 600 steps made of identical 2 048-cell blocks: every block (any chunk / workgroup of the
+    windowed path) reproduces the first one bit for bit, and the first cells match the oracle."""
+    from skdownscale_amd import synth
+
+    T, C, B, k = 14600, 16384, 2048, 30
+    fields = {}
+    for name, stream, kw in (("X", 20, {}), ("y", 20, dict(amp=2.0, stream2=21, amp2=1.0)), ("Xq", 22, {})):
+        d = ctx.empty((T, C))
+        for c0 in range(0, C, B):
+            ctx.synth_fill(d.cells(c0, c0 + B), synth.GAUSS, 5, stream, c_offset=0, c_full=B, **kw)
+        fields[name] = d
+    st = ctx.analog_fit(ctx.wrap(fields["X"].ptr, (T, 1, C)), fields["y"])
+    out, status = ctx.analog_predict(st, ctx.wrap(fields["Xq"].ptr, (T, 1, C)), k, 3)
+    assert (status == 0).all()
+    rows = np.unique(np.linspace(0, T - 1, 40).astype(np.int64))
+    got = np.stack([ctx.wrap(out.ptr + int(t) * 3 * C * 8, (3, C)).to_host() for t in rows])  # [rows, 3, C]
+    for c0 in range(B, C, B):
+        assert np.array_equal(got[:, :, c0:c0 + B], got[:, :, :B]), f"block at cell {c0} differs from block 0"
+    n = 2
+    Xh = fields["X"].cells(0, n).to_host()[:, None, :]
+    yh = fields["y"].cells(0, n).to_host()
+    Xqh = fields["Xq"].cells(0, n).to_host()[rows][:, None, :]
+    assert_close(got[:, :, :n], ao.pointwise_analog(Xh, yh, Xqh, k, ao.KIND_MEAN), what="large grid vs oracle")
+    st.close()
+    for d in fields.values():
+        d.free()
+    out.free()

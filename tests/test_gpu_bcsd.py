@@ -346,3 +346,43 @@ def test_pointwise_downscaler_bcsd_grid():
         PointWiseDownscaler(BcsdTemperature()).fit(mk(X, index), mk(y, index))
     with pytest.raises(TypeError):
         PointWiseDownscaler(object())
+
+
+def test_full_size_grid_is_consistent(ctx):
+    """BASELINE config 2 size (100 000 cells x 14 600 steps, 12 months) through a size-independent property: the grid
+    is made of identical 8 192-cell blocks, so every block -- whatever tile, workgroup and XCD it lands on -- must
+    reproduce the first one bit for bit; the first cells of block 0 are checked against the C oracle."""
+    import c_oracle
+    from skdownscale_amd import synth
+
+    if not c_oracle.available():
+        pytest.skip("C oracle not built")
+    T, C, B = 14600, 100_000, 8192
+    index = synth.daily_calendar(T)
+    gid = month_gid(index)
+    tabs = synth.tas_tables(index)
+    fields = {}
+    for name in ("X_hist", "y_obs", "X_fut"):
+        d = ctx.empty((T, C))
+        for c0 in range(0, C, B):
+            c1 = min(C, c0 + B)
+            ctx.synth_fill(d.cells(c0, c1), synth.GAUSS, 3, tabs[name]["stream"], c_offset=0, c_full=B, base=tabs[name]["base"],
+                           amp=tabs[name]["amp"], cell_scale=tabs[name]["cell_scale"])
+        fields[name] = d
+    out, status = ctx.bcsd_fit_predict(0, fields["X_hist"], fields["y_obs"], gid, 12, fields["X_fut"], gid)
+    assert (status == 0).all()
+    rows = np.unique(np.linspace(0, T - 1, 48).astype(np.int64))
+    got = np.empty((len(rows), C))
+    for i, t in enumerate(rows):  # one 800 KB row at a time
+        got[i] = ctx.wrap(out.ptr + int(t) * C * 8, (1, C)).to_host()[0]
+    for c0 in range(B, C, B):
+        c1 = min(C, c0 + B)
+        assert np.array_equal(got[:, c0:c1], got[:, :c1 - c0]), f"block at cell {c0} differs from block 0"
+    n = 16
+    cells = np.arange(n)
+    exp, _ = c_oracle.bcsd_fit_predict(0, synth.tas_field("X_hist", 3, index, cells, B), synth.tas_field("y_obs", 3, index, cells, B),
+                                       synth.tas_field("X_fut", 3, index, cells, B), gid, gid)
+    assert_close(got[:, :n], exp[rows], scale=float(np.std(exp)), what="full-size block 0 vs C oracle")
+    for d in fields.values():
+        d.free()
+    out.free()
