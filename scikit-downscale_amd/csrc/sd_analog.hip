@@ -939,7 +939,8 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(const double* __re
                                                               int64_t C, const double* __restrict__ xs_all,
                                                               const int32_t* __restrict__ xi_all,
                                                               const double* __restrict__ pq_all,
-                                                              const double* __restrict__ ybar_all, const double* __restrict__ Xc,
+                                                              const double* __restrict__ ybar_all,
+                                                              const double* __restrict__ yx_all, const double* __restrict__ Xc,
                                                               const double* __restrict__ yc,
                                                               const int32_t* __restrict__ fit_status, int32_t* status,
                                                               double* scratch_d, int32_t* scratch_i, PredictArgs pa) {
@@ -1009,12 +1010,21 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(const double* __re
                         f1_walk_query(0, pa, n, T, c, tq, q[j], xg, xi_all + c * T, Xc + c * T, yc + c * T, sd, si, nthr);
                         continue;
                     }
-                    const double2 a = pq[L], b = pq[L + k];
-                    const double m1 = (b.x - a.x) / kk;           // mean of the centred analogs
-                    const double var = (b.y - a.y) / kk - m1 * m1;
-                    pred = ybar + m1;                            // gard.py:329-333
-                    prob = 1.0;                                  // gard.py:346
-                    err = sqrt(var > 0.0 ? var : 0.0);           // ddof = 0 (gard.py:345)
+                    if (k == 1) {
+                        // a single analog (best_analog, or n_analogs = 1: gard.py:291-296): the value itself, no spread
+                        const double a1 = yx_all[c * T + L];
+                        const bool exc = !pa.has_thresh || a1 > pa.thresh;  // gard.py:307
+                        pred = (pa.kind == SD_ANALOG_BEST || exc) ? a1 : 0.0;  // mean / weight of a masked analog: NaN -> 0 (gard.py:341)
+                        prob = pa.has_thresh ? (exc ? 1.0 : 0.0) : 1.0;       // gard.py:343, 346
+                        err = exc ? 0.0 : nan;                                // gard.py:342, 345
+                    } else {
+                        const double2 a = pq[L], b = pq[L + k];
+                        const double m1 = (b.x - a.x) / kk;           // mean of the centred analogs
+                        const double var = (b.y - a.y) / kk - m1 * m1;
+                        pred = ybar + m1;                            // gard.py:329-333
+                        prob = 1.0;                                  // gard.py:346
+                        err = sqrt(var > 0.0 ? var : 0.0);           // ddof = 0 (gard.py:345)
+                    }
                 }
                 put_out(pa, tq, c, pred, prob, err);
             }
@@ -1357,7 +1367,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // mean_analogs without a threshold: statistics from the prefix sums, one pass with only xs in LDS
         const size_t lds_mean = sizeof(double) * (size_t)(T + 1);
-        const bool mean_only = mode == 0 && kind == SD_ANALOG_MEAN && !has_thresh && st->pq != nullptr && lds_mean <= ctx->lds_max &&
+        const bool mean_only = mode == 0 && ((kind == SD_ANALOG_MEAN && !has_thresh) || k == 1) && st->pq != nullptr && lds_mean <= ctx->lds_max &&
                                getenv("SD_ANALOG_NOPREFIX") == nullptr;
         if (mean_only)
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean_kernel),
@@ -1375,7 +1385,8 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
             if (mean_only) {
                 SD_LAUNCH(ctx, "analog_f1_mean_kernel", analog_f1_mean_kernel, dim3(nbc), dim3(nthr), lds_mean, (const double*)qc.p,
                           Tq, T, cc, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
-                          (const double*)st->pq + 2 * cb * (T + 1), (const double*)st->ybar + cb, (const double*)st->X + cb * T,
+                          (const double*)st->pq + 2 * cb * (T + 1), (const double*)st->ybar + cb, (const double*)st->yx + cb * T,
+                          (const double*)st->X + cb * T,
                           (const double*)st->y + cb * T, (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb,
                           sc_d.as<double>(), sc_i.as<int32_t>(), pw);
             } else {
