@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Randomised parity sweep on the GPU (development aid): random sizes / groups / kinds vs the oracles."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "scikit-downscale_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import analog_oracle as ao  # noqa: E402
+import bcsd_oracle as bo  # noqa: E402
+import qm_oracle as qo  # noqa: E402
+from _cases import assert_close  # noqa: E402
+from skdownscale_amd.engine import default_context  # noqa: E402
+
+
+def main(n_cases=40, seed=0):
+    ctx = default_context()
+    rng = np.random.default_rng(seed)
+    for it in range(n_cases):
+        what = rng.choice(["bcsd", "analog", "qm"])
+        if what == "bcsd":
+            kind = int(rng.integers(0, 2))
+            G = int(rng.choice([1, 3, 12, 12, 12]))
+            T = int(rng.integers(G * 12, 6000))
+            Tp = int(rng.choice([T, rng.integers(G * 3, 7000)]))
+            C = int(rng.integers(1, 40))
+            gid = rng.integers(0, G, T).astype(np.int32) if rng.random() < 0.3 else (np.arange(T) * G // T).astype(np.int32)
+            gid_p = (np.arange(Tp) % G).astype(np.int32)
+            gid[:G] = np.arange(G)  # every group is present in fit
+            # tie-heavy data on a dyadic grid: sums are exact, so the tie structure does not depend on the order of
+            # the climatology / rolling sums (with inexact decimals it does -- in the reference as well)
+            q = float(rng.choice([1, 4, 16]))
+            f = (lambda n: np.round((10 + 3 * rng.standard_normal((n, C))) * q) / q) if rng.random() < 0.4 else (lambda n: 10 + 3 * rng.standard_normal((n, C)))
+            X, y, Xp = f(T), f(T) + 20, f(Tp)
+            if kind == 1:
+                X, y, Xp = np.abs(X) * (rng.random(X.shape) > 0.4), np.abs(y) + 0.1, np.abs(Xp) * (rng.random(Xp.shape) > 0.4)
+            ra = bool(rng.integers(0, 2))
+            exp, est = bo.pointwise_fit_predict(kind, X, y, Xp, gid, gid_p, G=G, return_anoms=ra)
+            st = ctx.bcsd_fit(kind, X, y, gid, G, ra)
+            out, status = ctx.bcsd_predict(st, Xp, gid_p)
+            assert np.array_equal(status, est), (it, status, est)
+            assert_close(out, exp, what=f"case {it} bcsd kind={kind} G={G} T={T} Tp={Tp} C={C}")
+            fused, _ = ctx.bcsd_fit_predict(kind, ctx.to_device(X), ctx.to_device(y), gid, G, ctx.to_device(Xp), gid_p, ra)
+            assert_close(fused.to_host(), exp, what=f"case {it} fused")
+        elif what == "analog":
+            F = int(rng.choice([1, 1, 1, 2, 4]))
+            T = int(rng.integers(40, 3000))
+            Tq = int(rng.integers(1, 600))
+            C = int(rng.integers(1, 6))
+            k = int(rng.integers(1, min(T, 64)))
+            quant = rng.random() < 0.4
+            X = rng.standard_normal((T, F, C))
+            Xq = rng.standard_normal((Tq, F, C))
+            if quant:
+                X, Xq = np.round(X, 1), np.round(Xq, 1)
+            y = rng.standard_normal((T, C))
+            st = ctx.analog_fit(X, y)
+            kind = int(rng.choice([0, 2, 3]))
+            kk = 1 if kind == 0 else k
+            thresh = None if rng.random() < 0.5 else 0.0
+            out, _ = ctx.analog_predict(st, Xq, kk, kind, thresh)
+            exp = ao.pointwise_analog(X, y, Xq, kk, kind, thresh)
+            assert_close(out, exp, what=f"case {it} analog F={F} T={T} Tq={Tq} k={kk} kind={kind} thresh={thresh} quant={quant}")
+            out, _ = ctx.analogreg_predict(st, Xq, k)
+            # k <= F + 1 is under-determined: the reference's lstsq cut-off (eps * max(k, F)) sits at the rounding level of
+            # the centred analogs, its answer flips between the minimum-norm solution and noise -- unpinned
+            if k >= F + 2 and not quant:
+                exp = ao.pointwise_analog(X, y, Xq, k, 3, regression=True)
+                assert_close(out, exp, what=f"case {it} analogreg F={F} T={T} k={k}")
+        else:
+            T = int(rng.integers(21, 9000))
+            Tp = int(rng.integers(1, 9000))
+            C = int(rng.integers(1, 12))
+            q = rng.choice([1, 2, 8])
+            X, y, Xp = (np.round(5 + 2 * rng.standard_normal((n, C)), q) for n in (T, T, Tp))
+            y = y + 10
+            st = ctx.qm_fit(X, y)
+            for ex in (None, "1to1"):
+                out, _ = ctx.qm_predict(st, 0, Xp, ex == "1to1")
+                assert_close(out, qo.pointwise_qm("qmr", X, y, Xp, ex), what=f"case {it} qmr T={T} Tp={Tp} {ex}")
+                out, _ = ctx.qm_predict(st, 1, Xp, ex == "1to1")
+                assert_close(out, qo.pointwise_qm("ecm", X, y, Xp, ex, kind="difference"), what=f"case {it} ecm T={T} Tp={Tp} {ex}")
+        print(f"case {it}: {what} ok", flush=True)
+    print("fuzz ok")
+
+
+if __name__ == "__main__":
+    main(*(int(a) for a in sys.argv[1:]))
