@@ -88,6 +88,10 @@ def cpu_baseline(index, seed, c_full, target_seconds, check=None):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:  # started by hand: re-launch one process per GPU
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                   "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29531"),
+                                   os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
