@@ -15,6 +15,7 @@
 
 #include "sd_bcsd_rs.h"
 #include "sd_internal.h"
+#include "sd_sortnet.h"
 
 namespace {
 
@@ -445,6 +446,230 @@ int launch_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, int64
     return SD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// long segments (2 113 ... 19 456 samples per group, e.g. a whole 40-year daily series as one group):
+// one 1024-thread workgroup per (cell, group), the workgroup merge sort of sd_sortnet.h on a single LDS
+// array; the samples of a thread (K consecutive ones) and their shifts stay in registers.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* red /* 16 doubles */, int lane, int wave) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    return t;
+}
+
+template <int K>
+__global__ void __launch_bounds__(1024) bcsd_long_fit_kernel(int kind, const double* __restrict__ X, const double* __restrict__ y,
+                                                             int64_t ld, const int32_t* __restrict__ order,
+                                                             const int32_t* __restrict__ goff, int G, int64_t T, int64_t C,
+                                                             int return_anoms, double* __restrict__ ys,
+                                                             double* __restrict__ x_climo, double* __restrict__ y_climo,
+                                                             int32_t* status) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int64_t c = blockIdx.x;
+    const int g = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int beg = goff[g], n = goff[g + 1] - beg;
+    if (n == 0) return;
+    const int np = (n + K - 1) / K * K;
+    double* buf = reinterpret_cast<double*>(smem_raw);  // np + 1 doubles
+    int* xch = reinterpret_cast<int*>(buf + np + 1);     // nthr + 1 ints
+    double* red = reinterpret_cast<double*>(xch);        // 16 doubles, used between the sorts' exchanges
+    const int32_t* ord = order + beg;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    bool bad = false;
+    if (X != nullptr) {  // x climatology (bcsd.py:222); PR only validates X
+        double s = 0.0;
+        for (int i = tid; i < n; i += nthr) {
+            const double v = X[(int64_t)ord[i] * ld + c];
+            bad |= !sd_finite(v);
+            s += v;
+        }
+        s = block_sum(s, red, lane, wave);
+        if (kind == SD_BCSD_TAS && tid == 0) x_climo[c * G + g] = s / (double)n;
+    }
+    double s = 0.0;
+    for (int i = tid; i <= np; i += nthr) {
+        double v = inf;
+        if (i < n) {
+            v = y[(int64_t)ord[i] * ld + c];
+            bad |= !sd_finite(v);
+            s += v;
+        }
+        buf[i] = v;
+    }
+    if (bad) atomicOr(&status[c], SDI_NONFINITE);
+    s = block_sum(s, red, lane, wave);
+    if (tid == 0) {
+        const double m = s / (double)n;
+        y_climo[c * G + g] = m;  // bcsd.py:223 / 138
+        if (kind == SD_BCSD_PR && return_anoms && m <= 0.0) atomicOr(&status[c], SDI_BAD_CLIMO);  // bcsd.py:140-141
+    }
+    double v[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const int j = K * tid + i;
+        v[i] = buf[j < np ? j : np];
+    }
+    __syncthreads();
+    sdsort::block_merge_sort<K>(v, buf, np, xch, tid, nthr);  // quantile.py:462 np.sort
+    double* dst = ys + c * T + beg;
+    for (int i = tid; i < n; i += nthr) dst[i] = buf[i];
+}
+
+template <int K>
+__global__ void __launch_bounds__(1024) bcsd_long_predict_kernel(
+    int kind, const double* __restrict__ Xp, int64_t ld, const int32_t* __restrict__ order_p,
+    const int32_t* __restrict__ goff_p, const int32_t* __restrict__ goff_f, int G, int64_t Tf, int64_t C, int return_anoms,
+    const double* __restrict__ ys, const double* __restrict__ x_climo, const double* __restrict__ y_climo,
+    const int32_t* __restrict__ fit_status, int32_t* status, double* __restrict__ out, int64_t ld_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int64_t c = blockIdx.x;
+    const int g = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+    const int begp = goff_p[g], m = goff_p[g + 1] - begp;
+    const int begf = goff_f[g], n = goff_f[g + 1] - begf;
+    if (m == 0) return;
+    const int np = (m + K - 1) / K * K;
+    double* buf = reinterpret_cast<double*>(smem_raw);  // np + 1 doubles
+    int* xch = reinterpret_cast<int*>(buf + np + 1);     // nthr + 1 ints
+    __shared__ TailFit tf_s;
+    const int32_t* ord = order_p + begp;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    bool bad = false;
+    for (int i = tid; i <= np; i += nthr) {
+        double v = 0.0;
+        if (i < m) {
+            v = Xp[(int64_t)ord[i] * ld + c];
+            bad |= !sd_finite(v);
+        }
+        buf[i] = v;
+    }
+    if (bad) atomicOr(&status[c], SDI_NONFINITE);
+    const bool active = n > 0 && fit_status[c] == 0;
+    const double* ysg = ys + c * Tf + begf;
+    const double dn = pp_denom(n), dm = pp_denom(m);
+    if (tid == 0) {
+        TailFit tf = {0.0, 0.0, 0.0, 0.0};
+        if (active && m > n) {  // p can leave [pp_0, pp_{n-1}] only when the predict segment is longer
+            const int e = n < kEndpoints ? n : kEndpoints;
+            ols_line(ysg, 0, e, dn, &tf.slope_lo, &tf.icpt_lo);
+            ols_line(ysg, n - e, e, dn, &tf.slope_hi, &tf.icpt_hi);
+        }
+        tf_s = tf;
+    }
+    __syncthreads();
+    const double xc = kind == SD_BCSD_TAS ? x_climo[c * G + g] : 0.0;
+    const double yc = y_climo[c * G + g];
+    // u = X - (rolling mean - x_climo) (bcsd.py:247-256); PR maps raw X (bcsd.py:167)
+    double u[K], shift[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const int j = K * tid + i;
+        double x = 0.0, sh = 0.0;
+        if (j < m) {
+            x = buf[j];
+            if (kind == SD_BCSD_TAS) sh = rolling9(buf, m, j) - xc;
+        }
+        shift[i] = sh;
+        u[i] = j < m ? x - sh : inf;
+    }
+    __syncthreads();
+    {
+        double v[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) v[i] = u[i];
+        sdsort::block_merge_sort<K>(v, buf, np, xch, tid, nthr);  // self ECDF: np.sort(u) (quantile.py:462 via 505-521)
+    }
+    // rank = (#sorted <= u) - 1: np.interp's exact-hit index = max rank among ties (quantile.py:488)
+    int pos[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) pos[i] = -1;  // index of the last element known to be <= u
+#pragma unroll 1
+    for (int len = m; len > 1;) {
+        int half = len >> 1;
+        if ((half & 15) == 0) --half;  // keep the probe strides off the LDS bank period
+        len -= half;
+#pragma unroll
+        for (int i = 0; i < K; ++i) pos[i] += buf[pos[i] + half] <= u[i] ? half : 0;
+    }
+    const TailFit tf = tf_s;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const int j = K * tid + i;
+        if (j >= m) continue;
+        double res = nan;
+        if (active) {
+            const int cnt = pos[i] + 1 + (buf[pos[i] + 1] <= u[i] ? 1 : 0);
+            const int r = cnt > 0 ? cnt - 1 : 0;
+            const double q = inverse_cdf(pp_at(r, dm), ysg, n, dn, tf);
+            if (kind == SD_BCSD_TAS) {
+                res = shift[i] + q;                // bcsd.py:263
+                if (return_anoms) res = res - yc;  // bcsd.py:266-267
+            } else {
+                res = return_anoms ? q / yc : q;   // bcsd.py:170-185
+            }
+        }
+        out[(int64_t)ord[j] * ld_out + c] = res;
+    }
+}
+
+// register widths of the workgroup sort: n <= 1024 * K and the keys fit the LDS
+int long_width(int nmax, size_t lds_max) {
+    const int widths[] = {3, 5, 9, 13, 15, 17, 19};
+    for (int K : widths) {
+        const int64_t np = ((int64_t)nmax + K - 1) / K * K;
+        if (nmax <= 1024 * K && sizeof(double) * (size_t)(np + 1) + sizeof(int) * 1025 + 64 <= lds_max) return K;
+    }
+    return 0;
+}
+
+template <int K>
+int launch_long_fit(sd_ctx* ctx, int kind, const double* X, const double* y, int64_t ld, const DevGroupTable& gt, int G, int64_t T,
+                    int64_t C, int return_anoms, sd_bcsd_state* st) {
+    const int np = (gt.nmax + K - 1) / K * K;
+    const size_t lds = sizeof(double) * (size_t)(np + 1) + sizeof(int) * 1025;
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_long_fit_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    SD_LAUNCH(ctx, "bcsd_long_fit_kernel", bcsd_long_fit_kernel<K>, dim3((unsigned)C, (unsigned)G), dim3(1024), lds, kind, X, y, ld,
+              (const int32_t*)gt.order.p, (const int32_t*)gt.off.p, G, T, C, return_anoms, st->ys, st->x_climo, st->y_climo,
+              st->status);
+    return SD_OK;
+}
+
+template <int K>
+int launch_long_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, int64_t ld, const DevGroupTable& gt,
+                        int32_t* status_p, double* out, int64_t ld_out) {
+    const int np = (gt.nmax + K - 1) / K * K;
+    const size_t lds = sizeof(double) * (size_t)(np + 1) + sizeof(int) * 1025;
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_long_predict_kernel<K>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_LAUNCH(ctx, "bcsd_long_predict_kernel", bcsd_long_predict_kernel<K>, dim3((unsigned)st->C, (unsigned)st->G), dim3(1024), lds,
+              st->kind, Xp, ld, (const int32_t*)gt.order.p, (const int32_t*)gt.off.p, (const int32_t*)st->goff_dev, st->G, st->T,
+              st->C, st->return_anoms, (const double*)st->ys, (const double*)st->x_climo, (const double*)st->y_climo,
+              (const int32_t*)st->status, status_p, out, ld_out);
+    return SD_OK;
+}
+
+#define SD_LONG_DISPATCH(K, fn, ...)                       \
+    switch (K) {                                           \
+        case 3: SD_TRY(fn<3>(__VA_ARGS__)); break;         \
+        case 5: SD_TRY(fn<5>(__VA_ARGS__)); break;         \
+        case 9: SD_TRY(fn<9>(__VA_ARGS__)); break;         \
+        case 13: SD_TRY(fn<13>(__VA_ARGS__)); break;       \
+        case 15: SD_TRY(fn<15>(__VA_ARGS__)); break;       \
+        case 17: SD_TRY(fn<17>(__VA_ARGS__)); break;       \
+        default: SD_TRY(fn<19>(__VA_ARGS__)); break;       \
+    }
+
+bool use_long_path(int nmax, size_t lds_max) {
+    const char* e = getenv("SD_BCSD_PATH");  // "v1" keeps the generic LDS-bitonic kernels
+    if (e && e[0] == 'v' && e[1] == '1') return false;
+    return nmax > 64 * 33 && long_width(nmax, lds_max) != 0;
+}
+
 int alloc_state(sd_ctx* ctx, int kind, int G, int64_t T, int64_t C, int return_anoms, sd_bcsd_state** out) {
     sd_bcsd_state* st = new sd_bcsd_state();
     st->ctx = ctx;
@@ -496,7 +721,8 @@ int sd_bcsd_fit_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_
     SD_TRY(upload_group_table(ctx, group_id, T, G, &gt));
     int W = 0, stride = 0;
     const bool rs = use_rs_path(gt.nmax);
-    if (!rs) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 1, &W, &stride));
+    const bool lng = !rs && use_long_path(gt.nmax, ctx->lds_max);
+    if (!rs && !lng) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 1, &W, &stride));
     sd_bcsd_state* st = nullptr;
     int rc = alloc_state(ctx, kind, G, T, C, return_anoms, &st);
     if (rc != SD_OK) {
@@ -519,6 +745,8 @@ int sd_bcsd_fit_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_
             p.ys = st->ys; p.x_climo = st->x_climo; p.y_climo = st->y_climo; p.status_fit = st->status;
             p.ablate = rs_ablate();
             SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_FIT, p, gt.nmax));
+        } else if (lng) {
+            SD_LONG_DISPATCH(long_width(gt.nmax, ctx->lds_max), launch_long_fit, ctx, kind, X_dev, y_dev, ld, gt, G, T, C, return_anoms, st);
         } else
         switch (W) {
             case 8: SD_TRY(launch_fit<8>(ctx, kind, X_dev, y_dev, ld, gt, G, T, C, stride, return_anoms, st)); break;
@@ -549,7 +777,8 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
     int W = 0, stride = 0;
     const int nmax_all = gt.nmax > st->nmax ? gt.nmax : st->nmax;
     const bool rs = use_rs_path(nmax_all);
-    if (!rs) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 2, &W, &stride));
+    const bool lng = !rs && use_long_path(nmax_all, ctx->lds_max) && long_width(gt.nmax, ctx->lds_max) != 0;
+    if (!rs && !lng) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 2, &W, &stride));
     sd_scratch status_p, status_pub;
     SD_HIP(status_p.alloc(ctx, sizeof(int32_t) * C));
     SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
@@ -581,6 +810,8 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
             SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_RANK, p, nmax_all));
             SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_APPLY, p, nmax_all));
         }
+    } else if (lng) {
+        SD_LONG_DISPATCH(long_width(gt.nmax, ctx->lds_max), launch_long_predict, ctx, st, Xp_dev, ld, gt, status_p.as<int32_t>(), out_dev, ld_out);
     } else
     switch (W) {
         case 8: SD_TRY(launch_predict<8>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;

@@ -386,3 +386,35 @@ def test_full_size_grid_is_consistent(ctx):
     for d in fields.values():
         d.free()
     out.free()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("G,T,Tp,C", [(1, 14600, 14600, 3), (1, 2113, 2500, 2), (4, 14600, 9000, 3), (1, 19456, 19456, 1),
+                                     (2, 6000, 30000, 2), (1, 14600, 1000, 2)])
+def test_long_segments_workgroup_sort(ctx, kind, G, T, Tp, C):
+    """Groups of 2 113 ... 19 456 samples (e.g. a whole 40-year daily series as one group) run on the workgroup merge
+    sort: equal / longer / shorter predict series, tie-heavy dyadic data for the precipitation kind."""
+    rng = np.random.default_rng(G * T + Tp + kind)
+    X, y, Xp = (12 + 5 * rng.standard_normal((n, C)) for n in (T, T, Tp))
+    if kind == 1:
+        X, y, Xp = (np.round(np.abs(a) * 4) / 4 * (rng.random(a.shape) > 0.45) for a in (X, y, Xp))
+        y = y + 0.25
+    gid = (np.arange(T) * G // T).astype(np.int32)
+    gid_p = (np.arange(Tp) % G).astype(np.int32)
+    exp, est = bo.pointwise_fit_predict(kind, X, y, Xp, gid, gid_p, G=G)
+    st = ctx.bcsd_fit(kind, X, y, gid, G, True)
+    out, status = ctx.bcsd_predict(st, Xp, gid_p)
+    assert np.array_equal(status, est)
+    assert_close(out, exp, what=f"long segments kind={kind} G={G} {T}->{Tp}")
+    fused, _ = ctx.bcsd_fit_predict(kind, ctx.to_device(X), ctx.to_device(y), gid, G, ctx.to_device(Xp), gid_p)
+    assert np.array_equal(fused.to_host(), out)
+
+
+def test_segments_beyond_every_kernel_are_refused(ctx):
+    rng = np.random.default_rng(0)
+    T = 20000  # one group of 20 000 samples: beyond the workgroup sort and the generic predict kernel
+    X, y = rng.standard_normal((T, 1)), rng.standard_normal((T, 1))
+    gid = np.zeros(T, dtype=np.int32)
+    st = ctx.bcsd_fit(0, X, y, gid, 1, True)  # (the fit alone still fits the generic kernel)
+    with pytest.raises(NotImplementedError, match="does not fit"):
+        ctx.bcsd_predict(st, X, gid)

@@ -121,7 +121,7 @@ def test_quantile_mapper_transformer():
     assert_close(actual, g["qm_actual"], what="test_quantile_mapper golden")
     assert np.array_equal(mapper.x_cdf_fit_.cdf_.vals, np.sort(expected[:, 0]))
     rng = np.random.default_rng(8)
-    for nfit, npred in ((500, 500), (500, 800), (800, 300), (3000, 3000)):
+    for nfit, npred in ((500, 500), (500, 800), (800, 300), (3000, 3000), (14600, 14600), (14600, 9000)):
         a, b = rng.standard_normal((nfit, 1)), 0.5 + 1.5 * rng.standard_normal((npred, 1))
         m = QuantileMapper().fit(a)
         exp, _ = bo.pointwise_fit_predict(bo.PR, None, a, b, np.zeros(nfit, np.int32), np.zeros(npred, np.int32), G=1,
