@@ -5,14 +5,20 @@
 // KDTree.query is restated as: k training rows with the smallest reduced distance
 // rdist = sum_f (q_f - x_f)^2 (accumulated f = 0..F-1, no FMA), ascending by (rdist, index).
 //
-// fit   : mask / finite check, cell-major copies Xc[C][F][T], yc[C][T] (tiled LDS transpose); for
-//         F == 1 additionally a per-cell sort of (x, index) -> xs[C][T], xi[C][T], yx[C][T].
-// predict: one persistent workgroup per cell.
-//   F == 1 : the cell's sorted training values live in LDS; each thread answers queries by a binary
-//            search + two-pointer walk that emits neighbours in (rdist, index) order.
-//   F  > 1 : tiled brute force over the training set staged through LDS, per-thread top-k list.
-// Neighbour lists go to an L2-resident scratch [k][threads] per workgroup, then the statistics
-// epilogue (gard.py:303-346) or the per-query OLS (gard.py:194-224) runs on them.
+// fit   : mask / finite check, cell-major copies Xc[C][F][T], yc[C][T] (tiled LDS transpose); for F == 1
+//         additionally the sorted view of a cell: xs[C][T] (values by (x, index)), xi[C][T] (their training
+//         indices), yx[C][T] (y in that order) and pq[C][T+1][2] (prefix sums of the centred yx and its
+//         squares) -- analog_sort2_kernel: workgroup merge sort (sd_sortnet.h).
+// predict, F == 1 (one persistent workgroup per cell, queries and outputs through cell-major staging):
+//   analog_f1_mean_kernel   mean_analogs without a threshold, or a single analog: window search over xs in
+//                           LDS + prefix sums (single pass);
+//   analog_f1_window_kernel the other PureAnalog kinds and AnalogRegression: k-NN window over xs, statistics
+//                           from yx, both LDS-resident per value range;
+//   analog_f1_predict_kernel / f1_walk_query  exact (rdist, index)-ordered two-pointer walk: 'sample_analogs',
+//                           neighbour outputs, and any query whose window has a tie on its boundary.
+// predict, F > 1: analog_bf2_predict_kernel (one wave per 64 queries, scalar-loaded training points, top-k heap
+//   in LDS); analog_bf_predict_kernel (LDS-staged tiles, lists in global scratch) for k > 208.
+// Epilogues: PureAnalog statistics (gard.py:303-346), per-query least squares (gard.py:194-224).
 #include <algorithm>
 #include <cstdlib>
 
