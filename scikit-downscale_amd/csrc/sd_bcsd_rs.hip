@@ -1,27 +1,27 @@
 // BCSD quantile mapping, fast path: one 64-lane wave per (cell, month) segment, 8 adjacent cells per
-// 512-thread workgroup, two workgroups per CU.
+// 512-thread workgroup, two workgroups per CU (both the 160 KB LDS -- 16 rows of 10 KB -- and the 128-VGPR
+// budget allow 16 waves per CU).  Three kernels share one body (segment_body, MODE template):
+//   MODE_RANK   x side.  x_hist rows are streamed (16-byte loads, 4 lanes per 64-byte row fragment) and reduced
+//               to the per-cell climatology -- never stored; the x_fut tile is loaded the same way and transposed
+//               through LDS into one zero-padded row per cell; the owning wave takes K consecutive samples per
+//               lane, applies the 9-sample rolling-mean shift (bcsd.py:247-256), sorts a copy and ranks every
+//               sample in it by a branch-free, bank-conflict-free binary search (np.interp's "last xp <= x"
+//               rule); ranks leave as two 16-bit values per word in lane layout.
+//   MODE_APPLY  y side.  y rows are loaded/transposed, reduced to y_climo and sorted in the wave's LDS row; every
+//               rank is mapped through the fitted inverse CDF (the sorted value itself when fit and predict groups
+//               have equal lengths, else the precomputed index + weight table with OLS tails); the x_fut tile is
+//               read a second time to rebuild the shift; the result goes out transposed.
+//   MODE_FIT    the y side alone, writing the fitted state.  (MODE_BOTH = RANK then APPLY in one workgroup pass:
+//               optional, see sd_bcsd.hip.)
+// Sort (sd_sortnet.h): each lane sorts its K registers with a Batcher odd-even merge network
+// (v_min_f64/v_max_f64), writes the run to its LDS row, then 6 merge rounds double the run length; in every
+// round a lane finds its co-rank by binary search (merge path), loads its windows of the two runs and merges
+// them in registers with a pruned bitonic merger before the wave writes them back in place (LDS requests of one
+// wave are served in order, so a wavefront-scope fence replaces barriers inside the sort).  K is odd so that
+// lane-strided LDS accesses are bank-conflict free.
 //
-// Per workgroup (tile of 8 cells x one time group g):
-//   1. x_hist rows are streamed (16-byte loads, 4 lanes per 64-byte row fragment) and reduced to the
-//      per-cell climatology -- never stored.
-//   2. x_fut rows are loaded the same way and transposed through LDS into one row per cell; the owning
-//      wave pulls its row into registers (K consecutive samples per lane), applies the 9-sample
-//      rolling-mean shift (bcsd.py:247-256) in registers, sorts a copy (below), and ranks every sample
-//      in the sorted copy by a branch-free binary search (np.interp's "last xp <= x" rule).
-//   3. y rows are loaded/transposed the same way, reduced to y_climo and sorted; the sorted segment
-//      stays in the wave's LDS row and every sample is mapped through the precomputed inverse-CDF
-//      table (index + weight per rank, identical for all cells) and written back transposed.
-// Sort: each lane sorts its K registers with a Batcher odd-even merge network (v_min_f64/v_max_f64),
-// writes the run to its LDS row, then 6 merge rounds double the run length; in every round a lane
-// finds its co-rank by binary search (merge path) and merges exactly K outputs sequentially into
-// registers before the wave writes them back in place (LDS requests of one wave are served in
-// order, so no barrier is needed inside the sort).  K is odd so that lane-strided LDS accesses are
-// bank-conflict free.
-//
-// HBM traffic is the algorithmic minimum for the fused mode: 3 reads + 1 write of 8 bytes per
-// (cell, time step).  Workgroup ids are mapped XCD-aware (workgroup b runs on XCD b % 8): every XCD
-// owns a contiguous range of cell tiles, so the two 64-byte halves of a 128-byte line are fetched
-// by workgroups sharing an L2.
+// Workgroup ids are mapped XCD-aware (workgroup b runs on XCD b % 8): every XCD owns a contiguous range of cell
+// tiles, so the two 64-byte halves of a 128-byte line are fetched by workgroups sharing an L2.
 #include <cstdlib>
 
 #include "sd_bcsd_rs.h"
