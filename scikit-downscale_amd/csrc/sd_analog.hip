@@ -160,12 +160,13 @@ template <int K>
 __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __restrict__ Xc, const double* __restrict__ yc,
                                                             int64_t T, int64_t C, double* __restrict__ xs,
                                                             int32_t* __restrict__ xi, double* __restrict__ yx,
-                                                            double* __restrict__ pq_all, double* __restrict__ ybar_all) {
+                                                            double* __restrict__ pq_all, double* __restrict__ ybar_all,
+                                                            double* __restrict__ rx_all, double* __restrict__ xbar_all) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int np = (n + K - 1) / K * K;
     double* buf = reinterpret_cast<double*>(smem_raw);     // np + 1 doubles
-    int* xch = reinterpret_cast<int*>(buf + np + 1);        // nthr + 1 ints (also 3 x 16 doubles of reduction scratch)
+    int* xch = reinterpret_cast<int*>(buf + np + 1);        // nthr + 1 ints (also 5 x 16 doubles of reduction scratch)
     double* red = reinterpret_cast<double*>(xch);
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
@@ -256,61 +257,89 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
         __syncthreads();
         // buf[0..n) = y in sorted-x order: write it and its centred exclusive prefix sums (see analog_prefix_kernel)
         for (int i = tid; i < n; i += nthr) yx[c * T + i] = buf[i];
-        double yv[K];
-        double s = 0.0;
+        double yv[K], xv[K];
+        double s = 0.0, sx = 0.0;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             const int j = K * tid + i;
             yv[i] = j < n ? buf[j] : 0.0;
+            xv[i] = j < n ? xs[c * T + j] : 0.0;  // written above by this workgroup
             s += yv[i];
+            sx += xv[i];
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        for (int o = 32; o >= 1; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            sx += __shfl_xor(sx, o, 64);
+        }
         __syncthreads();  // (xch is free again)
-        if (lane == 0) red[wave] = s;
+        if (lane == 0) {
+            red[wave] = s;
+            red[48 + wave] = sx;
+        }
         __syncthreads();
-        double tot = 0.0;
-        for (int w = 0; w < 16; ++w) tot += red[w];
-        const double ybar = tot / (double)n;
-        if (tid == 0) ybar_all[c] = ybar;
-        double a = 0.0, b = 0.0;
+        double tot = 0.0, totx = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            tot += red[w];
+            totx += red[48 + w];
+        }
+        const double ybar = tot / (double)n, xbar = totx / (double)n;
+        if (tid == 0) {
+            ybar_all[c] = ybar;
+            xbar_all[c] = xbar;
+        }
+        double a = 0.0, b = 0.0, r = 0.0;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             const int j = K * tid + i;
             const double d = j < n ? yv[i] - ybar : 0.0;
+            const double e = j < n ? (xv[i] - xbar) * d : 0.0;
             yv[i] = d;
+            xv[i] = e;
             a += d;
             b += d * d;
+            r += e;
         }
-        double ia = a, ib = b;  // inclusive scan inside the wave
+        double ia = a, ib = b, ir = r;  // inclusive scan inside the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
+            const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64), tr = __shfl_up(ir, o, 64);
             if (lane >= o) {
                 ia += ta;
                 ib += tb;
+                ir += tr;
             }
         }
         __syncthreads();
         if (lane == 63) {
             red[16 + wave] = ia;
             red[32 + wave] = ib;
+            red[64 + wave] = ir;
         }
         __syncthreads();
-        double ra = ia - a, rb = ib - b;  // exclusive prefix at this thread's first element
+        double ra = ia - a, rb = ib - b, rr = ir - r;  // exclusive prefix at this thread's first element
         for (int w = 0; w < wave; ++w) {
             ra += red[16 + w];
             rb += red[32 + w];
+            rr += red[64 + w];
         }
         double2* pq = reinterpret_cast<double2*>(pq_all) + c * (T + 1);
+        double* rx = rx_all + c * (T + 1);
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             const int j = K * tid + i;
-            if (j <= n) pq[j] = make_double2(ra, rb);
+            if (j <= n) {
+                pq[j] = make_double2(ra, rb);
+                rx[j] = rr;
+            }
             ra += yv[i];
             rb += yv[i] * yv[i];
+            rr += xv[i];
         }
-        if (K * tid + K == n) pq[n] = make_double2(ra, rb);  // n = 1024 * K: no thread starts at position n
+        if (K * tid + K == n) {  // n = 1024 * K: no thread starts at position n
+            pq[n] = make_double2(ra, rb);
+            rx[n] = rr;
+        }
     }
 }
 
@@ -322,7 +351,7 @@ int launch_sort2(sd_ctx* ctx, sd_analog_state* st) {
                                (int)lds));
     const int nb = (int)std::min<int64_t>(st->C, (int64_t)ctx->cu_count * 4);
     SD_LAUNCH(ctx, "analog_sort2_kernel", analog_sort2_kernel<K>, dim3(nb), dim3(1024), lds, (const double*)st->X,
-              (const double*)st->y, st->T, st->C, st->xs, st->xi, st->yx, st->pq, st->ybar);
+              (const double*)st->y, st->T, st->C, st->xs, st->xi, st->yx, st->pq, st->ybar, st->rx, st->xbar);
     return SD_OK;
 }
 
@@ -339,64 +368,96 @@ int sort2_width(int64_t T, size_t lds_max) {
 // F == 1: exclusive prefix sums of the centred analog values in sorted-x order, pq[c][i] = (sum_{j<i} d_j,
 // sum_{j<i} d_j^2) with d = yx - mean(y).  The mean and standard deviation of any window of k consecutive analogs
 // then cost two 16-byte loads (centring keeps the running sums small: no cancellation for the differences).
+// rx[c][i] = sum_{j<i} (xs_j - mean(x)) d_j is the cross term the one-feature AnalogRegression needs.
 // One 1024-thread workgroup per cell: serial partial sums per thread, wave shuffles + LDS for the offsets.
-__global__ void __launch_bounds__(1024) analog_prefix_kernel(const double* __restrict__ yx_all, int64_t T, int64_t C,
-                                                             double* __restrict__ pq_all, double* __restrict__ ybar_all) {
-    __shared__ double wsum[2][16];
+__global__ void __launch_bounds__(1024) analog_prefix_kernel(const double* __restrict__ yx_all,
+                                                             const double* __restrict__ xs_all, int64_t T, int64_t C,
+                                                             double* __restrict__ pq_all, double* __restrict__ ybar_all,
+                                                             double* __restrict__ rx_all, double* __restrict__ xbar_all) {
+    __shared__ double wsum[3][16];
     const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int per = (n + nthr - 1) / nthr;  // consecutive elements per thread
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         const double* yx = yx_all + c * T;
+        const double* xs = xs_all + c * T;
         double2* pq = reinterpret_cast<double2*>(pq_all) + c * (T + 1);
+        double* rx = rx_all + c * (T + 1);
         const int beg = tid * per < n ? tid * per : n, end = beg + per < n ? beg + per : n;
-        // mean of y
-        double s = 0.0;
-        for (int i = beg; i < end; ++i) s += yx[i];
+        // means of y and x
+        double s = 0.0, sx = 0.0;
+        for (int i = beg; i < end; ++i) {
+            s += yx[i];
+            sx += xs[i];
+        }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        for (int o = 32; o >= 1; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            sx += __shfl_xor(sx, o, 64);
+        }
         __syncthreads();
-        if (lane == 0) wsum[0][wave] = s;
+        if (lane == 0) {
+            wsum[0][wave] = s;
+            wsum[1][wave] = sx;
+        }
         __syncthreads();
-        double tot = 0.0;
-        for (int w = 0; w < 16; ++w) tot += wsum[0][w];
-        const double ybar = tot / (double)n;
-        if (tid == 0) ybar_all[c] = ybar;
-        // per-thread totals of d and d^2, exclusive scan across the workgroup
-        double a = 0.0, b = 0.0;
+        double tot = 0.0, totx = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            tot += wsum[0][w];
+            totx += wsum[1][w];
+        }
+        const double ybar = tot / (double)n, xbar = totx / (double)n;
+        if (tid == 0) {
+            ybar_all[c] = ybar;
+            xbar_all[c] = xbar;
+        }
+        // per-thread totals of d, d^2 and (x - xbar) d, exclusive scan across the workgroup
+        double a = 0.0, b = 0.0, r = 0.0;
         for (int i = beg; i < end; ++i) {
             const double d = yx[i] - ybar;
             a += d;
             b += d * d;
+            r += (xs[i] - xbar) * d;
         }
-        double ia = a, ib = b;  // inclusive scan inside the wave
+        double ia = a, ib = b, ir = r;  // inclusive scan inside the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
+            const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64), tr = __shfl_up(ir, o, 64);
             if (lane >= o) {
                 ia += ta;
                 ib += tb;
+                ir += tr;
             }
         }
         __syncthreads();
         if (lane == 63) {
             wsum[0][wave] = ia;
             wsum[1][wave] = ib;
+            wsum[2][wave] = ir;
         }
         __syncthreads();
-        double oa = 0.0, ob = 0.0;
+        double oa = 0.0, ob = 0.0, orr = 0.0;
         for (int w = 0; w < wave; ++w) {
             oa += wsum[0][w];
             ob += wsum[1][w];
+            orr += wsum[2][w];
         }
-        double ra = oa + (ia - a), rb = ob + (ib - b);  // exclusive prefix at this thread's first element
+        double ra = oa + (ia - a), rb = ob + (ib - b), rr = orr + (ir - r);  // exclusive prefix at this thread's first element
         for (int i = beg; i < end; ++i) {
             pq[i] = make_double2(ra, rb);
+            rx[i] = rr;
             const double d = yx[i] - ybar;
             ra += d;
             rb += d * d;
+            rr += (xs[i] - xbar) * d;
         }
-        if (end == n && beg < n) pq[n] = make_double2(ra, rb);
-        if (n == 0 && tid == 0) pq[0] = make_double2(0.0, 0.0);
+        if (end == n && beg < n) {
+            pq[n] = make_double2(ra, rb);
+            rx[n] = rr;
+        }
+        if (n == 0 && tid == 0) {
+            pq[0] = make_double2(0.0, 0.0);
+            rx[0] = 0.0;
+        }
     }
 }
 
@@ -956,14 +1017,17 @@ __global__ void __launch_bounds__(1024) analog_f1_window_kernel(int mode, const 
     }
 }
 
-// F == 1, PureAnalog 'mean_analogs' without a threshold: the window statistics come from the prefix sums pq
-// (analog_prefix_kernel), so only the sorted training values have to be LDS-resident: a single pass over the
-// queries, the window search plus two 16-byte loads per query.  Tie handling as in analog_f1_window_kernel.
-__global__ void __launch_bounds__(1024) analog_f1_mean_kernel(const double* __restrict__ Xq /* [C][Tq] */, int64_t Tq, int64_t T,
-                                                              int64_t C, const double* __restrict__ xs_all,
+// F == 1, PureAnalog 'mean_analogs' without a threshold, a single analog, and AnalogRegression (mode 1, k >= 3): the
+// window statistics come from the prefix sums pq / rx (analog_prefix_kernel), so only the sorted training values
+// have to be LDS-resident: a single pass over the queries, the window search plus two (regression: three) pairs
+// of prefix loads per query.  Tie handling as in analog_f1_window_kernel.
+__global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const double* __restrict__ Xq /* [C][Tq] */, int64_t Tq,
+                                                              int64_t T, int64_t C, const double* __restrict__ xs_all,
                                                               const int32_t* __restrict__ xi_all,
                                                               const double* __restrict__ pq_all,
                                                               const double* __restrict__ ybar_all,
+                                                              const double* __restrict__ rx_all,
+                                                              const double* __restrict__ xbar_all,
                                                               const double* __restrict__ yx_all, const double* __restrict__ Xc,
                                                               const double* __restrict__ yc,
                                                               const int32_t* __restrict__ fit_status, int32_t* status,
@@ -985,6 +1049,11 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(const double* __re
         const double* xg = xs_all + c * T;
         const double2* pq = reinterpret_cast<const double2*>(pq_all) + c * (T + 1);
         const double ybar = ybar_all[c];
+        const double* rx = rx_all + c * (T + 1);
+        const double xbar = mode == 1 ? xbar_all[c] : 0.0;
+        // AnalogRegression: residual sums below this are left to direct summation (the prefix differences carry an
+        // absolute error of ~1e-16 of the cell total)
+        const double ss_floor = mode == 1 ? 1e-4 * kk * (pq[n].y / (double)n) : 0.0;
         __syncthreads();
         if (active)
             for (int i = tid; i < n; i += nthr) xs[i] = xg[i];
@@ -1031,10 +1100,51 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(const double* __re
                     const bool sep_l = L == 0 || sq_dist(q[j], xs[L - 1]) > worst;
                     const bool sep_r = L + k == n || sq_dist(q[j], xs[L + k]) > worst;
                     if (!(sep_l && sep_r)) {
-                        f1_walk_query(0, pa, n, T, c, tq, q[j], xg, xi_all + c * T, Xc + c * T, yc + c * T, sd, si, nthr);
+                        f1_walk_query(mode, pa, n, T, c, tq, q[j], xg, xi_all + c * T, Xc + c * T, yc + c * T, sd, si, nthr);
                         continue;
                     }
-                    if (k == 1) {
+                    if (mode == 1) {
+                        // one-feature OLS on the k analogs (gard.py:194-224), slope 0 when all x are equal.  The x sums
+                        // come from the LDS window, the y and cross sums from the prefix differences:
+                        //   sum (x - xm)(y - ym) = [rx] + (xbar - xm) [p],  sum (y - ym)^2 = [q] - k m1^2
+                        const double x0 = xs[L];
+                        double sx = 0.0, sxx = 0.0;
+                        for (int i = 0; i < k; ++i) {
+                            const double dx = xs[L + i] - x0;
+                            sx += dx;
+                            sxx += dx * dx;
+                        }
+                        const double2 a = pq[L], b = pq[L + k];
+                        const double s1 = b.x - a.x, m1 = s1 / kk, mx = sx / kk, xm = x0 + mx;
+                        const double vxx = sxx - kk * mx * mx, vyy = (b.y - a.y) - kk * m1 * m1;
+                        const double vxy = (rx[L + k] - rx[L]) + (xbar - xm) * s1;
+                        const double slope = vxx > 0.0 ? vxy / vxx : 0.0;
+                        double ss = vyy - slope * vxy;
+                        pred = (ybar + m1) + (q[j] - xm) * slope;
+                        if (!(ss > ss_floor)) {
+                            // (nearly) exact fit or constant analogs: the sums directly, as analog_f1_window_kernel
+                            const double* yl = yx_all + c * T + L;
+                            const double a0 = yl[0];
+                            double t1 = 0.0, txy = 0.0;
+                            for (int i = 0; i < k; ++i) {
+                                const double e = yl[i] - a0;
+                                t1 += e;
+                                txy += (xs[L + i] - x0) * e;
+                            }
+                            const double n1 = t1 / kk;
+                            const double wxy = txy - kk * mx * n1;
+                            const double sl = vxx > 0.0 ? wxy / vxx : 0.0;
+                            const double icpt = (a0 + n1) - xm * sl;
+                            pred = icpt + q[j] * sl;
+                            ss = 0.0;
+                            for (int i = 0; i < k; ++i) {
+                                const double r = yl[i] - (icpt + xs[L + i] * sl);
+                                ss += r * r;
+                            }
+                        }
+                        prob = 1.0;
+                        err = sqrt(ss / kk);  // root_mean_squared_error (gard.py:218-219)
+                    } else if (k == 1) {
                         // a single analog (best_analog, or n_analogs = 1: gard.py:291-296): the value itself, no spread
                         const double a1 = yx_all[c * T + L];
                         const bool exc = !pa.has_thresh || a1 > pa.thresh;  // gard.py:307
@@ -1391,8 +1501,8 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // mean_analogs without a threshold: statistics from the prefix sums, one pass with only xs in LDS
         const size_t lds_mean = sizeof(double) * (size_t)(T + 1);
-        const bool mean_only = mode == 0 && ((kind == SD_ANALOG_MEAN && !has_thresh) || k == 1) && st->pq != nullptr && lds_mean <= ctx->lds_max &&
-                               getenv("SD_ANALOG_NOPREFIX") == nullptr;
+        const bool mean_only = (mode == 1 ? k >= 3 : ((kind == SD_ANALOG_MEAN && !has_thresh) || k == 1)) && st->pq != nullptr &&
+                               lds_mean <= ctx->lds_max && getenv("SD_ANALOG_NOPREFIX") == nullptr;
         if (mean_only)
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean));
@@ -1407,9 +1517,10 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
             int nbc = nb;
             if ((int64_t)nbc > ((cc + 7) / 8) * 8) nbc = (int)(((cc + 7) / 8) * 8);
             if (mean_only) {
-                SD_LAUNCH(ctx, "analog_f1_mean_kernel", analog_f1_mean_kernel, dim3(nbc), dim3(nthr), lds_mean, (const double*)qc.p,
-                          Tq, T, cc, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
-                          (const double*)st->pq + 2 * cb * (T + 1), (const double*)st->ybar + cb, (const double*)st->yx + cb * T,
+                SD_LAUNCH(ctx, "analog_f1_mean_kernel", analog_f1_mean_kernel, dim3(nbc), dim3(nthr), lds_mean, mode,
+                          (const double*)qc.p, Tq, T, cc, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
+                          (const double*)st->pq + 2 * cb * (T + 1), (const double*)st->ybar + cb,
+                          (const double*)st->rx + cb * (T + 1), (const double*)st->xbar + cb, (const double*)st->yx + cb * T,
                           (const double*)st->X + cb * T,
                           (const double*)st->y + cb * T, (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb,
                           sc_d.as<double>(), sc_i.as<int32_t>(), pw);
@@ -1506,6 +1617,8 @@ int sd_analog_state_destroy(sd_analog_state* st) {
     sd_pool_release(st->ctx, st->yx);
     sd_pool_release(st->ctx, st->pq);
     sd_pool_release(st->ctx, st->ybar);
+    sd_pool_release(st->ctx, st->rx);
+    sd_pool_release(st->ctx, st->xbar);
     delete st;
     return SD_OK;
 }
@@ -1550,6 +1663,8 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->yx, sizeof(double) * (size_t)T * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->pq, sizeof(double) * 2 * (size_t)(T + 1) * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->ybar, sizeof(double) * C));
+            SD_HIP(sd_pool_malloc(ctx, (void**)&st->rx, sizeof(double) * (size_t)(T + 1) * C));
+            SD_HIP(sd_pool_malloc(ctx, (void**)&st->xbar, sizeof(double) * C));
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const int K2 = getenv("SD_ANALOG_SORT1") ? 0 : sort2_width(T, ctx->lds_max);
@@ -1568,8 +1683,8 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
             }
             if (K2 == 0) {  // (the fast sort writes the prefix sums itself)
                 const int nbp = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 2);
-                SD_LAUNCH(ctx, "analog_prefix_kernel", analog_prefix_kernel, dim3(nbp), dim3(1024), 0, (const double*)st->yx, T, C,
-                          st->pq, st->ybar);
+                SD_LAUNCH(ctx, "analog_prefix_kernel", analog_prefix_kernel, dim3(nbp), dim3(1024), 0, (const double*)st->yx,
+                          (const double*)st->xs, T, C, st->pq, st->ybar, st->rx, st->xbar);
             }
             SD_HIP(hipStreamSynchronize(ctx->stream));
         }

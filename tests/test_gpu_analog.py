@@ -103,6 +103,33 @@ def test_window_path_full_length_series(ctx, data):
     assert_close(out[:250], exp, what=f"window {data} regression")
 
 
+@pytest.mark.parametrize("case", ["exact_line", "constant_y", "dry_spells", "k2", "short"])
+def test_regression_prefix_path_edges(ctx, case):
+    """One-feature AnalogRegression takes the prefix-sum kernel (k >= 3): noise-free lines and constant analog sets
+    leave no residual for the prefix differences to resolve (direct summation branch); k = 2 stays on the
+    windowed kernel."""
+    rng = np.random.default_rng(17)
+    T, Tq, C, k = 3000, 400, 4, 30
+    X, Xq = rng.standard_normal((T, 1, C)), 1.2 * rng.standard_normal((Tq, 1, C))
+    y = 0.5 * X[:, 0, :] + rng.standard_normal((T, C))
+    if case == "exact_line":
+        y = 2.0 * X[:, 0, :] + 1.0
+    elif case == "constant_y":
+        y = np.full((T, C), 3.25)
+    elif case == "dry_spells":
+        y = np.where(X[:, 0, :] > 0.3, y, 0.0)  # every window left of 0.3 holds identical analog values
+    elif case == "k2":
+        k = 2
+    elif case == "short":
+        T, k = 40, 5
+        X, y = X[:T], y[:T]
+    st = ctx.analog_fit(X, y)
+    out, status = ctx.analogreg_predict(st, Xq, k)
+    exp = ao.pointwise_analog(X, y, Xq, k, ao.KIND_MEAN, regression=True)
+    assert (status == 0).all()
+    assert_close(out, exp, what=f"regression {case}")
+
+
 def test_cell_shard_views(ctx):
     """Cell ranges of resident fields by pointer + leading dimension (odd offset, odd leading dimension)."""
     rng = np.random.default_rng(9)
