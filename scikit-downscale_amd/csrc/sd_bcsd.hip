@@ -373,9 +373,10 @@ bool rs_one_kernel() {
     return e && e[0] == '1';
 }
 
-bool use_rs_path(int nmax) {
+bool use_rs_path(int nmax, int64_t ld_max) {
     const char* e = getenv("SD_BCSD_PATH");  // "v1" forces the generic LDS-bitonic kernels (A/B testing)
     if (e && e[0] == 'v' && e[1] == '1') return false;
+    if (ld_max >= ((int64_t)1 << 29)) return false;  // the fast kernels address rows with a 32-bit byte pitch
     return sd_bcsd_rs_supported(nmax);
 }
 
@@ -720,7 +721,7 @@ int sd_bcsd_fit_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_
     DevGroupTable gt;
     SD_TRY(upload_group_table(ctx, group_id, T, G, &gt));
     int W = 0, stride = 0;
-    const bool rs = use_rs_path(gt.nmax);
+    const bool rs = use_rs_path(gt.nmax, ld);
     const bool lng = !rs && use_long_path(gt.nmax, ctx->lds_max);
     if (!rs && !lng) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 1, &W, &stride));
     sd_bcsd_state* st = nullptr;
@@ -776,7 +777,7 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
     SD_TRY(upload_group_table(ctx, group_id_p, Tp, st->G, &gt));
     int W = 0, stride = 0;
     const int nmax_all = gt.nmax > st->nmax ? gt.nmax : st->nmax;
-    const bool rs = use_rs_path(nmax_all);
+    const bool rs = use_rs_path(nmax_all, ld > ld_out ? ld : ld_out);
     const bool lng = !rs && use_long_path(nmax_all, ctx->lds_max) && long_width(gt.nmax, ctx->lds_max) != 0;
     if (!rs && !lng) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 2, &W, &stride));
     sd_scratch status_p, status_pub;
@@ -845,7 +846,7 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
     SD_TRY(upload_group_table(ctx, group_id, T, G, &gf));
     SD_TRY(upload_group_table(ctx, group_id_p, Tp, G, &gp));
     const int nmax_all = gf.nmax > gp.nmax ? gf.nmax : gp.nmax;
-    if (!use_rs_path(nmax_all)) {
+    if (!use_rs_path(nmax_all, std::max(ld, std::max(ld_p, ld_out)))) {
         // generic path: fit then predict through a transient state
         sd_bcsd_state* st = nullptr;
         SD_TRY(sd_bcsd_fit_dev(ctx, kind, X_dev, y_dev, ld, group_id, G, T, C, return_anoms, &st));

@@ -152,6 +152,16 @@ struct TileRegs {
     double v0[RPT], v1[RPT];
 };
 
+// address of row ti of a [rows, ld] field, cp = pointer to the tile's column in row 0: one v_mad_u64_u32 (the
+// launcher guarantees 0 <= ti and 8 * ld < 2^32; the int64 product costs three quarter-rate multiplies per row)
+__device__ __forceinline__ const double* row_of(const double* cp, int ti, int64_t ld) {
+    const uint64_t off = (uint64_t)(uint32_t)ti * (uint64_t)(uint32_t)((uint32_t)ld * 8u);
+    return reinterpret_cast<const double*>(reinterpret_cast<const char*>(cp) + off);
+}
+__device__ __forceinline__ double* row_of(double* cp, int ti, int64_t ld) {
+    return const_cast<double*>(row_of(const_cast<const double*>(cp), ti, ld));
+}
+
 template <int RPT>
 __device__ __forceinline__ void tile_issue(const double* __restrict__ src, int64_t ld, const int32_t* __restrict__ ord,
                                            int nrows, int64_t c0, int64_t C, bool vec_ok, TileRegs<RPT>& t, int rmask = -1) {
@@ -168,14 +178,14 @@ __device__ __forceinline__ void tile_issue(const double* __restrict__ src, int64
     if (full) {
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const double2 v = *reinterpret_cast<const double2*>(src + (int64_t)ti[k] * ld + c);
+            const double2 v = *reinterpret_cast<const double2*>(row_of(src + c, ti[k], ld));
             t.v0[k] = v.x;
             t.v1[k] = v.y;
         }
     } else {
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const double* p = src + (int64_t)ti[k] * ld + c;
+            const double* p = row_of(src + c, ti[k], ld);
             t.v0[k] = c < C ? p[0] : 0.0;
             t.v1[k] = c + 1 < C ? p[1] : 0.0;
         }
@@ -224,7 +234,7 @@ __device__ __forceinline__ void store_tile(double* __restrict__ dst, int64_t ld,
     const bool full = vec_ok && c + 1 < C;
 #pragma unroll 4
     for (int r = rr; r < nrows; r += kRowsPerPass) {
-        double* p = dst + (int64_t)ord[r] * ld + c;
+        double* p = row_of(dst + c, ord[r], ld);
         if (full) {
             *reinterpret_cast<double2*>(p) = make_double2(s0[r], s1[r]);
         } else {

@@ -79,6 +79,8 @@ struct sd_analog_state {
     double* ybar = nullptr; // device [C]: mean of y
     double* rx = nullptr;   // device [C][T+1]: exclusive prefix sums of (xs - xbar)(yx - ybar) (one-feature AnalogRegression)
     double* xbar = nullptr; // device [C]: mean of x
+    // F > 1 slab search: training points sorted by feature 0 (original indices in xi)
+    double* ps = nullptr;   // device [C][F][T]
 };
 
 int sd_set_error(int code, const char* fmt, ...);

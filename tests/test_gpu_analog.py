@@ -130,6 +130,49 @@ def test_regression_prefix_path_edges(ctx, case):
     assert_close(out, exp, what=f"regression {case}")
 
 
+@pytest.mark.parametrize("F,T,Tq,C,k,data", [
+    (3, 5000, 700, 3, 30, "normal"),     # slab much narrower than the series
+    (3, 6000, 5000, 2, 30, "normal"),    # enough queries for the class order by default
+    (2, 3000, 333, 2, 7, "quantized"),   # ties on the sort axis and in the distances
+    (4, 200, 65, 2, 200, "normal"),      # k == T: every point is a neighbour, both sides run to the ends
+    (2, 64, 64, 2, 5, "normal"),         # one chunk
+    (3, 200, 100, 4500, 4, "normal"),    # more cells than one staging chunk
+])
+def test_slab_search_matches_full_scan(ctx, monkeypatch, F, T, Tq, C, k, data):
+    """F > 1: the feature-0 slab search (training points and queries sorted by feature 0, scan ends when the axis
+    distance alone exceeds every k-th distance) selects bit-identical (rdist, index) lists to the full scan and
+    to the oracle's brute force."""
+    rng = np.random.default_rng(F * 1000 + T)
+    X, Xq = rng.standard_normal((T, F, C)), 1.2 * rng.standard_normal((Tq, F, C))
+    if data == "quantized":
+        X, Xq = np.round(X * 4) / 4, np.round(Xq * 4) / 4  # dyadic grid: squared distances are exact
+    y = rng.standard_normal((T, C))
+    Xq[3, F - 1, 0] = np.nan  # one query without neighbours
+    monkeypatch.delenv("SD_ANALOG_NOSLAB", raising=False)
+    st = ctx.analog_fit(X, y)
+    out, status, inds, dist = ctx.analog_predict(st, Xq, k, 3, want_neighbors=True)
+    # the query order (classes by the other features, then feature 0) only groups the work: any class count agrees
+    monkeypatch.setenv("SD_ANALOG_SLAB_CLASSES", "8" if Tq < 4096 else "1")
+    out8, _, inds8, dist8 = ctx.analog_predict(st, Xq, k, 3, want_neighbors=True)
+    monkeypatch.delenv("SD_ANALOG_SLAB_CLASSES")
+    ok8 = np.arange(Tq) != 3
+    assert np.array_equal(inds8[ok8], inds[ok8]) and np.array_equal(dist8[ok8], dist[ok8]) and np.array_equal(out8[ok8], out[ok8])
+    monkeypatch.setenv("SD_ANALOG_NOSLAB", "1")
+    st0 = ctx.analog_fit(X, y)
+    out0, status0, inds0, dist0 = ctx.analog_predict(st0, Xq, k, 3, want_neighbors=True)
+    monkeypatch.delenv("SD_ANALOG_NOSLAB")
+    ok = np.ones(Tq, bool)
+    ok[3] = False
+    assert status.tolist() == status0.tolist() and status[0] == 2
+    assert np.array_equal(inds[ok], inds0[ok]) and np.array_equal(inds[3, :, 1:], inds0[3, :, 1:])
+    assert np.array_equal(dist[ok], dist0[ok])
+    assert np.array_equal(out[ok], out0[ok]) and np.isnan(out[3, :, 0]).all()
+    for c in range(min(C, 2)):
+        d, i = ao.knn(X[:, :, c], Xq[ok][:, :, c], k)
+        assert np.array_equal(inds[ok][:, :, c], i)
+        assert np.array_equal(dist[ok][:, :, c], d)
+
+
 def test_cell_shard_views(ctx):
     """Cell ranges of resident fields by pointer + leading dimension (odd offset, odd leading dimension)."""
     rng = np.random.default_rng(9)
