@@ -68,6 +68,14 @@ extern "C" {
 #define SD_QM_EDCDF_DIFFERENCE 1 /* EquidistantCdfMatcher(kind='difference') */
 #define SD_QM_EDCDF_RATIO 2      /* EquidistantCdfMatcher(kind='ratio') */
 
+/* CunnaneTransformer (sd_qm_cunnane): direction and tail handling (quantile.py:424, 485-486, 527-528) */
+#define SD_CUNNANE_FORWARD 0 /* transform: values -> plotting positions */
+#define SD_CUNNANE_INVERSE 1 /* inverse_transform: plotting positions -> values */
+#define SD_EXTRAP_NONE 0     /* extrapolate=None or '1to1': np.interp clamps at both ends */
+#define SD_EXTRAP_MIN 1      /* lower tail extended */
+#define SD_EXTRAP_MAX 2      /* upper tail extended */
+#define SD_EXTRAP_BOTH 3
+
 /* synthetic field kinds (sd_synth_fill) */
 #define SD_SYNTH_GAUSS 0
 #define SD_SYNTH_PRECIP 1
@@ -171,6 +179,17 @@ int sd_qm_predict(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_one,
                   double* out, int32_t* cell_status);
 int sd_qm_predict_dev(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_one, const double* Xp_dev,
                       int64_t ld, int64_t Tp, double* out_dev, int64_t ld_out, int32_t* cell_status);
+/* CunnaneTransformer.transform / inverse_transform (quantile.py:465-545) on the sorted X of a fitted state
+ * (sd_qm_fit accepts y = NULL for this use).  X: [Tp, C]; out: [Tp, C].
+ * FORWARD: np.interp(x, sorted X, Cunnane positions); a value beyond an extended tail yields -inf / +inf (the
+ * reference's own tail code for this direction, quantile.py:497/501, cannot run: it calls .values on an ndarray).
+ * INVERSE: np.interp(p, positions, sorted X); beyond an extended tail the centred least-squares line through the
+ * n_endpoints first / last (position, value) pairs (quantile.py:532-543). */
+int sd_qm_cunnane(sd_ctx* ctx, const sd_qm_state* st, int direction, int extrapolate, int n_endpoints, const double* X,
+                  int64_t Tp, double* out, int32_t* cell_status);
+int sd_qm_cunnane_dev(sd_ctx* ctx, const sd_qm_state* st, int direction, int extrapolate, int n_endpoints,
+                      const double* X_dev, int64_t ld, int64_t Tp, double* out_dev, int64_t ld_out,
+                      int32_t* cell_status);
 int sd_qm_state_info(const sd_qm_state* st, int64_t* T, int64_t* C);
 /* sorted fit series [C][T] (cell-major) and per-cell status; any pointer may be NULL */
 int sd_qm_state_export(const sd_qm_state* st, double* x_sorted, double* y_sorted, int32_t* cell_status);

@@ -1,9 +1,10 @@
 """TEST INFRASTRUCTURE ONLY -- NumPy restatement of the reference's quantile-mapping regressors.
 
 Follows ``/root/reference/skdownscale/pointwise_models/quantile.py``:
-``QuantileMappingReressor`` (160-395) and ``EquidistantCdfMatcher`` (556-636), one cell at a time,
-plus a grid driver over the cell axis like ``core.py:86-96,137-141``.  Pinned by
-``tests/golden/g9_qm.npz`` (generated from the real reference by ``tests/golden/make_golden.py``).
+``QuantileMappingReressor`` (160-395), ``EquidistantCdfMatcher`` (556-636) and ``CunnaneTransformer``
+(398-553), one cell at a time, plus a grid driver over the cell axis like ``core.py:86-96,137-141``.
+Pinned by ``tests/golden/g9_qm.npz`` and ``g10_cunnane.npz`` (generated from the real reference by
+``tests/golden/make_golden.py``).
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s CPU baseline may import this module.
 """
 from __future__ import annotations
@@ -133,4 +134,61 @@ def pointwise_qm(model, X, y, Xp, extrapolate=None, n_endpoints=10, kind="differ
             out[:, c] = qmr_predict(st, Xp[:, c], extrapolate, n_endpoints)
         else:
             out[:, c] = ecm_predict(st, Xp[:, c], kind, extrapolate, n_endpoints)
+    return out
+
+
+# ---- CunnaneTransformer (quantile.py:398-553) -------------------------------------------------------
+
+def _np_interp(x, xp, fp, left, right):
+    """``np.interp`` spelled out (numpy ``arr_interp``): last node <= x, exact hit returns the node value."""
+    x = np.asarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    n = len(xp)
+    for i, v in enumerate(x):
+        if v != v:
+            out[i] = v
+        elif v < xp[0]:
+            out[i] = left
+        elif v > xp[-1]:
+            out[i] = right
+        elif v == xp[-1]:
+            out[i] = fp[-1]
+        else:
+            j = int(np.searchsorted(xp, v, side="right")) - 1
+            if xp[j] == v or j == n - 1:
+                out[i] = fp[j]
+            else:
+                slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j])
+                out[i] = slope * (v - xp[j]) + fp[j]
+    return out
+
+
+def cunnane_fit(X):
+    """quantile.py:438-463: (plotting positions, sorted sample)."""
+    vals = np.sort(np.asarray(X, dtype=np.float64).ravel())
+    return plotting_positions(len(vals)), vals
+
+
+def cunnane_transform(cdf, X, extrapolate="both"):
+    """quantile.py:465-503 for the samples it can serve: a value beyond an extended tail comes back as -inf / +inf
+    (the reference's branch for those, 490-501, raises AttributeError on the ndarray ``check_array`` returned)."""
+    pp, vals = cdf
+    left = -np.inf if extrapolate in ("min", "both") else pp[0]
+    right = np.inf if extrapolate in ("max", "both") else pp[-1]
+    return _np_interp(X, vals, pp, left, right)
+
+
+def cunnane_inverse(cdf, P, extrapolate="both", n_endpoints=10):
+    """quantile.py:523-545: np.interp on the position grid, least-squares tails through the outermost points."""
+    pp, vals = cdf
+    P = np.asarray(P, dtype=np.float64)
+    lo_ext, hi_ext = extrapolate in ("min", "both"), extrapolate in ("max", "both")
+    out = _np_interp(P, pp, vals, -np.inf if lo_ext else vals[0], np.inf if hi_ext else vals[-1])
+    lower, upper = out == -np.inf, out == np.inf
+    if lower.any():
+        s = slice(None, n_endpoints)
+        out[lower] = ols_predict(pp[s], vals[s], P[lower])
+    if upper.any():
+        s = slice(-n_endpoints, None)
+        out[upper] = ols_predict(pp[s], vals[s], P[upper])
     return out

@@ -256,6 +256,84 @@ __global__ void __launch_bounds__(1024) qm_map_kernel(int model, int one_to_one,
     }
 }
 
+// CunnaneTransformer.transform / inverse_transform (quantile.py:465-545) for every sample of a cell.  One workgroup
+// per cell; the forward direction keeps the sorted fit values in LDS for the value -> index search, the inverse
+// direction finds its bracket analytically on the Cunnane grid.  Tails (inverse): centred least squares through the
+// first / last e = min(n_endpoints, n) (position, value) pairs, as sklearn's LinearRegression solves it.
+__global__ void __launch_bounds__(1024) qm_cunnane_kernel(int direction, int ext_lo, int ext_hi, int n_end,
+                                                          const double* __restrict__ qc /* [C][Tp] */,
+                                                          const double* __restrict__ xs_all, int64_t T, int64_t Tp, int64_t C,
+                                                          double* __restrict__ oc /* [C][Tp] */) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* xl = reinterpret_cast<double*>(smem_raw);  // forward: n sorted fit values
+    __shared__ double line[4];                          // inverse: (slope, intercept) of the lower and upper tail
+    const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x;
+    const double dn = pp_denom(n);
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const double* xs = xs_all + c * T;
+        __syncthreads();
+        if (direction == 0) {
+            for (int i = tid; i < n; i += nthr) xl[i] = xs[i];
+        } else if (tid < 2 && (tid == 0 ? ext_lo : ext_hi)) {
+            const int e = n_end < n ? n_end : n, first = tid == 0 ? 0 : n - e;
+            double pm = 0.0, vm = 0.0;
+            for (int i = 0; i < e; ++i) {
+                pm += pp_at(first + i, dn);
+                vm += xs[first + i];
+            }
+            pm /= (double)e;
+            vm /= (double)e;
+            double spp = 0.0, spv = 0.0;
+            for (int i = 0; i < e; ++i) {
+                const double dp = pp_at(first + i, dn) - pm;
+                spp += dp * dp;
+                spv += dp * (xs[first + i] - vm);
+            }
+            const double slope = spp > 0.0 ? spv / spp : 0.0;
+            line[2 * tid] = slope;
+            line[2 * tid + 1] = vm - slope * pm;
+        }
+        __syncthreads();
+        const double x_min = xs[0], x_max = xs[n - 1];
+        for (int64_t tq = tid; tq < Tp; tq += nthr) {
+            const double x = qc[c * Tp + tq];
+            double res;
+            if (direction == 0) {
+                if (x != x) {
+                    res = x;
+                } else if (x < x_min) {
+                    res = ext_lo ? -inf : pp_at(0, dn);
+                } else if (x >= x_max) {
+                    res = (x > x_max && ext_hi) ? inf : pp_at(n - 1, dn);
+                } else {
+                    int pos = -1;  // last index known to hold a value <= x
+                    for (int len = n; len > 1;) {
+                        int half = len >> 1;
+                        if ((half & 15) == 0) --half;
+                        len -= half;
+                        pos += xl[pos + half] <= x ? half : 0;
+                    }
+                    const int j = pos + (xl[pos + 1] <= x ? 1 : 0);  // in [0, n-2] here
+                    const double x0 = xl[j];
+                    if (x0 == x) {
+                        res = pp_at(j, dn);
+                    } else {
+                        const double slope = (pp_at(j + 1, dn) - pp_at(j, dn)) / (xl[j + 1] - x0);
+                        res = slope * (x - x0) + pp_at(j, dn);
+                    }
+                }
+            } else {
+                if (x != x) res = x;
+                else if (x < pp_at(0, dn) && ext_lo) res = line[0] * x + line[1];
+                else if (x > pp_at(n - 1, dn) && ext_hi) res = line[2] * x + line[3];
+                else res = interp_on_grid(x, n, dn, xs);
+            }
+            oc[c * Tp + tq] = res;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) qm_status_public_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b,
                                                                int64_t C, int32_t* __restrict__ outp) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -336,6 +414,7 @@ int sd_qm_state_export(const sd_qm_state* st, double* x_sorted, double* y_sorted
     SD_HIP(hipSetDevice(ctx->device));
     const size_t bytes = sizeof(double) * (size_t)st->T * st->C;
     if (x_sorted) SD_HIP(hipMemcpyAsync(x_sorted, st->xs, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SD_CHECK_ARG(!y_sorted || st->ys, "sd_qm_state_export: the state was fitted without y");
     if (y_sorted) SD_HIP(hipMemcpyAsync(y_sorted, st->ys, bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (cell_status) {
         std::vector<int32_t> bits(st->C);
@@ -348,7 +427,7 @@ int sd_qm_state_export(const sd_qm_state* st, double* x_sorted, double* y_sorted
 }
 
 int sd_qm_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t ld, int64_t T, int64_t C, sd_qm_state** out) {
-    SD_CHECK_ARG(ctx && X_dev && y_dev && out, "sd_qm_fit: NULL argument");
+    SD_CHECK_ARG(ctx && X_dev && out, "sd_qm_fit: NULL argument");  // y may be NULL (CunnaneTransformer: only the X CDF)
     SD_CHECK_ARG(T >= 2 && C > 0 && ld >= C, "sd_qm_fit: bad sizes");
     *out = nullptr;
     SD_HIP(hipSetDevice(ctx->device));
@@ -360,14 +439,16 @@ int sd_qm_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t
     st->C = C;
     auto body = [&]() -> int {
         SD_HIP(sd_pool_malloc(ctx, (void**)&st->xs, sizeof(double) * (size_t)T * C));
-        SD_HIP(sd_pool_malloc(ctx, (void**)&st->ys, sizeof(double) * (size_t)T * C));
+        if (y_dev) SD_HIP(sd_pool_malloc(ctx, (void**)&st->ys, sizeof(double) * (size_t)T * C));
         SD_HIP(sd_pool_malloc(ctx, (void**)&st->status, sizeof(int32_t) * C));
         SD_HIP(hipMemsetAsync(st->status, 0, sizeof(int32_t) * C, ctx->stream));
         dim3 grid((unsigned)((C + 31) / 32), (unsigned)((T + 31) / 32));
         SD_LAUNCH(ctx, "qm_transpose_kernel", qm_transpose_kernel, grid, dim3(256), 0, X_dev, ld, T, C, st->xs, st->status, 1);
-        SD_LAUNCH(ctx, "qm_transpose_kernel", qm_transpose_kernel, grid, dim3(256), 0, y_dev, ld, T, C, st->ys, st->status, 0);
         QM_DISPATCH_K(K, launch_sort, ctx, st->xs, T, C);
-        QM_DISPATCH_K(K, launch_sort, ctx, st->ys, T, C);
+        if (y_dev) {
+            SD_LAUNCH(ctx, "qm_transpose_kernel", qm_transpose_kernel, grid, dim3(256), 0, y_dev, ld, T, C, st->ys, st->status, 0);
+            QM_DISPATCH_K(K, launch_sort, ctx, st->ys, T, C);
+        }
         SD_HIP(hipStreamSynchronize(ctx->stream));
         return SD_OK;
     };
@@ -381,22 +462,25 @@ int sd_qm_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t
 }
 
 int sd_qm_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int64_t C, sd_qm_state** out) {
-    SD_CHECK_ARG(ctx && X && y && out, "sd_qm_fit: NULL argument");
+    SD_CHECK_ARG(ctx && X && out, "sd_qm_fit: NULL argument");
     SD_CHECK_ARG(T >= 2 && C > 0, "sd_qm_fit: bad sizes");
     SD_HIP(hipSetDevice(ctx->device));
     sd_scratch dX, dy;
     const size_t bytes = sizeof(double) * (size_t)T * C;
     SD_HIP(dX.alloc(ctx, bytes));
-    SD_HIP(dy.alloc(ctx, bytes));
     SD_HIP(hipMemcpyAsync(dX.p, X, bytes, hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(hipMemcpyAsync(dy.p, y, bytes, hipMemcpyHostToDevice, ctx->stream));
-    return sd_qm_fit_dev(ctx, dX.as<double>(), dy.as<double>(), C, T, C, out);
+    if (y) {
+        SD_HIP(dy.alloc(ctx, bytes));
+        SD_HIP(hipMemcpyAsync(dy.p, y, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return sd_qm_fit_dev(ctx, dX.as<double>(), y ? dy.as<double>() : nullptr, C, T, C, out);
 }
 
 int sd_qm_predict_dev(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_one, const double* Xp_dev, int64_t ld,
                       int64_t Tp, double* out_dev, int64_t ld_out, int32_t* cell_status) {
     SD_CHECK_ARG(ctx && st && Xp_dev && out_dev, "sd_qm_predict: NULL argument");
     SD_CHECK_ARG(model >= SD_QM_REGRESSOR && model <= SD_QM_EDCDF_RATIO, "sd_qm_predict: unknown model %d", model);
+    SD_CHECK_ARG(st->ys, "sd_qm_predict: the state was fitted without y");
     SD_CHECK_ARG(Tp > 0 && ld >= st->C && ld_out >= st->C, "sd_qm_predict: bad sizes");
     SD_HIP(hipSetDevice(ctx->device));
     const int64_t C = st->C, T = st->T;
@@ -444,6 +528,58 @@ int sd_qm_predict(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_one,
     SD_HIP(dout.alloc(ctx, bytes));
     SD_HIP(hipMemcpyAsync(dX.p, Xp, bytes, hipMemcpyHostToDevice, ctx->stream));
     SD_TRY(sd_qm_predict_dev(ctx, st, model, one_to_one, dX.as<double>(), st->C, Tp, dout.as<double>(), st->C, cell_status));
+    SD_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_qm_cunnane_dev(sd_ctx* ctx, const sd_qm_state* st, int direction, int extrapolate, int n_endpoints, const double* X_dev,
+                      int64_t ld, int64_t Tp, double* out_dev, int64_t ld_out, int32_t* cell_status) {
+    SD_CHECK_ARG(ctx && st && X_dev && out_dev, "sd_qm_cunnane: NULL argument");
+    SD_CHECK_ARG(direction == SD_CUNNANE_FORWARD || direction == SD_CUNNANE_INVERSE, "sd_qm_cunnane: unknown direction %d", direction);
+    SD_CHECK_ARG(extrapolate >= SD_EXTRAP_NONE && extrapolate <= SD_EXTRAP_BOTH, "sd_qm_cunnane: unknown extrapolate code %d", extrapolate);
+    SD_CHECK_ARG(n_endpoints >= 1, "sd_qm_cunnane: n_endpoints must be positive");
+    SD_CHECK_ARG(Tp > 0 && ld >= st->C && ld_out >= st->C, "sd_qm_cunnane: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    const int64_t C = st->C, T = st->T;
+    const size_t lds = direction == SD_CUNNANE_FORWARD ? sizeof(double) * (size_t)T : 8;
+    SD_CHECK_ARG(lds <= ctx->lds_max, "sd_qm_cunnane: fitted series too long for the LDS-resident search");
+    sd_scratch qc, oc, status_p, status_pub;
+    SD_HIP(qc.alloc(ctx, sizeof(double) * (size_t)Tp * C));
+    SD_HIP(oc.alloc(ctx, sizeof(double) * (size_t)Tp * C));
+    SD_HIP(status_p.alloc(ctx, sizeof(int32_t) * C));
+    SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
+    dim3 grid((unsigned)((C + 31) / 32), (unsigned)((Tp + 31) / 32));
+    SD_LAUNCH(ctx, "qm_transpose_kernel", qm_transpose_kernel, grid, dim3(256), 0, X_dev, ld, Tp, C, qc.as<double>(),
+              status_p.as<int32_t>(), 0);
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qm_cunnane_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nb = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * (lds > ctx->lds_max / 2 ? 1 : 2));
+    SD_LAUNCH(ctx, "qm_cunnane_kernel", qm_cunnane_kernel, dim3(nb), dim3(1024), lds, direction, extrapolate & SD_EXTRAP_MIN,
+              extrapolate & SD_EXTRAP_MAX, n_endpoints, (const double*)qc.p, (const double*)st->xs, T, Tp, C, oc.as<double>());
+    SD_LAUNCH(ctx, "qm_untranspose_kernel", qm_untranspose_kernel, grid, dim3(256), 0, (const double*)oc.p, Tp, C, out_dev, ld_out,
+              (const int32_t*)st->status, (const int32_t*)status_p.p);
+    if (cell_status) {
+        SD_HIP(status_pub.alloc(ctx, sizeof(int32_t) * C));
+        SD_LAUNCH(ctx, "qm_status_public_kernel", qm_status_public_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
+                  (const int32_t*)st->status, (const int32_t*)status_p.p, C, status_pub.as<int32_t>());
+        SD_HIP(hipMemcpyAsync(cell_status, status_pub.p, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_qm_cunnane(sd_ctx* ctx, const sd_qm_state* st, int direction, int extrapolate, int n_endpoints, const double* X, int64_t Tp,
+                  double* out, int32_t* cell_status) {
+    SD_CHECK_ARG(ctx && st && X && out, "sd_qm_cunnane: NULL argument");
+    SD_CHECK_ARG(Tp > 0, "sd_qm_cunnane: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_scratch dX, dout;
+    const size_t bytes = sizeof(double) * (size_t)Tp * st->C;
+    SD_HIP(dX.alloc(ctx, bytes));
+    SD_HIP(dout.alloc(ctx, bytes));
+    SD_HIP(hipMemcpyAsync(dX.p, X, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_qm_cunnane_dev(ctx, st, direction, extrapolate, n_endpoints, dX.as<double>(), st->C, Tp, dout.as<double>(), st->C,
+                             cell_status));
     SD_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(hipStreamSynchronize(ctx->stream));
     return SD_OK;

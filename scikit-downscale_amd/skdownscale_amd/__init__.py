@@ -7,7 +7,8 @@ from .bcsd import BcsdGridModel, BcsdPrecipitation, BcsdTemperature
 from .core import GridArray, GridDataset, PointWiseDownscaler
 from .gard import AnalogGridModel, AnalogRegression, PureAnalog
 from .groupers import DAY_GROUPER, MONTH_GROUPER
-from .quantile import EquidistantCdfMatcher, QmGridModel, QuantileMapper, QuantileMappingReressor
+from .quantile import (CunnaneGridModel, CunnaneTransformer, EquidistantCdfMatcher, QmGridModel, QuantileMapper,
+                       QuantileMappingReressor)
 
 __all__ = [
     "AnalogRegression",
@@ -25,5 +26,7 @@ __all__ = [
     "QuantileMapper",
     "EquidistantCdfMatcher",
     "QmGridModel",
+    "CunnaneTransformer",
+    "CunnaneGridModel",
 ]
 __version__ = "0.1.0"

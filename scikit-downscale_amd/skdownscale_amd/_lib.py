@@ -19,6 +19,8 @@ BCSD_TAS, BCSD_PR = 0, 1
 CELL_OK, CELL_MASKED, CELL_NONFINITE, CELL_BAD_CLIMO = 0, 1, 2, 3
 ANALOG_BEST, ANALOG_SAMPLE, ANALOG_WEIGHT, ANALOG_MEAN = 0, 1, 2, 3
 QM_REGRESSOR, QM_EDCDF_DIFFERENCE, QM_EDCDF_RATIO = 0, 1, 2
+CUNNANE_FORWARD, CUNNANE_INVERSE = 0, 1
+EXTRAP_CODES = {None: 0, "1to1": 0, "min": 1, "max": 2, "both": 3}  # SD_EXTRAP_*
 SYNTH_GAUSS, SYNTH_PRECIP = 0, 1
 
 _p = C.c_void_p
@@ -70,6 +72,8 @@ SIGNATURES = {
     "sd_qm_fit_dev": [_p, _p, _p, _i64, _i64, _i64, C.POINTER(_p)],
     "sd_qm_predict": [_p, _p, _int, _int, _p, _i64, _p, _p],
     "sd_qm_predict_dev": [_p, _p, _int, _int, _p, _i64, _i64, _p, _i64, _p],
+    "sd_qm_cunnane": [_p, _p, _int, _int, _int, _p, _i64, _p, _p],
+    "sd_qm_cunnane_dev": [_p, _p, _int, _int, _int, _p, _i64, _i64, _p, _i64, _p],
     "sd_qm_state_info": [_p, C.POINTER(_i64), C.POINTER(_i64)],
     "sd_qm_state_export": [_p, _p, _p, _p],
     "sd_qm_state_destroy": [_p],

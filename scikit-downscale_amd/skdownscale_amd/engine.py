@@ -129,11 +129,12 @@ class QmState(_State):
         check(self.ctx.lib.sd_qm_state_info(self.vptr, C.byref(T), C.byref(Cc)))
         return dict(T=T.value, C=Cc.value)
 
-    def export(self):
+    def export(self, with_y=True):
         i = self.info()
-        xs, ys = np.empty((i["C"], i["T"])), np.empty((i["C"], i["T"]))
+        xs = np.empty((i["C"], i["T"]))
+        ys = np.empty((i["C"], i["T"])) if with_y else None
         status = np.empty(i["C"], dtype=np.int32)
-        check(self.ctx.lib.sd_qm_state_export(self.vptr, ptr(xs), ptr(ys), ptr(status)))
+        check(self.ctx.lib.sd_qm_state_export(self.vptr, ptr(xs), None if ys is None else ptr(ys), ptr(status)))
         return dict(x_sorted=xs, y_sorted=ys, status=status)
 
 
@@ -272,18 +273,38 @@ class Context:
         return BcsdState(self, h.value, self.lib.sd_bcsd_state_destroy)
 
     # ---- quantile-mapping regressors ----
-    def qm_fit(self, X, y):
-        """X, y [T, C] numpy or DeviceArray -> QmState (sorted series per cell)."""
+    def qm_fit(self, X, y=None):
+        """X, y [T, C] numpy or DeviceArray -> QmState (sorted series per cell); y=None keeps only the CDF of X
+        (CunnaneTransformer)."""
         h = C.c_void_p()
-        if isinstance(y, DeviceArray):
-            T, Cc = y.shape
-            assert X.ld == y.ld
-            check(self.lib.sd_qm_fit_dev(self.handle, X.vptr, y.vptr, y.ld, T, Cc, C.byref(h)))
+        if isinstance(X, DeviceArray):
+            T, Cc = X.shape
+            assert y is None or X.ld == y.ld
+            check(self.lib.sd_qm_fit_dev(self.handle, X.vptr, None if y is None else y.vptr, X.ld, T, Cc, C.byref(h)))
         else:
-            X, y = _lib.as_f64(X), _lib.as_f64(y)
-            T, Cc = y.shape
-            check(self.lib.sd_qm_fit(self.handle, ptr(X), ptr(y), T, Cc, C.byref(h)))
+            X = _lib.as_f64(X)
+            y = None if y is None else _lib.as_f64(y)
+            T, Cc = X.shape
+            check(self.lib.sd_qm_fit(self.handle, ptr(X), None if y is None else ptr(y), T, Cc, C.byref(h)))
         return QmState(self, h.value, self.lib.sd_qm_state_destroy)
+
+    def qm_cunnane(self, state, direction, X, extrapolate="both", n_endpoints=10, out=None):
+        """CunnaneTransformer.transform (direction 0) / inverse_transform (1) of X [Tp, C] on the fitted CDFs."""
+        Cc = state.info()["C"]
+        status = np.empty(Cc, dtype=np.int32)
+        code = _lib.EXTRAP_CODES[extrapolate]
+        if isinstance(X, DeviceArray):
+            Tp = X.shape[0]
+            out = self.empty((Tp, Cc)) if out is None else out
+            check(self.lib.sd_qm_cunnane_dev(self.handle, state.vptr, int(direction), code, int(n_endpoints), X.vptr, X.ld, Tp,
+                                             out.vptr, out.ld, ptr(status)))
+        else:
+            X = _lib.as_f64(X)
+            Tp = X.shape[0]
+            out = np.empty((Tp, Cc))
+            check(self.lib.sd_qm_cunnane(self.handle, state.vptr, int(direction), code, int(n_endpoints), ptr(X), Tp, ptr(out),
+                                         ptr(status)))
+        return out, status
 
     def qm_predict(self, state, model, Xp, one_to_one=False, out=None):
         Cc = state.info()["C"]

@@ -103,6 +103,112 @@ class QuantileMapper(TransformerMixin, BaseEstimator):
         return replace(tags, _skip_test="QuantileMapper only supports 1 feature and has temporal dependencies")
 
 
+class CunnaneTransformer(TransformerMixin, BaseEstimator):
+    """Quantile transform using Cunnane plotting positions with optional extrapolation (quantile.py:398-553).
+
+    ``fit`` keeps the sorted sample and its plotting positions (``cdf_``); ``transform`` maps values to positions with
+    ``np.interp`` semantics, ``inverse_transform`` maps positions to values, with the tails selected by ``extrapolate``
+    extended by a least-squares line through the ``n_endpoints`` outermost points.  All three run on the HIP engine
+    (``sd_qm_fit`` / ``sd_qm_cunnane``)."""
+
+    _fit_attributes = ["cdf_"]
+
+    def __init__(self, *, alpha=0.4, beta=0.4, extrapolate="both", n_endpoints=10):
+        self.alpha = alpha
+        self.beta = beta
+        self.extrapolate = extrapolate
+        self.n_endpoints = n_endpoints
+
+    def _check(self):
+        # (alpha / beta are accepted and, as in the reference, unused: fit calls plotting_positions(len(X)) with its
+        # defaults, quantile.py:462)
+        if self.extrapolate not in _lib.EXTRAP_CODES:
+            raise ValueError(f"unknown value for extrapolate: {self.extrapolate}")
+
+    def fit(self, X, y=None):
+        self._check()
+        X = check_array(X, ensure_2d=True)
+        if X.shape[1] > 1:
+            raise ValueError("CunnaneTransformer.fit() only supports a single feature")
+        Xv = np.ascontiguousarray(X[:, :1], dtype=np.float64)
+        if len(Xv) < 2:
+            raise ValueError("CunnaneTransformer.fit() needs at least 2 samples on the HIP engine")
+        self._state = default_context().qm_fit(Xv)
+        self.cdf_ = Cdf(plotting_positions(len(Xv)), self._state.export(with_y=False)["x_sorted"][0])
+        self.n_features_in_ = 1
+        return self
+
+    def _apply(self, direction, X):
+        if not hasattr(self, "cdf_"):
+            raise NotFittedError(
+                f"This {type(self).__name__} instance is not fitted yet. Call 'fit' with appropriate arguments before using this estimator.")
+        self._check()
+        Xv = np.ascontiguousarray(X[:, :1], dtype=np.float64)
+        ctx = default_context()
+        if getattr(self, "_state", None) is None:  # unpickled: rebuild the device state from the fitted CDF
+            self._state = ctx.qm_fit(np.asarray(self.cdf_.vals, dtype=np.float64).reshape(-1, 1))
+        out, _ = ctx.qm_cunnane(self._state, direction, Xv, self.extrapolate, self.n_endpoints)
+        return out
+
+    def transform(self, X):
+        X = check_array(X, ensure_2d=True)
+        if X.shape[1] > 1:
+            raise ValueError("CunnaneTransformer.transform() only supports a single feature")
+        pps = self._apply(_lib.CUNNANE_FORWARD, X)
+        if np.isinf(pps).any():
+            # values beyond an extended tail: the reference fails here too (quantile.py:497/501 call ``.values`` on the
+            # ndarray that check_array returned)
+            raise AttributeError("'numpy.ndarray' object has no attribute 'values' (CunnaneTransformer.transform of values outside "
+                                 f"the fitted range with extrapolate={self.extrapolate!r}: quantile.py:497)")
+        return pps
+
+    def fit_transform(self, X, y=None):
+        return self.fit(X).transform(X)
+
+    def inverse_transform(self, X):
+        X = check_array(X, ensure_2d=True)
+        return self._apply(_lib.CUNNANE_INVERSE, X)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_state", None)
+        return d
+
+    def __sklearn_tags__(self):
+        from dataclasses import replace
+
+        tags = super().__sklearn_tags__()
+        return replace(tags, _skip_test="CunnaneTransformer only supports 1 feature")
+
+
+class CunnaneGridModel:
+    """Batched CunnaneTransformer over the cell axis: X [T, C] (numpy or DeviceArray), one CDF per cell."""
+
+    def __init__(self, extrapolate="both", n_endpoints=10, ctx=None):
+        if extrapolate not in _lib.EXTRAP_CODES:
+            raise ValueError(f"unknown value for extrapolate: {extrapolate}")
+        self.extrapolate = extrapolate
+        self.n_endpoints = int(n_endpoints)
+        self.ctx = ctx or default_context()
+        self.state = None
+
+    def fit(self, X):
+        self.state = self.ctx.qm_fit(X)
+        return self
+
+    def _apply(self, direction, X, out):
+        if self.state is None:
+            raise NotFittedError("This Cunnane grid model is not fitted yet.")
+        return self.ctx.qm_cunnane(self.state, direction, X, self.extrapolate, self.n_endpoints, out=out)
+
+    def transform(self, X, out=None):
+        """positions [Tp, C]; values beyond an extended tail come back as -inf / +inf (see CunnaneTransformer.transform)"""
+        return self._apply(_lib.CUNNANE_FORWARD, X, out)
+
+    def inverse_transform(self, P, out=None):
+        return self._apply(_lib.CUNNANE_INVERSE, P, out)
+
+
 class QmGridModel:
     """Batched quantile-mapping regressor over the cell axis: X, y [T, C], Xp [Tp, C] (numpy or DeviceArray)."""
 

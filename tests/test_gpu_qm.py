@@ -135,3 +135,78 @@ def test_quantile_mapper_transformer():
     pw.fit(GridArray(X, ("time", "y", "x")))
     out = pw.transform(GridArray(X + 1.0, ("time", "y", "x")))
     assert_close(out.values[:, 0], X, what="pointwise quantile mapper")  # the bias is removed
+
+
+# ---- CunnaneTransformer (quantile.py:398-553) through sd_qm_cunnane ----
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_cunnane_goldens_from_the_reference(ctx, case):
+    """g10_cunnane.npz: transform (bit-exact positions: the same divisions as NumPy), fit_transform, inverse_transform
+    with the least-squares tails, every extrapolate mode, n_endpoints 10 / 3, a fit shorter than n_endpoints."""
+    g = load("g10_cunnane")
+    x = g[f"x{case}"]
+    st = ctx.qm_fit(x.reshape(-1, 1))
+    assert np.array_equal(st.export(with_y=False)["x_sorted"][0], np.sort(x))
+    for ex in qo.EXTRAPOLATE:
+        for ne in (10, 3):
+            fwd, status = ctx.qm_cunnane(st, 0, g[f"inside{case}"].reshape(-1, 1), ex, ne)
+            assert (status == 0).all()
+            assert_close(fwd[:, 0], g[f"fwd{case}_{ex}_{ne}"], rtol=1e-13, what=f"cunnane forward {case} {ex}")
+            if ex in (None, "1to1"):
+                out, _ = ctx.qm_cunnane(st, 0, g[f"outside{case}"].reshape(-1, 1), ex, ne)
+                assert_close(out[:, 0], g[f"fwd_out{case}_{ex}_{ne}"], rtol=1e-13, what="cunnane forward clamped")
+            inv, _ = ctx.qm_cunnane(st, 1, g[f"p{case}"].reshape(-1, 1), ex, ne)
+            assert_close(inv[:, 0], g[f"inv{case}_{ex}_{ne}"], rtol=1e-9, what=f"cunnane inverse {case} {ex} {ne}")
+    ft, _ = ctx.qm_cunnane(st, 0, x.reshape(-1, 1), "both", 10)
+    assert_close(ft[:, 0], g[f"fit_transform{case}"], rtol=1e-13, what="fit_transform")
+
+
+@pytest.mark.parametrize("T,Tp,C", [(365, 500, 5), (14600, 14600, 3), (19000, 700, 2)])
+def test_cunnane_grid_vs_oracle(ctx, T, Tp, C):
+    """Grid model over the cell axis, resident fields, quantized data (ties), values beyond the ends -> +-inf marks."""
+    from skdownscale_amd import CunnaneGridModel
+
+    rng = np.random.default_rng(T + C)
+    X = np.round((10 + 3 * rng.standard_normal((T, C))) * 8) / 8
+    Xn = 10 + 3.6 * rng.standard_normal((Tp, C))
+    P = rng.uniform(-0.05, 1.05, (Tp, C))
+    for ex, ne in (("both", 10), (None, 10), ("min", 4)):
+        gm = CunnaneGridModel(ex, ne, ctx).fit(ctx.to_device(X))
+        fwd, _ = gm.transform(ctx.to_device(Xn))
+        inv, _ = gm.inverse_transform(ctx.to_device(P))
+        fwd, inv = fwd.to_host(), inv.to_host()
+        for c in range(C):
+            cdf = qo.cunnane_fit(X[:, c])
+            exp = qo.cunnane_transform(cdf, Xn[:, c], ex)
+            fin = np.isfinite(exp)
+            assert np.array_equal(np.isinf(fwd[:, c]), ~fin) and np.array_equal(fwd[~fin, c], exp[~fin])
+            assert_close(fwd[fin, c], exp[fin], rtol=1e-13, what=f"grid forward {ex}")
+            assert_close(inv[:, c], qo.cunnane_inverse(cdf, P[:, c], ex, ne), rtol=1e-9, what=f"grid inverse {ex} {ne}")
+
+
+def test_cunnane_estimator_surface():
+    from sklearn.exceptions import NotFittedError
+
+    from skdownscale_amd import CunnaneTransformer
+
+    g = load("g10_cunnane")
+    x = g["x0"].reshape(-1, 1)
+    t = CunnaneTransformer()
+    with pytest.raises(NotFittedError):
+        t.transform(x)
+    pp = t.fit_transform(x)
+    assert pp.shape == x.shape
+    assert_close(pp[:, 0], g["fit_transform0"], rtol=1e-13, what="estimator fit_transform")
+    assert np.array_equal(t.cdf_.vals, np.sort(x[:, 0])) and t.cdf_.pp.shape == (len(x),)
+    back = t.inverse_transform(pp)
+    assert_close(back[:, 0], x[:, 0], rtol=1e-12, what="inverse of transform")
+    assert_close(t.inverse_transform(g["p0"].reshape(-1, 1))[:, 0], g["inv0_both_10"], rtol=1e-9, what="estimator inverse")
+    with pytest.raises(AttributeError):  # the reference fails the same way beyond an extended tail (quantile.py:497)
+        t.transform(np.array([[x.max() + 1.0]]))
+    assert CunnaneTransformer(extrapolate=None).fit(x).transform(np.array([[x.max() + 1.0]]))[0, 0] == t.cdf_.pp[-1]
+    t2 = pickle.loads(pickle.dumps(t))
+    assert np.array_equal(t2.inverse_transform(pp), back)
+    with pytest.raises(ValueError, match="single feature"):
+        CunnaneTransformer().fit(np.zeros((5, 2)))
+    with pytest.raises(ValueError, match="unknown value for extrapolate"):
+        CunnaneTransformer(extrapolate="sideways").fit(x)

@@ -127,6 +127,27 @@ def test_sharded_gather_world_size_2_gloo(tmp_path):
     assert "GATHER_OK" in res.stdout
 
 
+def test_cunnane_transformer_argument_checks():
+    """CunnaneTransformer behaviour that needs no GPU (quantile.py:420-463): parameters, feature count, fit state."""
+    from sklearn.base import clone
+    from sklearn.exceptions import NotFittedError
+
+    from skdownscale_amd import CunnaneGridModel, CunnaneTransformer
+
+    t = CunnaneTransformer(extrapolate="max", n_endpoints=4)
+    assert clone(t).get_params() == dict(alpha=0.4, beta=0.4, extrapolate="max", n_endpoints=4)
+    with pytest.raises(ValueError, match="single feature"):
+        t.fit(np.zeros((5, 2)))
+    with pytest.raises(ValueError, match="unknown value for extrapolate"):
+        CunnaneTransformer(extrapolate="sideways").fit(np.arange(5.0).reshape(-1, 1))
+    with pytest.raises(ValueError, match="NaN"):
+        t.fit(np.array([[1.0], [np.nan], [2.0]]))
+    with pytest.raises(NotFittedError):
+        t.inverse_transform(np.array([[0.5]]))
+    with pytest.raises(ValueError, match="unknown value for extrapolate"):
+        CunnaneGridModel("sideways", ctx=object())
+
+
 def test_quantile_mapping_estimators_argument_checks():
     """Constructor / argument behaviour of the quantile-mapping regressors that needs no GPU (quantile.py:181-190, 576-593)."""
     from skdownscale_amd import EquidistantCdfMatcher, QuantileMappingReressor

@@ -161,3 +161,23 @@ def test_quantile_mapping_regressors_match_reference():
     x = np.arange(1, 22.0)  # the reference's test_EquidistantCdfMatcher: exact
     assert np.array_equal(qo.ecm_predict(qo.qm_fit(x, x + 3), x + 2, "difference"), g["reftest_difference"])
     assert np.array_equal(qo.ecm_predict(qo.qm_fit(x, x + 3), x * 2, "ratio"), g["reftest_ratio"])
+
+
+def test_cunnane_oracle_matches_golden():
+    """CunnaneTransformer restatement (oracle/qm_oracle.py) vs g10_cunnane.npz (the real reference): transform inside
+    the fitted range for every mode, beyond it for the clamping modes, fit_transform, and inverse_transform with the
+    least-squares tails (n_endpoints 10 / 3, and a 6-sample fit shorter than n_endpoints)."""
+    import qm_oracle as qo
+
+    g = load("g10_cunnane")
+    for case in range(3):
+        cdf = qo.cunnane_fit(g[f"x{case}"])
+        for ex in qo.EXTRAPOLATE:
+            for ne in (10, 3):
+                got = qo.cunnane_transform(cdf, g[f"inside{case}"], ex)
+                assert np.array_equal(got, g[f"fwd{case}_{ex}_{ne}"]), (case, ex)
+                if ex in (None, "1to1"):
+                    assert np.array_equal(qo.cunnane_transform(cdf, g[f"outside{case}"], ex), g[f"fwd_out{case}_{ex}_{ne}"])
+                assert_close(qo.cunnane_inverse(cdf, g[f"p{case}"], ex, ne), g[f"inv{case}_{ex}_{ne}"], rtol=1e-12,
+                             what=f"cunnane inverse {case} {ex} {ne}")
+        assert np.array_equal(qo.cunnane_transform(cdf, g[f"x{case}"], "both"), g[f"fit_transform{case}"])
