@@ -8,16 +8,19 @@
 // fit   : mask / finite check, cell-major copies Xc[C][F][T], yc[C][T] (tiled LDS transpose); for F == 1
 //         additionally the sorted view of a cell: xs[C][T] (values by (x, index)), xi[C][T] (their training
 //         indices), yx[C][T] (y in that order) and pq[C][T+1][2] (prefix sums of the centred yx and its
-//         squares) -- analog_sort2_kernel: workgroup merge sort (sd_sortnet.h).
+//         squares; rx[C][T+1]: cross term for the one-feature regression) -- analog_sort2_kernel: workgroup
+//         merge sort (sd_sortnet.h).  For F > 1 a copy of the training points sorted by feature 0 (ps, indices xi).
 // predict, F == 1 (one persistent workgroup per cell, queries and outputs through cell-major staging):
-//   analog_f1_mean_kernel   mean_analogs without a threshold, or a single analog: window search over xs in
-//                           LDS + prefix sums (single pass);
-//   analog_f1_window_kernel the other PureAnalog kinds and AnalogRegression: k-NN window over xs, statistics
-//                           from yx, both LDS-resident per value range;
+//   analog_f1_mean_kernel   mean_analogs without a threshold, a single analog, AnalogRegression: window search
+//                           over xs in LDS + prefix sums (single pass);
+//   analog_f1_window_kernel the other PureAnalog kinds: k-NN window over xs, statistics from yx, both
+//                           LDS-resident per value range;
 //   analog_f1_predict_kernel / f1_walk_query  exact (rdist, index)-ordered two-pointer walk: 'sample_analogs',
 //                           neighbour outputs, and any query whose window has a tie on its boundary.
-// predict, F > 1: analog_bf2_predict_kernel (one wave per 64 queries, scalar-loaded training points, top-k heap
-//   in LDS); analog_bf_predict_kernel (LDS-staged tiles, lists in global scratch) for k > 208.
+// predict, F > 1: analog_slab_predict_kernel (one wave per 64 queries sorted by feature 0, scalar-loaded training
+//   points from the feature-0 sorted copy, only the reachable slab is scanned, top-k heap in LDS);
+//   analog_bf2_predict_kernel (same scanner over the whole set in index order); analog_bf_predict_kernel
+//   (LDS-staged tiles, lists in global scratch) for k > 208.
 // Epilogues: PureAnalog statistics (gard.py:303-346), per-query least squares (gard.py:194-224).
 #include <algorithm>
 #include <cstdlib>
