@@ -8,7 +8,7 @@ from .core import GridArray, GridDataset, PointWiseDownscaler
 from .gard import AnalogGridModel, AnalogRegression, PureAnalog
 from .groupers import DAY_GROUPER, MONTH_GROUPER
 from .quantile import (CunnaneGridModel, CunnaneTransformer, EquidistantCdfMatcher, QmGridModel, QuantileMapper,
-                       QuantileMappingReressor)
+                       QuantileMapperGridModel, QuantileMappingReressor)
 
 __all__ = [
     "AnalogRegression",
@@ -28,5 +28,6 @@ __all__ = [
     "QmGridModel",
     "CunnaneTransformer",
     "CunnaneGridModel",
+    "QuantileMapperGridModel",
 ]
 __version__ = "0.1.0"

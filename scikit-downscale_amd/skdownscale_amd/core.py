@@ -19,7 +19,8 @@ import pandas as pd
 from . import _lib
 from .bcsd import BcsdBase, BcsdGridModel, check_supported
 from .gard import AnalogBase, AnalogGridModel, AnalogRegression, PureAnalog
-from .quantile import QmGridModel, QuantileMappingReressor, check_extrapolate
+from .quantile import (CunnaneGridModel, CunnaneTransformer, QmGridModel, QuantileMapper, QuantileMapperGridModel,
+                       QuantileMappingReressor, check_extrapolate)
 
 DEFAULT_FEATURE_DIM = "variable"
 
@@ -115,7 +116,7 @@ class _BatchedModels:
     """Fitted state of a whole grid held by the engine (replaces the object array of estimators)."""
 
     def __init__(self, kind, grid_model, mask, spatial_dims, spatial_shape, coords):
-        self.kind = kind  # 'bcsd' | 'analog'
+        self.kind = kind  # 'bcsd' | 'analog' | 'qm' | 'cunnane' | 'qmapper' | 'loop'
         self.grid_model = grid_model
         self.mask = mask
         self.spatial_dims = spatial_dims
@@ -168,6 +169,12 @@ class PointWiseDownscaler:
             check_extrapolate(m.extrapolate)
             m._engine_code()
             return "qm"
+        if isinstance(m, CunnaneTransformer):
+            m._check()
+            return "cunnane"
+        if isinstance(m, QuantileMapper):
+            m._check()
+            return "qmapper"
         return None
 
     # ------------------------------------------------------------------------------------------
@@ -194,10 +201,20 @@ class PointWiseDownscaler:
             self._models = self._fit_loop(Xg, yg, Xv, mask, index, feature_dim, spatial_dims, spatial_shape, coords,
                                           {k: v for k, v in kws.items() if k not in ("along_dim", "feature_dim")})
             return
+        m = self._model
+        if kind in ("cunnane", "qmapper"):  # transformers: fit(X) only (a y, if given, is ignored like in the reference)
+            if F != 1:
+                if kind == "cunnane":
+                    raise ValueError("CunnaneTransformer.fit() only supports a single feature")
+                raise ValueError(f"Found array with {F} features (shape=({T}, {F})) while a maximum of 1 is required")
+            gm = (CunnaneGridModel(m.extrapolate, m.n_endpoints) if kind == "cunnane" else QuantileMapperGridModel()).fit(Xv[:, 0, :])
+            gm.status_ = gm.state.export(with_y=False)["status"] if kind == "cunnane" else gm.status_
+            self._raise_for_status(gm.status_, Xv[:, 0, :], Xv[:, 0, :])
+            self._models = _BatchedModels(kind, gm, mask, spatial_dims, spatial_shape, coords)
+            return
         if yg is None:
             raise TypeError(f"{type(self._model).__name__}.fit() missing 1 required positional argument: 'y'")
         yv = np.ascontiguousarray(yg.values, dtype=np.float64).reshape(T, C)
-        m = self._model
         if kind == "bcsd":
             if F != 1:
                 msg = "BCSD only supports up to 4 features, found {}" if m._kind == _lib.BCSD_TAS else "BCSD only supports 1 feature, found {}"
@@ -335,7 +352,8 @@ class PointWiseDownscaler:
         """core.py:146-171 (``_transform_wrapper``): same dims / shape as the feature-normalised X, masked cells NaN."""
         if self._models is None:
             raise ValueError("PointWiseDownscaler is not fitted: call fit() first")
-        if self._models.kind != "loop":
+        kind = self._models.kind
+        if kind not in ("loop", "cunnane", "qmapper") or (kind == "qmapper" and direction != "transform"):
             raise AttributeError(f"{type(self._model).__name__} has no {direction}()")
         kws = {"feature_dim": DEFAULT_FEATURE_DIM} | kwargs
         feature_dim = kws.pop("feature_dim")
@@ -345,6 +363,17 @@ class PointWiseDownscaler:
         C = int(np.prod(spatial_shape, dtype=np.int64)) if spatial_shape else 1
         if tuple(spatial_shape) != tuple(self._models.spatial_shape):
             raise ValueError(f"spatial shape {spatial_shape} does not match the fitted grid {self._models.spatial_shape}")
+        if kind != "loop":  # one batched launch for the whole grid
+            if F != 1:
+                raise ValueError(f"{type(self._model).__name__}.{direction}() only supports a single feature")
+            Xb = np.ascontiguousarray(Xg.values, dtype=np.float64).reshape(T, C)
+            out, status = getattr(self._models.grid_model, direction)(Xb)
+            self._raise_for_status(status, Xb, Xb)
+            if kind == "cunnane" and direction == "transform" and np.isinf(out[:, self._models.mask]).any():
+                raise AttributeError("'numpy.ndarray' object has no attribute 'values' (CunnaneTransformer.transform of values "
+                                     f"outside the fitted range with extrapolate={self._model.extrapolate!r}: quantile.py:497)")
+            out = out.reshape(Xg.shape).astype(Xg.dtype, copy=False)
+            return _from_grid(GridArray(out, Xg.dims, dict(Xg.coords)), was_x)
         Xv = np.asarray(Xg.values).reshape(T, F, C)
         index = _time_index(Xg, self._dim)
         columns = list(Xg.coords.get(feature_dim, [f"feature{i}" for i in range(F)]))

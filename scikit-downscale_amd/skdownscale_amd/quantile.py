@@ -209,6 +209,26 @@ class CunnaneGridModel:
         return self._apply(_lib.CUNNANE_INVERSE, P, out)
 
 
+class QuantileMapperGridModel:
+    """Batched QuantileMapper (``detrend=False``) over the cell axis: the BCSD kernels with the whole series of a cell as
+    one group (quantile.py:81-147 per cell).  X [T, C] numpy or DeviceArray."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        self.state = None
+
+    def fit(self, X):
+        T = X.shape[0]
+        self.state = self.ctx.bcsd_fit(_lib.BCSD_PR, None, X, np.zeros(T, dtype=np.int32), 1, False)
+        self.status_ = self.state.status()
+        return self
+
+    def transform(self, X, out=None):
+        if self.state is None:
+            raise NotFittedError("This QuantileMapper grid model is not fitted yet.")
+        return self.ctx.bcsd_predict(self.state, X, np.zeros(X.shape[0], dtype=np.int32), out=out)
+
+
 class QmGridModel:
     """Batched quantile-mapping regressor over the cell axis: X, y [T, C], Xp [Tp, C] (numpy or DeviceArray)."""
 

@@ -210,3 +210,42 @@ def test_cunnane_estimator_surface():
         CunnaneTransformer().fit(np.zeros((5, 2)))
     with pytest.raises(ValueError, match="unknown value for extrapolate"):
         CunnaneTransformer(extrapolate="sideways").fit(x)
+
+
+def test_pointwise_transformers_are_batched():
+    """PointWiseDownscaler.transform / inverse_transform (core.py:340-403) with CunnaneTransformer / QuantileMapper: one
+    engine launch for the grid, same numbers as one estimator per cell, masked cells NaN, the reference's failures."""
+    from skdownscale_amd import CunnaneTransformer, GridArray, PointWiseDownscaler, QuantileMapper
+
+    rng = np.random.default_rng(21)
+    dims = ("time", "y", "x")
+    X = 10 + 3 * rng.standard_normal((300, 3, 4))
+    X[0, 2, 1] = np.nan  # masked cell (core.py:35-37)
+    Xn = X + 0.25
+    ok = np.ones((3, 4), bool)
+    ok[2, 1] = False
+    for model in (CunnaneTransformer(extrapolate=None), QuantileMapper()):
+        pw = PointWiseDownscaler(model)
+        pw.fit(GridArray(X, dims))
+        assert pw._models.kind in ("cunnane", "qmapper")
+        out = pw.transform(GridArray(Xn, dims))
+        assert out.dims == ("time", "variable", "y", "x") and out.shape == (300, 1, 3, 4)
+        assert np.isnan(out.values[:, 0, 2, 1]).all()
+        for iy, ix in zip(*np.nonzero(ok)):
+            one = type(model)(**model.get_params()).fit(X[:, iy, ix].reshape(-1, 1)).transform(Xn[:, iy, ix].reshape(-1, 1))
+            assert np.array_equal(out.values[:, 0, iy, ix], one[:, 0])
+    pw = PointWiseDownscaler(CunnaneTransformer())
+    pw.fit(GridArray(X, dims))
+    pp = pw.transform(GridArray(X, dims))
+    back = pw.inverse_transform(pp)
+    assert_close(back.values[:, 0][:, ok], X[:, ok], rtol=1e-12, what="grid inverse of transform")
+    with pytest.raises(AttributeError):  # beyond an extended tail (quantile.py:497)
+        pw.transform(GridArray(Xn + 20.0, dims))
+    with pytest.raises(AttributeError):  # QuantileMapper has no inverse_transform
+        p2 = PointWiseDownscaler(QuantileMapper())
+        p2.fit(GridArray(X, dims))
+        p2.inverse_transform(GridArray(X, dims))
+    bad = Xn.copy()
+    bad[5, 0, 0] = np.nan
+    with pytest.raises(ValueError, match="NaN"):
+        pw.transform(GridArray(bad, dims))
