@@ -8,8 +8,9 @@
 // fit   : mask / finite check, cell-major copies Xc[C][F][T], yc[C][T] (tiled LDS transpose); for F == 1
 //         additionally the sorted view of a cell: xs[C][T] (values by (x, index)), xi[C][T] (their training
 //         indices), yx[C][T] (y in that order) and pq[C][T+1][2] (prefix sums of the centred yx and its
-//         squares; rx[C][T+1]: cross term for the one-feature regression) -- analog_sort2_kernel: workgroup
-//         merge sort (sd_sortnet.h).  For F > 1 a copy of the training points sorted by feature 0 (ps, indices xi).
+//         squares) -- analog_sort2_kernel: workgroup merge sort (sd_sortnet.h); rx[C][T+1], the cross term of
+//         the one-feature regression, is added by analog_rx_kernel on the first AnalogRegression call.  For
+//         F > 1 a copy of the training points sorted by feature 0 (ps, indices xi).
 // predict, F == 1 (one persistent workgroup per cell, queries and outputs through cell-major staging):
 //   analog_f1_mean_kernel   mean_analogs without a threshold, a single analog, AnalogRegression: window search
 //                           over xs in LDS + prefix sums (single pass);
@@ -167,13 +168,12 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
                                                             const double* __restrict__ yc,
                                                             int64_t T, int64_t C, double* __restrict__ xs,
                                                             int32_t* __restrict__ xi, double* __restrict__ yx,
-                                                            double* __restrict__ pq_all, double* __restrict__ ybar_all,
-                                                            double* __restrict__ rx_all, double* __restrict__ xbar_all) {
+                                                            double* __restrict__ pq_all, double* __restrict__ ybar_all) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int np = (n + K - 1) / K * K;
     double* buf = reinterpret_cast<double*>(smem_raw);     // np + 1 doubles
-    int* xch = reinterpret_cast<int*>(buf + np + 1);        // nthr + 1 ints (also 5 x 16 doubles of reduction scratch)
+    int* xch = reinterpret_cast<int*>(buf + np + 1);        // nthr + 1 ints (also 3 x 16 doubles of reduction scratch)
     double* red = reinterpret_cast<double*>(xch);
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
@@ -269,89 +269,61 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
         __syncthreads();
         // buf[0..n) = y in sorted-x order: write it and its centred exclusive prefix sums (see analog_prefix_kernel)
         for (int i = tid; i < n; i += nthr) yx[c * T + i] = buf[i];
-        double yv[K], xv[K];
-        double s = 0.0, sx = 0.0;
+        double yv[K];
+        double s = 0.0;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             const int j = K * tid + i;
             yv[i] = j < n ? buf[j] : 0.0;
-            xv[i] = j < n ? xs[c * T + j] : 0.0;  // written above by this workgroup
             s += yv[i];
-            sx += xv[i];
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            s += __shfl_xor(s, o, 64);
-            sx += __shfl_xor(sx, o, 64);
-        }
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
         __syncthreads();  // (xch is free again)
-        if (lane == 0) {
-            red[wave] = s;
-            red[48 + wave] = sx;
-        }
+        if (lane == 0) red[wave] = s;
         __syncthreads();
-        double tot = 0.0, totx = 0.0;
-        for (int w = 0; w < 16; ++w) {
-            tot += red[w];
-            totx += red[48 + w];
-        }
-        const double ybar = tot / (double)n, xbar = totx / (double)n;
-        if (tid == 0) {
-            ybar_all[c] = ybar;
-            xbar_all[c] = xbar;
-        }
-        double a = 0.0, b = 0.0, r = 0.0;
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += red[w];
+        const double ybar = tot / (double)n;
+        if (tid == 0) ybar_all[c] = ybar;
+        double a = 0.0, b = 0.0;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             const int j = K * tid + i;
             const double d = j < n ? yv[i] - ybar : 0.0;
-            const double e = j < n ? (xv[i] - xbar) * d : 0.0;
             yv[i] = d;
-            xv[i] = e;
             a += d;
             b += d * d;
-            r += e;
         }
-        double ia = a, ib = b, ir = r;  // inclusive scan inside the wave
+        double ia = a, ib = b;  // inclusive scan inside the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64), tr = __shfl_up(ir, o, 64);
+            const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
             if (lane >= o) {
                 ia += ta;
                 ib += tb;
-                ir += tr;
             }
         }
         __syncthreads();
         if (lane == 63) {
             red[16 + wave] = ia;
             red[32 + wave] = ib;
-            red[64 + wave] = ir;
         }
         __syncthreads();
-        double ra = ia - a, rb = ib - b, rr = ir - r;  // exclusive prefix at this thread's first element
+        double ra = ia - a, rb = ib - b;  // exclusive prefix at this thread's first element
         for (int w = 0; w < wave; ++w) {
             ra += red[16 + w];
             rb += red[32 + w];
-            rr += red[64 + w];
         }
         double2* pq = reinterpret_cast<double2*>(pq_all) + c * (T + 1);
-        double* rx = rx_all + c * (T + 1);
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             const int j = K * tid + i;
-            if (j <= n) {
-                pq[j] = make_double2(ra, rb);
-                rx[j] = rr;
-            }
+            if (j <= n) pq[j] = make_double2(ra, rb);
             ra += yv[i];
             rb += yv[i] * yv[i];
-            rr += xv[i];
         }
-        if (K * tid + K == n) {  // n = 1024 * K: no thread starts at position n
-            pq[n] = make_double2(ra, rb);
-            rx[n] = rr;
-        }
+        if (K * tid + K == n) pq[n] = make_double2(ra, rb);  // n = 1024 * K: no thread starts at position n
     }
 }
 
@@ -363,7 +335,7 @@ struct Sort2Args {
     int64_t T, C;
     double* xs;
     int32_t* xi;
-    double *yx, *pq, *ybar, *rx, *xbar;
+    double *yx, *pq, *ybar;
 };
 
 template <int K>
@@ -374,7 +346,7 @@ int launch_sort2(sd_ctx* ctx, const Sort2Args& a) {
                                (int)lds));
     const int nb = (int)std::min<int64_t>(a.C, (int64_t)ctx->cu_count * 4);
     SD_LAUNCH(ctx, "analog_sort2_kernel", analog_sort2_kernel<K>, dim3(nb), dim3(1024), lds, a.X, a.x_stride, a.keys_only, a.y, a.T,
-              a.C, a.xs, a.xi, a.yx, a.pq, a.ybar, a.rx, a.xbar);
+              a.C, a.xs, a.xi, a.yx, a.pq, a.ybar);
     return SD_OK;
 }
 
@@ -403,96 +375,118 @@ int sort2_width(int64_t T, size_t lds_max) {
 // F == 1: exclusive prefix sums of the centred analog values in sorted-x order, pq[c][i] = (sum_{j<i} d_j,
 // sum_{j<i} d_j^2) with d = yx - mean(y).  The mean and standard deviation of any window of k consecutive analogs
 // then cost two 16-byte loads (centring keeps the running sums small: no cancellation for the differences).
-// rx[c][i] = sum_{j<i} (xs_j - mean(x)) d_j is the cross term the one-feature AnalogRegression needs.
 // One 1024-thread workgroup per cell: serial partial sums per thread, wave shuffles + LDS for the offsets.
-__global__ void __launch_bounds__(1024) analog_prefix_kernel(const double* __restrict__ yx_all,
-                                                             const double* __restrict__ xs_all, int64_t T, int64_t C,
-                                                             double* __restrict__ pq_all, double* __restrict__ ybar_all,
-                                                             double* __restrict__ rx_all, double* __restrict__ xbar_all) {
-    __shared__ double wsum[3][16];
+__global__ void __launch_bounds__(1024) analog_prefix_kernel(const double* __restrict__ yx_all, int64_t T, int64_t C,
+                                                             double* __restrict__ pq_all, double* __restrict__ ybar_all) {
+    __shared__ double wsum[2][16];
     const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int per = (n + nthr - 1) / nthr;  // consecutive elements per thread
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         const double* yx = yx_all + c * T;
-        const double* xs = xs_all + c * T;
         double2* pq = reinterpret_cast<double2*>(pq_all) + c * (T + 1);
-        double* rx = rx_all + c * (T + 1);
         const int beg = tid * per < n ? tid * per : n, end = beg + per < n ? beg + per : n;
-        // means of y and x
-        double s = 0.0, sx = 0.0;
-        for (int i = beg; i < end; ++i) {
-            s += yx[i];
-            sx += xs[i];
-        }
+        // mean of y
+        double s = 0.0;
+        for (int i = beg; i < end; ++i) s += yx[i];
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            s += __shfl_xor(s, o, 64);
-            sx += __shfl_xor(sx, o, 64);
-        }
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
         __syncthreads();
-        if (lane == 0) {
-            wsum[0][wave] = s;
-            wsum[1][wave] = sx;
-        }
+        if (lane == 0) wsum[0][wave] = s;
         __syncthreads();
-        double tot = 0.0, totx = 0.0;
-        for (int w = 0; w < 16; ++w) {
-            tot += wsum[0][w];
-            totx += wsum[1][w];
-        }
-        const double ybar = tot / (double)n, xbar = totx / (double)n;
-        if (tid == 0) {
-            ybar_all[c] = ybar;
-            xbar_all[c] = xbar;
-        }
-        // per-thread totals of d, d^2 and (x - xbar) d, exclusive scan across the workgroup
-        double a = 0.0, b = 0.0, r = 0.0;
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += wsum[0][w];
+        const double ybar = tot / (double)n;
+        if (tid == 0) ybar_all[c] = ybar;
+        // per-thread totals of d and d^2, exclusive scan across the workgroup
+        double a = 0.0, b = 0.0;
         for (int i = beg; i < end; ++i) {
             const double d = yx[i] - ybar;
             a += d;
             b += d * d;
-            r += (xs[i] - xbar) * d;
         }
-        double ia = a, ib = b, ir = r;  // inclusive scan inside the wave
+        double ia = a, ib = b;  // inclusive scan inside the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64), tr = __shfl_up(ir, o, 64);
+            const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
             if (lane >= o) {
                 ia += ta;
                 ib += tb;
-                ir += tr;
             }
         }
         __syncthreads();
         if (lane == 63) {
             wsum[0][wave] = ia;
             wsum[1][wave] = ib;
-            wsum[2][wave] = ir;
         }
         __syncthreads();
-        double oa = 0.0, ob = 0.0, orr = 0.0;
+        double oa = 0.0, ob = 0.0;
         for (int w = 0; w < wave; ++w) {
             oa += wsum[0][w];
             ob += wsum[1][w];
-            orr += wsum[2][w];
         }
-        double ra = oa + (ia - a), rb = ob + (ib - b), rr = orr + (ir - r);  // exclusive prefix at this thread's first element
+        double ra = oa + (ia - a), rb = ob + (ib - b);  // exclusive prefix at this thread's first element
         for (int i = beg; i < end; ++i) {
             pq[i] = make_double2(ra, rb);
-            rx[i] = rr;
             const double d = yx[i] - ybar;
             ra += d;
             rb += d * d;
-            rr += (xs[i] - xbar) * d;
         }
-        if (end == n && beg < n) {
-            pq[n] = make_double2(ra, rb);
-            rx[n] = rr;
+        if (end == n && beg < n) pq[n] = make_double2(ra, rb);
+        if (n == 0 && tid == 0) pq[0] = make_double2(0.0, 0.0);
+    }
+}
+
+// F == 1, one-feature AnalogRegression: rx[c][i] = sum_{j<i} (xs_j - mean(x)) (yx_j - mean(y)), the cross term of the
+// window regression (analog_f1_mean_kernel), computed on the first regression call on a state.  The products are
+// formed with coalesced reads into LDS, scanned there (odd number of consecutive elements per thread: conflict-free)
+// and stored coalesced.
+__global__ void __launch_bounds__(1024) analog_rx_kernel(const double* __restrict__ xs_all, const double* __restrict__ yx_all,
+                                                         const double* __restrict__ ybar_all, int64_t T, int64_t C,
+                                                         double* __restrict__ rx_all, double* __restrict__ xbar_all) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* e = reinterpret_cast<double*>(smem_raw);  // n + 1 doubles
+    __shared__ double wsum[16];
+    const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int per = ((n + nthr - 1) / nthr) | 1;
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const double* xs = xs_all + c * T;
+        const double* yx = yx_all + c * T;
+        double s = 0.0;
+        for (int i = tid; i < n; i += nthr) s += xs[i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        __syncthreads();
+        if (lane == 0) wsum[wave] = s;
+        __syncthreads();
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += wsum[w];
+        const double xbar = tot / (double)n, ybar = ybar_all[c];
+        if (tid == 0) xbar_all[c] = xbar;
+        for (int i = tid; i < n; i += nthr) e[i] = (xs[i] - xbar) * (yx[i] - ybar);
+        __syncthreads();
+        const int beg = tid * per < n ? tid * per : n, end = beg + per < n ? beg + per : n;
+        double a = 0.0;
+        for (int i = beg; i < end; ++i) a += e[i];
+        double ia = a;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double ta = __shfl_up(ia, o, 64);
+            if (lane >= o) ia += ta;
         }
-        if (n == 0 && tid == 0) {
-            pq[0] = make_double2(0.0, 0.0);
-            rx[0] = 0.0;
+        if (lane == 63) wsum[wave] = ia;  // (all reads of wsum above are behind the barrier before the products)
+        __syncthreads();
+        double ra = ia - a;
+        for (int w = 0; w < wave; ++w) ra += wsum[w];
+        for (int i = beg; i < end; ++i) {
+            const double t = e[i];
+            e[i] = ra;
+            ra += t;
         }
+        if (end == n && (beg < n || tid * per == n)) e[n] = ra;
+        if (n == 0 && tid == 0) e[0] = 0.0;
+        __syncthreads();
+        double* rx = rx_all + c * (T + 1);
+        for (int i = tid; i <= n; i += nthr) rx[i] = e[i];
     }
 }
 
@@ -1052,10 +1046,11 @@ __global__ void __launch_bounds__(1024) analog_f1_window_kernel(int mode, const 
     }
 }
 
-// F == 1, PureAnalog 'mean_analogs' without a threshold, a single analog, and AnalogRegression (mode 1, k >= 3): the
-// window statistics come from the prefix sums pq / rx (analog_prefix_kernel), so only the sorted training values
-// have to be LDS-resident: a single pass over the queries, the window search plus two (regression: three) pairs
-// of prefix loads per query.  Tie handling as in analog_f1_window_kernel.
+// F == 1, single pass over the queries with only the sorted training values LDS-resident.  'mean_analogs' without a
+// threshold, a single analog and AnalogRegression (mode 1, k >= 3) take the window statistics from the prefix sums
+// pq / rx (analog_prefix_kernel): the window search plus two (regression: three) pairs of prefix loads per query.
+// 'weight_analogs' and the thresholded kinds read the k consecutive analog values of the window from memory.
+// Tie handling as in analog_f1_window_kernel.
 __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const double* __restrict__ Xq /* [C][Tq] */, int64_t Tq,
                                                               int64_t T, int64_t C, const double* __restrict__ xs_all,
                                                               const int32_t* __restrict__ xi_all,
@@ -1186,13 +1181,59 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                         pred = (pa.kind == SD_ANALOG_BEST || exc) ? a1 : 0.0;  // mean / weight of a masked analog: NaN -> 0 (gard.py:341)
                         prob = pa.has_thresh ? (exc ? 1.0 : 0.0) : 1.0;       // gard.py:343, 346
                         err = exc ? 0.0 : nan;                                // gard.py:342, 345
-                    } else {
+                    } else if (pa.kind == SD_ANALOG_MEAN && !pa.has_thresh) {
                         const double2 a = pq[L], b = pq[L + k];
                         const double m1 = (b.x - a.x) / kk;           // mean of the centred analogs
                         const double var = (b.y - a.y) / kk - m1 * m1;
                         pred = ybar + m1;                            // gard.py:329-333
                         prob = 1.0;                                  // gard.py:346
                         err = sqrt(var > 0.0 ? var : 0.0);           // ddof = 0 (gard.py:345)
+                    } else {
+                        // weights and / or a threshold need every analog: the window of yx is read from memory (k
+                        // consecutive values, cache-resident), the training values come from LDS
+                        const double* yl = yx_all + c * T + L;
+                        const double a0 = yl[0];
+                        double s1 = 0.0, s2 = 0.0, wsum = 0.0, awsum = 0.0;
+                        int nexc = 0;
+                        for (int i0 = 0; i0 < k; i0 += kWinBatch) {
+                            double ab[kWinBatch];
+#pragma unroll
+                            for (int b = 0; b < kWinBatch; ++b) ab[b] = i0 + b < k ? yl[i0 + b] : 0.0;
+#pragma unroll
+                            for (int b = 0; b < kWinBatch; ++b) {
+                                const int i = i0 + b;
+                                if (i < k) {
+                                    const double ai = ab[b], e = ai - a0;
+                                    s1 += e;
+                                    s2 += e * e;
+                                    nexc += (!pa.has_thresh || ai > pa.thresh) ? 1 : 0;  // gard.py:307
+                                    if (pa.kind == SD_ANALOG_WEIGHT) {
+                                        // w = 1 / distance (gard.py:322-323): v_rcp_f64 + two Newton steps (< 1 ulp)
+                                        double d = __builtin_fabs(q[j] - xs[L + i]);
+                                        d = d == 0.0 ? 1e-20 : d;
+                                        double r = __builtin_amdgcn_rcp(d);
+                                        r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+                                        r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+                                        wsum += r;
+                                        awsum += ai * r;
+                                    }
+                                }
+                            }
+                        }
+                        const bool any_masked = nexc != k;
+                        const double m1 = s1 / kk;
+                        if (pa.kind == SD_ANALOG_WEIGHT) pred = any_masked ? nan : awsum / wsum;  // gard.py:319-327
+                        else pred = any_masked ? nan : a0 + m1;                                    // gard.py:329-333
+                        if (pa.has_thresh) {
+                            pred = nan_to_num(pred);     // gard.py:341
+                            prob = (double)nexc / kk;    // gard.py:343
+                        } else {
+                            prob = 1.0;  // gard.py:346
+                        }
+                        if (!any_masked) {
+                            const double var = s2 / kk - m1 * m1;
+                            err = sqrt(var > 0.0 ? var : 0.0);  // ddof = 0 (gard.py:342,345)
+                        }
                     }
                 }
                 put_out(pa, tq, c, pred, prob, err);
@@ -1819,7 +1860,7 @@ int predict_slab(sd_ctx* ctx, int mode, const sd_analog_state* st, const double*
                       qc.as<double>(), status_p + cb, 0);
         const int nbk = (int)std::min<int64_t>(cc, (int64_t)ctx->cu_count * 8);
         Sort2Args a{qc.as<double>(), (int64_t)F * Tq, 1, nullptr, Tq, cc, qs.as<double>(), qi.as<int32_t>(),
-                    nullptr, nullptr, nullptr, nullptr, nullptr};
+                    nullptr, nullptr, nullptr};
         if (nclass > 1) {
             SD_LAUNCH(ctx, "analog_slab_s2_kernel", analog_slab_s2_kernel, dim3(nbk), dim3(256), 0, (const double*)qc.p, Tq, F, cc,
                       key.as<double>());
@@ -1911,13 +1952,24 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
         SD_HIP(oc.alloc(ctx, sizeof(double) * (size_t)Tq * 3 * cc_max));
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_window_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        // mean_analogs without a threshold: statistics from the prefix sums, one pass with only xs in LDS
+        // single pass with only xs in LDS (statistics from the prefix sums, or the window of yx read from memory)
         const size_t lds_mean = sizeof(double) * (size_t)(T + 1);
-        const bool mean_only = (mode == 1 ? k >= 3 : ((kind == SD_ANALOG_MEAN && !has_thresh) || k == 1)) && st->pq != nullptr &&
+        const bool mean_only = (mode == 1 ? k >= 3 : (kind == SD_ANALOG_MEAN || kind == SD_ANALOG_WEIGHT || k == 1)) && st->pq != nullptr &&
                                lds_mean <= ctx->lds_max && getenv("SD_ANALOG_NOPREFIX") == nullptr;
         if (mean_only)
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean));
+        if (mean_only && mode == 1 && st->rx == nullptr) {
+            // first regression on this state: the cross-term prefix sums (calls on a context are serialised)
+            sd_analog_state* ms = const_cast<sd_analog_state*>(st);
+            SD_HIP(sd_pool_malloc(ctx, (void**)&ms->rx, sizeof(double) * (size_t)(T + 1) * C));
+            SD_HIP(sd_pool_malloc(ctx, (void**)&ms->xbar, sizeof(double) * C));
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_rx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_mean));
+            SD_LAUNCH(ctx, "analog_rx_kernel", analog_rx_kernel, dim3((unsigned)std::min<int64_t>(C, (int64_t)ctx->cu_count * 2)),
+                      dim3(1024), lds_mean, (const double*)st->xs, (const double*)st->yx, (const double*)st->ybar, T, C, ms->rx,
+                      ms->xbar);
+        }
         for (int64_t cb = 0; cb < C; cb += chunk) {
             const int64_t cc = C - cb < chunk ? C - cb : chunk;
             dim3 tgrid((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32));
@@ -2079,21 +2131,19 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->yx, sizeof(double) * (size_t)T * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->pq, sizeof(double) * 2 * (size_t)(T + 1) * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->ybar, sizeof(double) * C));
-            SD_HIP(sd_pool_malloc(ctx, (void**)&st->rx, sizeof(double) * (size_t)(T + 1) * C));
-            SD_HIP(sd_pool_malloc(ctx, (void**)&st->xbar, sizeof(double) * C));
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const int K2 = getenv("SD_ANALOG_SORT1") ? 0 : sort2_width(T, ctx->lds_max);
             if (K2 != 0) {
-                const Sort2Args a{st->X, T, 0, st->y, T, C, st->xs, st->xi, st->yx, st->pq, st->ybar, st->rx, st->xbar};
+                const Sort2Args a{st->X, T, 0, st->y, T, C, st->xs, st->xi, st->yx, st->pq, st->ybar};
                 SD_TRY(launch_sort2_width(ctx, K2, a));
             } else {  // (the fast sort writes the prefix sums itself)
                 int nb = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 4);
                 SD_LAUNCH(ctx, "analog_sort_kernel", analog_sort_kernel, dim3(nb), dim3(1024), lds, (const double*)st->X,
                           (const double*)st->y, T, C, st->xs, st->xi, st->yx);
                 const int nbp = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 2);
-                SD_LAUNCH(ctx, "analog_prefix_kernel", analog_prefix_kernel, dim3(nbp), dim3(1024), 0, (const double*)st->yx,
-                          (const double*)st->xs, T, C, st->pq, st->ybar, st->rx, st->xbar);
+                SD_LAUNCH(ctx, "analog_prefix_kernel", analog_prefix_kernel, dim3(nbp), dim3(1024), 0, (const double*)st->yx, T, C,
+                          st->pq, st->ybar);
             }
             SD_HIP(hipStreamSynchronize(ctx->stream));
         }
@@ -2105,7 +2155,7 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->xi, sizeof(int32_t) * (size_t)T * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->ps, sizeof(double) * (size_t)T * F * C));
             const Sort2Args a{st->X, (int64_t)F * T, 1, nullptr, T, C, keys.as<double>(), st->xi,
-                              nullptr, nullptr, nullptr, nullptr, nullptr};
+                              nullptr, nullptr, nullptr};
             SD_TRY(launch_sort2_width(ctx, Ks, a));
             SD_LAUNCH(ctx, "analog_gather_sorted_kernel", analog_gather_sorted_kernel,
                       dim3((unsigned)std::min<int64_t>(C, (int64_t)ctx->cu_count * 64)), dim3(256), 0, (const double*)st->X,

@@ -77,7 +77,7 @@ struct sd_analog_state {
     double* yx = nullptr;   // device [C][T]: y in the order of xs (analog values of a sorted-x window are contiguous)
     double* pq = nullptr;   // device [C][T+1][2]: exclusive prefix sums of (yx - ybar) and (yx - ybar)^2 (window mean / std in 2 loads)
     double* ybar = nullptr; // device [C]: mean of y
-    double* rx = nullptr;   // device [C][T+1]: exclusive prefix sums of (xs - xbar)(yx - ybar) (one-feature AnalogRegression)
+    double* rx = nullptr;   // device [C][T+1]: exclusive prefix sums of (xs - xbar)(yx - ybar); filled by the first one-feature AnalogRegression call
     double* xbar = nullptr; // device [C]: mean of x
     // F > 1 slab search: training points sorted by feature 0 (original indices in xi)
     double* ps = nullptr;   // device [C][F][T]
