@@ -1398,13 +1398,16 @@ __device__ __forceinline__ void heap_replace_root(double* sd, IT* si, int lane, 
 //    scan next (next_j0), so that `cur` is ready on entry.
 // SORTED: points arrive in feature-0 order, equal distances are decided by the index comparison with the heap root;
 // otherwise they arrive in index order and an equal distance never displaces.
-constexpr int kScanG = 8;
+// points per group of wave-uniform coordinates: two groups (current + requested) of F x G doubles must fit the ~100
+// scalar registers, or they spill into vector-register lanes inside the scan loop
+template <int F>
+constexpr int kScanG = F <= 2 ? 8 : 4;
 template <int F, typename IT, bool SORTED>
 __device__ __forceinline__ void scan_chunk(const double* __restrict__ P, int64_t T, const int32_t* __restrict__ PI, int j0, int nj,
-                                           int next_j0, double (&cur)[F][kScanG], const double (&q)[F], double& tau, double* sd,
+                                           int next_j0, double (&cur)[F][kScanG<F>], const double (&q)[F], double& tau, double* sd,
                                            IT* si, int k, int lane, double* stage /* [F][64] */, int32_t* stage_i /* [64] */,
                                            int ablate = 0, unsigned long long* dbg = nullptr) {
-    constexpr int G = kScanG;
+    constexpr int G = kScanG<F>;
     double mine[F];
     int32_t mine_i = 0;
 #pragma unroll
@@ -1515,11 +1518,11 @@ __global__ void __launch_bounds__(64) analog_bf2_predict_kernel(int mode, const 
     const double* __restrict__ Xcell = Xc + c * F * T;  // [F][T]
     double tau = ok ? inf : -1.0;  // k-th best distance so far; a lane without a query never flags a point
     double* stage = reinterpret_cast<double*>(si + (size_t)k * 64);  // [F][64] chunk coordinates for the insertion loop
-    double cur[F][kScanG];
+    double cur[F][kScanG<F>];
 #pragma unroll
     for (int f = 0; f < F; ++f)
 #pragma unroll
-        for (int g = 0; g < kScanG; ++g) cur[f][g] = T >= 64 ? Xcell[(int64_t)f * T + g] : 0.0;
+        for (int g = 0; g < kScanG<F>; ++g) cur[f][g] = T >= 64 ? Xcell[(int64_t)f * T + g] : 0.0;
     for (int64_t j0 = 0; j0 < T; j0 += 64) {
         const int nj = (int)(T - j0 < 64 ? T - j0 : 64);
         const int next_j0 = j0 + 128 <= T ? (int)j0 + 64 : 0;  // one uniform form: the last full chunk re-reads the first group
@@ -1663,7 +1666,7 @@ __global__ void __launch_bounds__(64) analog_slab_predict_kernel(int mode, const
         const bool rdone = R >= (int)T, ldone = L <= 0;
         double* stage = reinterpret_cast<double*>(si + (size_t)k * 64);   // [F][64]
         int32_t* stage_i = reinterpret_cast<int32_t*>(stage + F * 64);     // [64]
-        double cur[F][kScanG];
+        double cur[F][kScanG<F>];
         SlabCursor cs{R, L, 0, rdone, ldone};
         int cur_j = -1;
         SlabChunk ch = slab_pick(P, (int)T, qlo, qhi, uniform_f64(wave_max_f64(tau)), cs);
@@ -1676,7 +1679,7 @@ __global__ void __launch_bounds__(64) analog_slab_predict_kernel(int mode, const
 #pragma unroll
                 for (int f = 0; f < F; ++f)
 #pragma unroll
-                    for (int g = 0; g < kScanG; ++g) cur[f][g] = P[(int64_t)f * T + j0 + g];
+                    for (int g = 0; g < kScanG<F>; ++g) cur[f][g] = P[(int64_t)f * T + j0 + g];
             }
             const int next_j0 = njn == 64 ? j0n : j0;
             scan_chunk<F, IT, true>(P, T, PI, j0, nj, next_j0, cur, q, tau, sd, si, k, lane, stage, stage_i, ablate, dbg);
