@@ -73,7 +73,8 @@ def main():
         def step():
             st = ctx.analog_fit(X3, y)
             if args.workload == "analog":
-                r = ctx.analog_predict(st, Xq3, args.k, kinds[args.kind], out=out)
+                k_eff = 1 if args.kind == "best_analog" else args.k  # gard.py:291-296: best_analog queries one neighbour
+                r = ctx.analog_predict(st, Xq3, k_eff, kinds[args.kind], out=out)
             else:
                 r = ctx.analogreg_predict(st, Xq3, args.k, out=out)
             st.close()
