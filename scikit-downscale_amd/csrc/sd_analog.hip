@@ -1070,8 +1070,8 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     double* sd = scratch_d + (int64_t)blockIdx.x * k * nthr;
     int32_t* si = scratch_i + (int64_t)blockIdx.x * k * nthr;
-    int nsteps = 0;
-    while ((1 << nsteps) < n - k + 1) ++nsteps;
+    int nsteps = 0;  // window refinement: the range p - k .. p holds at most k + 1 candidates
+    while ((1 << nsteps) < (k + 1 < n - k + 1 ? k + 1 : n - k + 1)) ++nsteps;
     const double kk = (double)k;
     int64_t step, end;
     for (int64_t c = first_cell(C, &step, &end); c < end; c += step) {
@@ -1101,11 +1101,30 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                 if (active && has[j] && !ok[j]) atomicOr(&status[c], SDI_NONFINITE);
                 if (!ok[j]) q[j] = 0.0;
             }
+            // p = number of training values < q (one LDS read per step; strides that are multiples of 16 doubles are
+            // shortened by one, see the rank search in sd_bcsd_rs.hip).  Without ties the k nearest values are a window
+            // [L, L + k) with p - k <= L <= p: the smallest L of that range with rdist(L) <= rdist(L + k), log2(k + 1)
+            // more steps of two reads (rdist is unimodal along xs).  With ties the separation test below sends the query
+            // to the exact walk.
             int lo[kWinQ], hi[kWinQ];
+            {
+                int pos[kWinQ];
 #pragma unroll
-            for (int j = 0; j < kWinQ; ++j) {
-                lo[j] = 0;
-                hi[j] = n - k;
+                for (int j = 0; j < kWinQ; ++j) pos[j] = -1;  // index of the last value known to be < q
+#pragma unroll 1
+                for (int len = n; len > 1;) {
+                    int half = len >> 1;
+                    if ((half & 15) == 0) --half;
+                    len -= half;
+#pragma unroll
+                    for (int j = 0; j < kWinQ; ++j) pos[j] += xs[pos[j] + half] < q[j] ? half : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < kWinQ; ++j) {
+                    const int p = pos[j] + 1 + (xs[pos[j] + 1] < q[j] ? 1 : 0);
+                    lo[j] = p - k > 0 ? p - k : 0;
+                    hi[j] = p < n - k ? p : n - k;
+                }
             }
 #pragma unroll 1
             for (int s = 0; s < nsteps; ++s) {
