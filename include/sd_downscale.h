@@ -84,6 +84,7 @@ typedef struct sd_ctx sd_ctx;
 typedef struct sd_bcsd_state sd_bcsd_state;
 typedef struct sd_analog_state sd_analog_state;
 typedef struct sd_qm_state sd_qm_state;
+typedef struct sd_linreg_state sd_linreg_state;
 
 /* ---- library / context ---------------------------------------------------------------------- */
 int sd_version(void);
@@ -194,6 +195,23 @@ int sd_qm_state_info(const sd_qm_state* st, int64_t* T, int64_t* C);
 /* sorted fit series [C][T] (cell-major) and per-cell status; any pointer may be NULL */
 int sd_qm_state_export(const sd_qm_state* st, double* x_sorted, double* y_sorted, int32_t* cell_status);
 int sd_qm_state_destroy(sd_qm_state* st);
+
+/* ---- PureRegression (thresh=None) ------------------------------------------------------------------
+ * Replaces core.py:86-96 / 137-141 looping gard.py:414-470: per cell an ordinary least-squares fit of y [T, C] on
+ * X [T, F, C] (centred lstsq like sklearn's LinearRegression, minimum-norm for collinear features) and its RMSE
+ * (fit_error_); predict writes out [Tq, 3, C] = pred / 1.0 / fit_error_ (gard.py:254-255 column order). */
+int sd_linreg_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int F, int64_t C, sd_linreg_state** out);
+int sd_linreg_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t ld, int64_t T, int F, int64_t C,
+                      sd_linreg_state** out);
+int sd_linreg_predict(sd_ctx* ctx, const sd_linreg_state* st, const double* Xq, int64_t Tq, double* out,
+                      int32_t* cell_status);
+int sd_linreg_predict_dev(sd_ctx* ctx, const sd_linreg_state* st, const double* Xq_dev, int64_t ld, int64_t Tq,
+                          double* out_dev, int64_t ld_out, int32_t* cell_status);
+int sd_linreg_state_info(const sd_linreg_state* st, int64_t* T, int* F, int64_t* C);
+/* coef [F][C], intercept [C], fit_error [C], status [C]; any pointer may be NULL */
+int sd_linreg_state_export(const sd_linreg_state* st, double* coef, double* intercept, double* fit_error,
+                           int32_t* cell_status);
+int sd_linreg_state_destroy(sd_linreg_state* st);
 
 #ifdef __cplusplus
 }

@@ -134,3 +134,27 @@ def pointwise_analog(X, y, Xq, n_analogs, kind, thresh=None, sample_inds=None, r
                                           None if sample_inds is None else sample_inds[:, c])
         out[:, :, c] = o
     return out
+
+
+def pure_regression(X, y, Xq):
+    """PureRegression(thresh=None).fit(X, y).predict(Xq) (gard.py:414-470): sklearn LinearRegression = lstsq on the
+    centred data (minimum-norm for collinear features), fit_error_ = RMSE of the fit.  Returns ([Tq,3], coef, intercept,
+    fit_error)."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    Xq = np.asarray(Xq, dtype=np.float64)
+    xm, ym = X.mean(axis=0), y.mean()
+    coef = np.linalg.lstsq(X - xm, y - ym, rcond=None)[0]
+    icpt = ym - xm @ coef
+    err = np.sqrt(np.mean((y - (X @ coef + icpt)) ** 2))
+    out = np.column_stack([Xq @ coef + icpt, np.ones(len(Xq)), np.full(len(Xq), err)])
+    return out, coef, icpt, err
+
+
+def pointwise_pure_regression(X, y, Xq):
+    """Grid driver over the cell axis: X [T,F,C], y [T,C], Xq [Tq,F,C] -> [Tq,3,C]."""
+    C = X.shape[2]
+    out = np.empty((Xq.shape[0], 3, C))
+    for c in range(C):
+        out[:, :, c] = pure_regression(X[:, :, c], y[:, c], Xq[:, :, c])[0]
+    return out

@@ -27,11 +27,12 @@
 #include <cstdlib>
 
 #include "sd_internal.h"
+#include "sd_lsq.h"
 #include "sd_sortnet.h"
 
 namespace {
 
-constexpr int kMaxF = 8;
+constexpr int kMaxF = sdlsq::kMaxF;
 
 __device__ __forceinline__ bool sd_finite(double v) { return (__double_as_longlong(v) & 0x7ff0000000000000ll) != 0x7ff0000000000000ll; }
 
@@ -600,58 +601,7 @@ __device__ void analog_regression(int k, int F, XV xv /* (i,f) */, YV yv /* (i) 
     }
     for (int f = 0; f < F; ++f)
         for (int g = 0; g < f; ++g) A[f][g] = A[g][f];
-    // Minimum-norm least squares like LinearRegression's lstsq (gard.py:215-217): eigen-decomposition of the centred
-    // normal matrix A = V diag(lam) V^T by cyclic Jacobi rotations, coef = sum over the non-null directions of
-    // v (v . b) / lam.  Under-determined (k <= F) and collinear analog sets then give the same coefficients as the
-    // reference's pseudo-inverse.  A direction is null when lam <= 1e-12 * lam_max (singular value below 1e-6 of the
-    // largest: the normal equations cannot resolve more).
-    double V[kMaxF][kMaxF], bvec[kMaxF];
-    for (int f = 0; f < F; ++f) {
-        bvec[f] = A[f][F];
-        for (int g = 0; g < F; ++g) V[f][g] = f == g ? 1.0 : 0.0;
-    }
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        double off = 0.0, diag = 0.0;
-        for (int f = 0; f < F; ++f) {
-            diag += A[f][f] * A[f][f];
-            for (int g = f + 1; g < F; ++g) off += A[f][g] * A[f][g];
-        }
-        if (off <= 1e-30 * diag || off == 0.0) break;
-        for (int p = 0; p < F - 1; ++p)
-            for (int r = p + 1; r < F; ++r) {
-                const double apr = A[p][r];
-                if (apr == 0.0) continue;
-                const double theta = (A[r][r] - A[p][p]) / (2.0 * apr);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-                for (int g = 0; g < F; ++g) {  // A <- J^T A J on rows / columns p, r
-                    const double agp = A[g][p], agr = A[g][r];
-                    A[g][p] = cs * agp - sn * agr;
-                    A[g][r] = sn * agp + cs * agr;
-                }
-                for (int g = 0; g < F; ++g) {
-                    const double apg = A[p][g], arg = A[r][g];
-                    A[p][g] = cs * apg - sn * arg;
-                    A[r][g] = sn * apg + cs * arg;
-                }
-                for (int g = 0; g < F; ++g) {
-                    const double vgp = V[g][p], vgr = V[g][r];
-                    V[g][p] = cs * vgp - sn * vgr;
-                    V[g][r] = sn * vgp + cs * vgr;
-                }
-            }
-    }
-    double lam_max = 0.0;
-    for (int f = 0; f < F; ++f) lam_max = fmax(lam_max, A[f][f]);
-    for (int f = 0; f < F; ++f) coef[f] = 0.0;
-    for (int e = 0; e < F; ++e) {
-        const double lam = A[e][e];
-        if (!(lam > 1e-12 * lam_max)) continue;
-        double vb = 0.0;
-        for (int f = 0; f < F; ++f) vb += V[f][e] * bvec[f];
-        const double w = vb / lam;
-        for (int f = 0; f < F; ++f) coef[f] += V[f][e] * w;
-    }
+    sdlsq::minnorm_solve(F, A, coef);  // like LinearRegression's lstsq (gard.py:215-217)
     double icpt = ym;
     for (int f = 0; f < F; ++f) icpt -= xm[f] * coef[f];
     double p = icpt;

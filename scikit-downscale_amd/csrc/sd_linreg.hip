@@ -1,0 +1,339 @@
+// PureRegression with thresh=None (gard.py:367-504), batched over the cell axis: one ordinary least-squares fit of y on
+// the F features per cell (sklearn LinearRegression = centred lstsq, gard.py:439-442), fit_error_ = RMSE of that fit;
+// predict returns [pred, 1.0, fit_error_] per sample (gard.py:462-470).
+//
+// Fields stay in their time-major layout: a workgroup owns 64 adjacent cells x 8 time slices, every load is a
+// 512-byte row fragment, so fit is three streaming passes (means, centred cross products, residuals) and predict one.
+#include <algorithm>
+#include <vector>
+
+#include "sd_internal.h"
+#include "sd_lsq.h"
+
+struct sd_linreg_state {
+    sd_ctx* ctx = nullptr;
+    int64_t T = 0, C = 0;
+    int F = 0;
+    double* coef = nullptr;       // device [F][C]
+    double* intercept = nullptr;  // device [C]
+    double* rmse = nullptr;       // device [C]
+    int32_t* status = nullptr;    // device [C] internal bitmask
+};
+
+namespace {
+
+constexpr int kMaxF = sdlsq::kMaxF;
+constexpr int kCells = 64, kSlices = 8;
+
+__device__ __forceinline__ bool lr_finite(double v) { return (__double_as_longlong(v) & 0x7ff0000000000000ll) != 0x7ff0000000000000ll; }
+
+// sum over the time slices of a workgroup: part[slice][cell] -> every thread gets the total of its cell
+__device__ __forceinline__ double slice_sum(double v, double* part, int cx, int ty) {
+    __syncthreads();
+    part[ty * kCells + cx] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int s = 0; s < kSlices; ++s) t += part[s * kCells + cx];
+    return t;
+}
+
+template <int F>
+__global__ void __launch_bounds__(kCells * kSlices) linreg_fit_kernel(const double* __restrict__ X, const double* __restrict__ y,
+                                                                      int64_t ld, int64_t T, int64_t C,
+                                                                      double* __restrict__ coef_out, double* __restrict__ icpt_out,
+                                                                      double* __restrict__ rmse_out, int32_t* __restrict__ status) {
+    __shared__ double part[kSlices * kCells];
+    __shared__ double model[(F + 1) * kCells];  // coefficients and intercept of the tile's cells
+    const int cx = threadIdx.x % kCells, ty = threadIdx.x / kCells;
+    const int64_t c = (int64_t)blockIdx.x * kCells + cx;
+    const bool live = c < C;
+    const double n = (double)T;
+    // pass 1: means (and the mask / finite bookkeeping of core.py:35-37, base.py:18-20)
+    double sx[F], sy = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int f = 0; f < F; ++f) sx[f] = 0.0;
+    if (live)
+        for (int64_t t = ty; t < T; t += kSlices) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const double v = X[(t * F + f) * ld + c];
+                bad |= !lr_finite(v);
+                sx[f] += v;
+            }
+            const double w = y[t * ld + c];
+            bad |= !lr_finite(w);
+            sy += w;
+        }
+    if (live && ty == 0) {
+        const double first = X[c];
+        if (first != first) atomicOr(&status[c], SDI_MASKED);
+    }
+    if (live && bad) atomicOr(&status[c], SDI_NONFINITE);
+    double xm[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) xm[f] = slice_sum(sx[f], part, cx, ty) / n;
+    const double ym = slice_sum(sy, part, cx, ty) / n;
+    // pass 2: centred cross products (upper triangle) and the right-hand side
+    double S[F][F], b[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        b[f] = 0.0;
+#pragma unroll
+        for (int g = 0; g < F; ++g) S[f][g] = 0.0;
+    }
+    if (live)
+        for (int64_t t = ty; t < T; t += kSlices) {
+            double d[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) d[f] = X[(t * F + f) * ld + c] - xm[f];
+            const double dy = y[t * ld + c] - ym;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                b[f] += d[f] * dy;
+#pragma unroll
+                for (int g = f; g < F; ++g) S[f][g] += d[f] * d[g];
+            }
+        }
+    double A[kMaxF][kMaxF + 1];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        A[f][F] = slice_sum(b[f], part, cx, ty);
+#pragma unroll
+        for (int g = f; g < F; ++g) {
+            const double v = slice_sum(S[f][g], part, cx, ty);
+            A[f][g] = v;
+            A[g][f] = v;
+        }
+    }
+    if (ty == 0) {
+        double coef[kMaxF];
+        sdlsq::minnorm_solve(F, A, coef);
+        double icpt = ym;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            icpt -= xm[f] * coef[f];
+            model[f * kCells + cx] = coef[f];
+        }
+        model[F * kCells + cx] = icpt;
+    }
+    __syncthreads();
+    // pass 3: residuals of the fit (root_mean_squared_error, gard.py:441-442)
+    double cf[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) cf[f] = model[f * kCells + cx];
+    const double icpt = model[F * kCells + cx];
+    double ss = 0.0;
+    if (live)
+        for (int64_t t = ty; t < T; t += kSlices) {
+            double yh = icpt;
+#pragma unroll
+            for (int f = 0; f < F; ++f) yh += X[(t * F + f) * ld + c] * cf[f];
+            const double r = y[t * ld + c] - yh;
+            ss += r * r;
+        }
+    ss = slice_sum(ss, part, cx, ty);
+    if (live && ty == 0) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) coef_out[(int64_t)f * C + c] = cf[f];
+        icpt_out[c] = icpt;
+        rmse_out[c] = sqrt(ss / n);
+    }
+}
+
+template <int F>
+__global__ void __launch_bounds__(kCells * kSlices) linreg_predict_kernel(const double* __restrict__ Xq, int64_t ld, int64_t Tq, int64_t C,
+                                                                          const double* __restrict__ coef, const double* __restrict__ icpt_all,
+                                                                          const double* __restrict__ rmse_all,
+                                                                          const int32_t* __restrict__ fit_status, int32_t* __restrict__ status,
+                                                                          double* __restrict__ out, int64_t ld_out) {
+    const int cx = threadIdx.x % kCells, ty = threadIdx.x / kCells;
+    const int64_t c = (int64_t)blockIdx.x * kCells + cx;
+    if (c >= C) return;
+    const bool active = fit_status[c] == 0;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    double cf[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) cf[f] = coef[(int64_t)f * C + c];
+    const double icpt = icpt_all[c], rmse = rmse_all[c];
+    bool bad = false;
+    const int64_t t0 = (int64_t)blockIdx.y * kSlices * 16;
+    for (int64_t t = t0 + ty; t < t0 + kSlices * 16 && t < Tq; t += kSlices) {
+        double p = icpt;
+        bool fin = true;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const double v = Xq[(t * F + f) * ld + c];
+            fin = fin && lr_finite(v);
+            p += v * cf[f];
+        }
+        bad |= !fin;
+        const bool okq = active && fin;
+        out[(t * 3 + 0) * ld_out + c] = okq ? p : nan;      // gard.py:465
+        out[(t * 3 + 1) * ld_out + c] = okq ? 1.0 : nan;    // gard.py:459
+        out[(t * 3 + 2) * ld_out + c] = okq ? rmse : nan;   // gard.py:461-463
+    }
+    if (active && bad) atomicOr(&status[c], SDI_NONFINITE);
+}
+
+__global__ void __launch_bounds__(256) linreg_status_public_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b, int64_t C,
+                                                                   int32_t* __restrict__ outp) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const int32_t bits = a[c] | (b ? b[c] : 0);
+        outp[c] = (bits & SDI_MASKED) ? SD_CELL_MASKED : (bits & SDI_NONFINITE) ? SD_CELL_NONFINITE : SD_CELL_OK;
+    }
+}
+
+template <int F>
+int launch_fit(sd_ctx* ctx, const double* X, const double* y, int64_t ld, sd_linreg_state* st) {
+    SD_LAUNCH(ctx, "linreg_fit_kernel", linreg_fit_kernel<F>, dim3((unsigned)((st->C + kCells - 1) / kCells)), dim3(kCells * kSlices), 0,
+              X, y, ld, st->T, st->C, st->coef, st->intercept, st->rmse, st->status);
+    return SD_OK;
+}
+
+template <int F>
+int launch_predict(sd_ctx* ctx, const sd_linreg_state* st, const double* Xq, int64_t ld, int64_t Tq, int32_t* status_p, double* out,
+                   int64_t ld_out) {
+    const dim3 grid((unsigned)((st->C + kCells - 1) / kCells), (unsigned)((Tq + kSlices * 16 - 1) / (kSlices * 16)));
+    SD_LAUNCH(ctx, "linreg_predict_kernel", linreg_predict_kernel<F>, grid, dim3(kCells * kSlices), 0, Xq, ld, Tq, st->C,
+              (const double*)st->coef, (const double*)st->intercept, (const double*)st->rmse, (const int32_t*)st->status, status_p, out,
+              ld_out);
+    return SD_OK;
+}
+
+#define LINREG_DISPATCH_F(F, fn, ...)                      \
+    switch (F) {                                           \
+        case 1: SD_TRY(fn<1>(__VA_ARGS__)); break;         \
+        case 2: SD_TRY(fn<2>(__VA_ARGS__)); break;         \
+        case 3: SD_TRY(fn<3>(__VA_ARGS__)); break;         \
+        case 4: SD_TRY(fn<4>(__VA_ARGS__)); break;         \
+        case 5: SD_TRY(fn<5>(__VA_ARGS__)); break;         \
+        case 6: SD_TRY(fn<6>(__VA_ARGS__)); break;         \
+        case 7: SD_TRY(fn<7>(__VA_ARGS__)); break;         \
+        default: SD_TRY(fn<8>(__VA_ARGS__)); break;        \
+    }
+
+}  // namespace
+
+extern "C" {
+
+int sd_linreg_state_destroy(sd_linreg_state* st) {
+    if (!st) return SD_OK;
+    if (st->ctx) {
+        (void)hipSetDevice(st->ctx->device);
+        (void)hipStreamSynchronize(st->ctx->stream);
+    }
+    sd_pool_release(st->ctx, st->coef);
+    sd_pool_release(st->ctx, st->intercept);
+    sd_pool_release(st->ctx, st->rmse);
+    sd_pool_release(st->ctx, st->status);
+    delete st;
+    return SD_OK;
+}
+
+int sd_linreg_state_info(const sd_linreg_state* st, int64_t* T, int* F, int64_t* C) {
+    SD_CHECK_ARG(st, "state is NULL");
+    if (T) *T = st->T;
+    if (F) *F = st->F;
+    if (C) *C = st->C;
+    return SD_OK;
+}
+
+int sd_linreg_state_export(const sd_linreg_state* st, double* coef, double* intercept, double* fit_error, int32_t* cell_status) {
+    SD_CHECK_ARG(st, "state is NULL");
+    sd_ctx* ctx = st->ctx;
+    SD_HIP(hipSetDevice(ctx->device));
+    if (coef) SD_HIP(hipMemcpyAsync(coef, st->coef, sizeof(double) * (size_t)st->F * st->C, hipMemcpyDeviceToHost, ctx->stream));
+    if (intercept) SD_HIP(hipMemcpyAsync(intercept, st->intercept, sizeof(double) * st->C, hipMemcpyDeviceToHost, ctx->stream));
+    if (fit_error) SD_HIP(hipMemcpyAsync(fit_error, st->rmse, sizeof(double) * st->C, hipMemcpyDeviceToHost, ctx->stream));
+    if (cell_status) {
+        std::vector<int32_t> bits(st->C);
+        SD_HIP(hipMemcpyAsync(bits.data(), st->status, sizeof(int32_t) * st->C, hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        for (int64_t c = 0; c < st->C; ++c) cell_status[c] = sd_public_status(bits[c]);
+    }
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_linreg_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t ld, int64_t T, int F, int64_t C,
+                      sd_linreg_state** out) {
+    SD_CHECK_ARG(ctx && X_dev && y_dev && out, "sd_linreg_fit: NULL argument");
+    SD_CHECK_ARG(T > 0 && C > 0 && ld >= C, "sd_linreg_fit: bad sizes");
+    SD_CHECK_ARG(F >= 1 && F <= kMaxF, "sd_linreg_fit: F=%d outside [1,%d]", F, kMaxF);
+    *out = nullptr;
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_linreg_state* st = new sd_linreg_state();
+    st->ctx = ctx;
+    st->T = T;
+    st->F = F;
+    st->C = C;
+    auto body = [&]() -> int {
+        SD_HIP(sd_pool_malloc(ctx, (void**)&st->coef, sizeof(double) * (size_t)F * C));
+        SD_HIP(sd_pool_malloc(ctx, (void**)&st->intercept, sizeof(double) * C));
+        SD_HIP(sd_pool_malloc(ctx, (void**)&st->rmse, sizeof(double) * C));
+        SD_HIP(sd_pool_malloc(ctx, (void**)&st->status, sizeof(int32_t) * C));
+        SD_HIP(hipMemsetAsync(st->status, 0, sizeof(int32_t) * C, ctx->stream));
+        LINREG_DISPATCH_F(F, launch_fit, ctx, X_dev, y_dev, ld, st);
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        return SD_OK;
+    };
+    const int rc = body();
+    if (rc != SD_OK) {
+        sd_linreg_state_destroy(st);
+        return rc;
+    }
+    *out = st;
+    return SD_OK;
+}
+
+int sd_linreg_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int F, int64_t C, sd_linreg_state** out) {
+    SD_CHECK_ARG(ctx && X && y && out, "sd_linreg_fit: NULL argument");
+    SD_CHECK_ARG(T > 0 && C > 0 && F >= 1, "sd_linreg_fit: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_scratch dX, dy;
+    SD_HIP(dX.alloc(ctx, sizeof(double) * (size_t)T * F * C));
+    SD_HIP(dy.alloc(ctx, sizeof(double) * (size_t)T * C));
+    SD_HIP(hipMemcpyAsync(dX.p, X, sizeof(double) * (size_t)T * F * C, hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(hipMemcpyAsync(dy.p, y, sizeof(double) * (size_t)T * C, hipMemcpyHostToDevice, ctx->stream));
+    return sd_linreg_fit_dev(ctx, dX.as<double>(), dy.as<double>(), C, T, F, C, out);
+}
+
+int sd_linreg_predict_dev(sd_ctx* ctx, const sd_linreg_state* st, const double* Xq_dev, int64_t ld, int64_t Tq, double* out_dev,
+                          int64_t ld_out, int32_t* cell_status) {
+    SD_CHECK_ARG(ctx && st && Xq_dev && out_dev, "sd_linreg_predict: NULL argument");
+    SD_CHECK_ARG(Tq > 0 && ld >= st->C && ld_out >= st->C, "sd_linreg_predict: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    const int64_t C = st->C;
+    sd_scratch status_p, status_pub;
+    SD_HIP(status_p.alloc(ctx, sizeof(int32_t) * C));
+    SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
+    LINREG_DISPATCH_F(st->F, launch_predict, ctx, st, Xq_dev, ld, Tq, status_p.as<int32_t>(), out_dev, ld_out);
+    if (cell_status) {
+        SD_HIP(status_pub.alloc(ctx, sizeof(int32_t) * C));
+        SD_LAUNCH(ctx, "linreg_status_public_kernel", linreg_status_public_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
+                  (const int32_t*)st->status, (const int32_t*)status_p.p, C, status_pub.as<int32_t>());
+        SD_HIP(hipMemcpyAsync(cell_status, status_pub.p, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_linreg_predict(sd_ctx* ctx, const sd_linreg_state* st, const double* Xq, int64_t Tq, double* out, int32_t* cell_status) {
+    SD_CHECK_ARG(ctx && st && Xq && out, "sd_linreg_predict: NULL argument");
+    SD_CHECK_ARG(Tq > 0, "sd_linreg_predict: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_scratch dX, dout;
+    const size_t in_bytes = sizeof(double) * (size_t)Tq * st->F * st->C, out_bytes = sizeof(double) * (size_t)Tq * 3 * st->C;
+    SD_HIP(dX.alloc(ctx, in_bytes));
+    SD_HIP(dout.alloc(ctx, out_bytes));
+    SD_HIP(hipMemcpyAsync(dX.p, Xq, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_linreg_predict_dev(ctx, st, dX.as<double>(), st->C, Tq, dout.as<double>(), st->C, cell_status));
+    SD_HIP(hipMemcpyAsync(out, dout.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+}  // extern "C"

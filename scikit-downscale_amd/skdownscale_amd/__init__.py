@@ -5,7 +5,7 @@ Public names mirror ``skdownscale.pointwise_models`` for the hot path only
 """
 from .bcsd import BcsdGridModel, BcsdPrecipitation, BcsdTemperature
 from .core import GridArray, GridDataset, PointWiseDownscaler
-from .gard import AnalogGridModel, AnalogRegression, PureAnalog
+from .gard import AnalogGridModel, AnalogRegression, PureAnalog, PureRegression, RegressionGridModel
 from .groupers import DAY_GROUPER, MONTH_GROUPER
 from .quantile import (CunnaneGridModel, CunnaneTransformer, EquidistantCdfMatcher, QmGridModel, QuantileMapper,
                        QuantileMapperGridModel, QuantileMappingReressor)
@@ -29,5 +29,7 @@ __all__ = [
     "CunnaneTransformer",
     "CunnaneGridModel",
     "QuantileMapperGridModel",
+    "PureRegression",
+    "RegressionGridModel",
 ]
 __version__ = "0.1.0"

@@ -68,6 +68,13 @@ SIGNATURES = {
     "sd_analogreg_predict_dev": [_p, _p, _p, _i64, _i64, _int, _p, _i64, _p],
     "sd_analog_state_info": [_p, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_i64)],
     "sd_analog_state_destroy": [_p],
+    "sd_linreg_fit": [_p, _p, _p, _i64, _int, _i64, C.POINTER(_p)],
+    "sd_linreg_fit_dev": [_p, _p, _p, _i64, _i64, _int, _i64, C.POINTER(_p)],
+    "sd_linreg_predict": [_p, _p, _p, _i64, _p, _p],
+    "sd_linreg_predict_dev": [_p, _p, _p, _i64, _i64, _p, _i64, _p],
+    "sd_linreg_state_info": [_p, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_i64)],
+    "sd_linreg_state_export": [_p, _p, _p, _p, _p],
+    "sd_linreg_state_destroy": [_p],
     "sd_qm_fit": [_p, _p, _p, _i64, _i64, C.POINTER(_p)],
     "sd_qm_fit_dev": [_p, _p, _p, _i64, _i64, _i64, C.POINTER(_p)],
     "sd_qm_predict": [_p, _p, _int, _int, _p, _i64, _p, _p],

@@ -18,7 +18,7 @@ import pandas as pd
 
 from . import _lib
 from .bcsd import BcsdBase, BcsdGridModel, check_supported
-from .gard import AnalogBase, AnalogGridModel, AnalogRegression, PureAnalog
+from .gard import AnalogBase, AnalogGridModel, AnalogRegression, PureAnalog, PureRegression, RegressionGridModel
 from .quantile import (CunnaneGridModel, CunnaneTransformer, QmGridModel, QuantileMapper, QuantileMapperGridModel,
                        QuantileMappingReressor, check_extrapolate)
 
@@ -165,6 +165,9 @@ class PointWiseDownscaler:
             if isinstance(m, AnalogRegression) and (m.thresh is not None or m.lr_kwargs):
                 raise NotImplementedError("AnalogRegression(thresh=... / lr_kwargs) is not supported on the HIP engine")
             return "analog"
+        if isinstance(m, PureRegression):
+            m._check()
+            return "linreg"
         if isinstance(m, QuantileMappingReressor):
             check_extrapolate(m.extrapolate)
             m._engine_code()
@@ -232,8 +235,7 @@ class PointWiseDownscaler:
             gm.status_ = gm.state.export()["status"]
             self._raise_for_status(gm.status_, Xv[:, 0, :], yv)
         else:
-            gm = AnalogGridModel(m.n_analogs)
-            gm.fit(Xv, yv)
+            gm = RegressionGridModel().fit(Xv, yv) if kind == "linreg" else AnalogGridModel(m.n_analogs).fit(Xv, yv)
             gm.status_ = np.where(mask, 0, _lib.CELL_MASKED).astype(np.int32)
             bad = mask & ~(np.isfinite(Xv).all(axis=(0, 1)) & np.isfinite(yv).all(axis=0))
             if bad.any():
@@ -306,9 +308,11 @@ class PointWiseDownscaler:
             self._raise_for_status(status, Xv[:, 0, :], Xv[:, 0, :])
             vals = out.reshape((T,) + tuple(spatial_shape)).astype(Xg.dtype, copy=False)
             res = GridArray(vals, (self._dim,) + spatial_dims, coords)
-        elif mdl.kind == "analog":
+        elif mdl.kind in ("analog", "linreg"):
             m = self._model
-            if isinstance(m, AnalogRegression):
+            if mdl.kind == "linreg":
+                out, status = mdl.grid_model.predict(Xv)
+            elif isinstance(m, AnalogRegression):
                 out, status = mdl.grid_model.predict_regression(Xv)
             else:
                 out, status = mdl.grid_model.predict_pure(Xv, m.kind, m.thresh)

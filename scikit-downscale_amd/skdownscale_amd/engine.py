@@ -123,6 +123,20 @@ class AnalogState(_State):
         return dict(T=T.value, F=F.value, C=Cc.value)
 
 
+class LinregState(_State):
+    def info(self):
+        T, Cc, F = C.c_int64(), C.c_int64(), C.c_int()
+        check(self.ctx.lib.sd_linreg_state_info(self.vptr, C.byref(T), C.byref(F), C.byref(Cc)))
+        return dict(T=T.value, F=F.value, C=Cc.value)
+
+    def export(self):
+        i = self.info()
+        coef, icpt, err = np.empty((i["F"], i["C"])), np.empty(i["C"]), np.empty(i["C"])
+        status = np.empty(i["C"], dtype=np.int32)
+        check(self.ctx.lib.sd_linreg_state_export(self.vptr, ptr(coef), ptr(icpt), ptr(err), ptr(status)))
+        return dict(coef=coef, intercept=icpt, fit_error=err, status=status)
+
+
 class QmState(_State):
     def info(self):
         T, Cc = C.c_int64(), C.c_int64()
@@ -374,6 +388,35 @@ class Context:
             Tq = Xq.shape[0]
             out = np.empty((Tq, 3, Cc))
             check(self.lib.sd_analogreg_predict(self.handle, state.vptr, ptr(Xq), Tq, k, ptr(out), ptr(status)))
+        return out, status
+
+
+    # ---- PureRegression (thresh=None) ----
+    def linreg_fit(self, X, y):
+        """X [T,F,C], y [T,C] numpy or DeviceArray -> LinregState (coefficients, intercept, fit error per cell)."""
+        h = C.c_void_p()
+        if isinstance(X, DeviceArray):
+            T, F, Cc = X.shape
+            assert X.ld == y.ld
+            check(self.lib.sd_linreg_fit_dev(self.handle, X.vptr, y.vptr, y.ld, T, F, Cc, C.byref(h)))
+        else:
+            X, y = _lib.as_f64(X), _lib.as_f64(y)
+            T, F, Cc = X.shape
+            check(self.lib.sd_linreg_fit(self.handle, ptr(X), ptr(y), T, F, Cc, C.byref(h)))
+        return LinregState(self, h.value, self.lib.sd_linreg_state_destroy)
+
+    def linreg_predict(self, state, Xq, out=None):
+        Cc = state.info()["C"]
+        status = np.empty(Cc, dtype=np.int32)
+        if isinstance(Xq, DeviceArray):
+            Tq = Xq.shape[0]
+            out = self.empty((Tq, 3, Cc)) if out is None else out
+            check(self.lib.sd_linreg_predict_dev(self.handle, state.vptr, Xq.vptr, Xq.ld, Tq, out.vptr, out.ld, ptr(status)))
+        else:
+            Xq = _lib.as_f64(Xq)
+            Tq = Xq.shape[0]
+            out = np.empty((Tq, 3, Cc))
+            check(self.lib.sd_linreg_predict(self.handle, state.vptr, ptr(Xq), Tq, ptr(out), ptr(status)))
         return out, status
 
 

@@ -1,7 +1,7 @@
 """GARD analog estimators with the reference's surface, computed by the HIP engine.
 
 Mirrors ``skdownscale/pointwise_models/gard.py``: ``AnalogBase`` (55-98), ``AnalogRegression``
-(101-224, ``thresh=None`` only) and ``PureAnalog`` (227-364).  The KD-tree of the reference is
+(101-224, ``thresh=None`` only), ``PureAnalog`` (227-364) and ``PureRegression`` (367-504, ``thresh=None`` only).  The KD-tree of the reference is
 replaced by batched exact nearest-neighbour search in ``csrc/sd_analog.hip`` (neighbours ordered by
 (squared distance, training index); identical to ``KDTree.query`` on tie-free data).
 """
@@ -169,3 +169,101 @@ class PureAnalog(AnalogBase):
         k = 1 if (self.kind == "best_analog" or self.n_analogs == 1) else self.k_
         _, _, inds, dist = self._grid.ctx.analog_predict(self._grid.state, X2[:, :, None], k, _lib.ANALOG_MEAN, None, None, True)
         return dist[:, :, 0], inds[:, :, 0]
+
+
+class RegressionGridModel:
+    """Batched PureRegression(thresh=None) over the cell axis: X [T,F,C], y [T,C], Xq [Tq,F,C] (numpy or DeviceArray)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        self.state = None
+
+    def fit(self, X, y):
+        self.state = self.ctx.linreg_fit(X, y)
+        return self
+
+    def predict(self, Xq, out=None):
+        if self.state is None:
+            raise NotFittedError("This regression grid model is not fitted yet.")
+        return self.ctx.linreg_predict(self.state, Xq, out=out)
+
+    def export(self):
+        return self.state.export()
+
+
+class _FittedLinearModel:
+    """``linear_model_`` stand-in: the attributes of the fitted sklearn LinearRegression (gard.py:439)."""
+
+    def __init__(self, coef, intercept):
+        self.coef_ = coef
+        self.intercept_ = intercept
+
+    def predict(self, X):
+        return _as_2d(X, "X") @ self.coef_ + self.intercept_
+
+
+class PureRegression(RegressorMixin, BaseEstimator):
+    """PureRegression (gard.py:367-504) with ``thresh=None``: ordinary least squares of y on the features, the RMSE of the
+    fit as prediction error, exceedance probability 1.  ``thresh`` (a LogisticRegression for the exceedance probability,
+    lbfgs) and non-default ``linear_kwargs`` are outside the engine's path and raise NotImplementedError."""
+
+    _fit_attributes = ["logistic_model_", "linear_model_", "fit_error_"]
+    n_outputs = 3
+    output_names = OUTPUT_NAMES
+
+    def __init__(self, thresh=None, logistic_kwargs=None, linear_kwargs=None):
+        self.thresh = thresh
+        self.logistic_kwargs = logistic_kwargs
+        self.linear_kwargs = linear_kwargs
+
+    def _check(self):
+        if self.thresh is not None:
+            raise NotImplementedError("PureRegression(thresh=...) (LogisticRegression, gard.py:416-420) is not supported on "
+                                      "the HIP engine")
+        if self.linear_kwargs:
+            raise NotImplementedError("linear_kwargs are not supported on the HIP engine (plain OLS with intercept)")
+
+    def fit(self, X, y):
+        self._check()
+        X2 = _as_2d(X, "X")
+        y1 = _as_2d(y, "y")
+        if y1.ndim == 2:
+            if y1.shape[1] != 1:
+                raise ValueError(f"y should be a 1d array, got an array of shape {y1.shape} instead.")
+            y1 = y1[:, 0]
+        if len(X2) != len(y1):
+            raise ValueError(f"Found input variables with inconsistent numbers of samples: [{len(X2)}, {len(y1)}]")
+        self.n_features_in_ = X2.shape[1]
+        self._grid = RegressionGridModel().fit(X2[:, :, None], y1[:, None])
+        e = self._grid.export()
+        self.linear_model_ = _FittedLinearModel(e["coef"][:, 0].copy(), float(e["intercept"][0]))
+        self.fit_error_ = float(e["fit_error"][0])
+        return self
+
+    def predict(self, X):
+        if not hasattr(self, "linear_model_"):
+            raise NotFittedError(
+                f"This {type(self).__name__} instance is not fitted yet. Call 'fit' with appropriate arguments before "
+                "using this estimator.")
+        X2 = _as_2d(X, "X")
+        if X2.shape[1] != self.n_features_in_:
+            raise ValueError(f"X has {X2.shape[1]} features, but {type(self).__name__} is expecting "
+                             f"{self.n_features_in_} features as input.")
+        if getattr(self, "_grid", None) is None:  # unpickled: the fitted numbers are enough
+            pred = self.linear_model_.predict(X2)
+            out = np.column_stack([pred, np.ones(len(X2)), np.full(len(X2), self.fit_error_)])
+        else:
+            out, _ = self._grid.predict(X2[:, :, None])
+            out = out[:, :, 0]
+        return pd.DataFrame(out, columns=self.output_names) if isinstance(X, pd.DataFrame) else out  # gard.py:467-489
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_grid", None)
+        return d
+
+    def __sklearn_tags__(self):
+        from dataclasses import replace
+
+        tags = super().__sklearn_tags__()
+        return replace(tags, _skip_test="GARD models output 3 columns pandas dataframe instead of one during predict")

@@ -127,6 +127,29 @@ def test_sharded_gather_world_size_2_gloo(tmp_path):
     assert "GATHER_OK" in res.stdout
 
 
+def test_pure_regression_argument_checks():
+    """PureRegression behaviour that needs no GPU (gard.py:402-412): parameters, refused configurations, fit state."""
+    from sklearn.base import clone
+    from sklearn.exceptions import NotFittedError
+
+    from skdownscale_amd import PureRegression
+
+    m = PureRegression()
+    assert clone(m).get_params() == dict(thresh=None, logistic_kwargs=None, linear_kwargs=None)
+    assert m.n_outputs == 3 and m.output_names == ["pred", "exceedance_prob", "prediction_error"]
+    X, y = np.arange(10.0).reshape(-1, 1), np.arange(10.0)
+    with pytest.raises(NotImplementedError, match="thresh"):
+        PureRegression(thresh=1.0).fit(X, y)
+    with pytest.raises(NotImplementedError, match="linear_kwargs"):
+        PureRegression(linear_kwargs={"fit_intercept": False}).fit(X, y)
+    with pytest.raises(NotFittedError):
+        m.predict(X)
+    with pytest.raises(ValueError, match="NaN"):
+        m.fit(X * np.nan, y)
+    with pytest.raises(ValueError, match="inconsistent numbers of samples"):
+        m.fit(X, y[:5])
+
+
 def test_cunnane_transformer_argument_checks():
     """CunnaneTransformer behaviour that needs no GPU (quantile.py:420-463): parameters, feature count, fit state."""
     from sklearn.base import clone

@@ -181,3 +181,18 @@ def test_cunnane_oracle_matches_golden():
                 assert_close(qo.cunnane_inverse(cdf, g[f"p{case}"], ex, ne), g[f"inv{case}_{ex}_{ne}"], rtol=1e-12,
                              what=f"cunnane inverse {case} {ex} {ne}")
         assert np.array_equal(qo.cunnane_transform(cdf, g[f"x{case}"], "both"), g[f"fit_transform{case}"])
+
+
+def test_pure_regression_oracle_matches_golden():
+    """PureRegression(thresh=None) restatement (oracle/analog_oracle.py) vs g11_pure_regression.npz: 1 / 3 features,
+    two collinear features (minimum-norm coefficients), a noise-free target."""
+    import analog_oracle as ao
+
+    g = load("g11_pure_regression")
+    for case in range(4):
+        out, coef, icpt, err = ao.pure_regression(g[f"X{case}"], g[f"y{case}"], g[f"Xq{case}"])
+        assert_close(out[:, 0], g[f"out{case}"][:, 0], rtol=1e-9, what=f"pure regression pred {case}")
+        assert np.array_equal(out[:, 1], g[f"out{case}"][:, 1])
+        assert_close(coef, g[f"coef{case}"], rtol=1e-9, what="coef")
+        assert abs(icpt - float(g[f"intercept{case}"])) <= 1e-9 * (1 + abs(icpt))
+        assert abs(err - float(g[f"fit_error{case}"])) <= 1e-9 * (1 + err) + 1e-12

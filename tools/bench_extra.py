@@ -22,7 +22,7 @@ from skdownscale_amd.engine import Context  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["bcsd_pr", "analog", "analogreg", "qmr", "ecm"], default="analog")
+    ap.add_argument("--workload", choices=["bcsd_pr", "analog", "analogreg", "qmr", "ecm", "pure_regression"], default="analog")
     ap.add_argument("--cells", type=int, default=8192)
     ap.add_argument("--times", type=int, default=14600)
     ap.add_argument("--steps", type=int, default=2)
@@ -71,6 +71,11 @@ def main():
         kinds = {"best_analog": 0, "sample_analogs": 1, "weight_analogs": 2, "mean_analogs": 3}
 
         def step():
+            if args.workload == "pure_regression":
+                st = ctx.linreg_fit(X3, y)
+                r = ctx.linreg_predict(st, Xq3, out=out)
+                st.close()
+                return r
             st = ctx.analog_fit(X3, y)
             if args.workload == "analog":
                 k_eff = 1 if args.kind == "best_analog" else args.k  # gard.py:291-296: best_analog queries one neighbour
@@ -80,7 +85,9 @@ def main():
             st.close()
             return r
         bytes_per_cell = 8 * (F * T + T + F * T + 3 * T)
-        name = f"{'PureAnalog ' + args.kind if args.workload == 'analog' else 'AnalogRegression'} k={args.k} F={args.features}, {C} cells x {T} steps"
+        label = {"analog": "PureAnalog " + args.kind + f" k={args.k}", "analogreg": f"AnalogRegression k={args.k}",
+                 "pure_regression": "PureRegression"}[args.workload]
+        name = f"{label} F={args.features}, {C} cells x {T} steps"
     step()
     ctx.synchronize()
     ctx.prof_reset()
