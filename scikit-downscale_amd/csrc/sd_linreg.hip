@@ -3,7 +3,8 @@
 // predict returns [pred, 1.0, fit_error_] per sample (gard.py:462-470).
 //
 // Fields stay in their time-major layout: a workgroup owns 64 adjacent cells x 8 time slices, every load is a
-// 512-byte row fragment, so fit is three streaming passes (means, centred cross products, residuals) and predict one.
+// 512-byte row fragment, so fit is two streaming passes (shifted sums and cross products, then the residuals) and
+// predict one.
 #include <algorithm>
 #include <vector>
 
@@ -49,60 +50,56 @@ __global__ void __launch_bounds__(kCells * kSlices) linreg_fit_kernel(const doub
     const int64_t c = (int64_t)blockIdx.x * kCells + cx;
     const bool live = c < C;
     const double n = (double)T;
-    // pass 1: means (and the mask / finite bookkeeping of core.py:35-37, base.py:18-20)
-    double sx[F], sy = 0.0;
+    // pass 1: sums and cross products of the data shifted by the cell's first sample (one pass; the shift keeps the
+    // centring subtraction below benign), plus the mask / finite bookkeeping of core.py:35-37, base.py:18-20
+    double x0[F], sx[F], S[F][F], b[F], sy = 0.0;
     bool bad = false;
 #pragma unroll
-    for (int f = 0; f < F; ++f) sx[f] = 0.0;
-    if (live)
-        for (int64_t t = ty; t < T; t += kSlices) {
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const double v = X[(t * F + f) * ld + c];
-                bad |= !lr_finite(v);
-                sx[f] += v;
-            }
-            const double w = y[t * ld + c];
-            bad |= !lr_finite(w);
-            sy += w;
-        }
-    if (live && ty == 0) {
-        const double first = X[c];
-        if (first != first) atomicOr(&status[c], SDI_MASKED);
-    }
-    if (live && bad) atomicOr(&status[c], SDI_NONFINITE);
-    double xm[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f) xm[f] = slice_sum(sx[f], part, cx, ty) / n;
-    const double ym = slice_sum(sy, part, cx, ty) / n;
-    // pass 2: centred cross products (upper triangle) and the right-hand side
-    double S[F][F], b[F];
-#pragma unroll
     for (int f = 0; f < F; ++f) {
+        x0[f] = live ? X[(int64_t)f * ld + c] : 0.0;
+        sx[f] = 0.0;
         b[f] = 0.0;
 #pragma unroll
         for (int g = 0; g < F; ++g) S[f][g] = 0.0;
     }
+    const double y0 = live ? y[c] : 0.0;
     if (live)
         for (int64_t t = ty; t < T; t += kSlices) {
             double d[F];
 #pragma unroll
-            for (int f = 0; f < F; ++f) d[f] = X[(t * F + f) * ld + c] - xm[f];
-            const double dy = y[t * ld + c] - ym;
+            for (int f = 0; f < F; ++f) {
+                const double v = X[(t * F + f) * ld + c];
+                bad |= !lr_finite(v);
+                d[f] = v - x0[f];
+                sx[f] += d[f];
+            }
+            const double w = y[t * ld + c];
+            bad |= !lr_finite(w);
+            const double e = w - y0;
+            sy += e;
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                b[f] += d[f] * dy;
+                b[f] += d[f] * e;
 #pragma unroll
                 for (int g = f; g < F; ++g) S[f][g] += d[f] * d[g];
             }
         }
+    if (live && ty == 0 && x0[0] != x0[0]) atomicOr(&status[c], SDI_MASKED);
+    if (live && bad) atomicOr(&status[c], SDI_NONFINITE);
+    double xm[F], dm[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        dm[f] = slice_sum(sx[f], part, cx, ty) / n;  // mean of the shifted feature
+        xm[f] = x0[f] + dm[f];
+    }
+    const double em = slice_sum(sy, part, cx, ty) / n, ym = y0 + em;
     double A[kMaxF][kMaxF + 1];
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        A[f][F] = slice_sum(b[f], part, cx, ty);
+        A[f][F] = slice_sum(b[f], part, cx, ty) - n * dm[f] * em;  // centred: sum d e - n mean(d) mean(e)
 #pragma unroll
         for (int g = f; g < F; ++g) {
-            const double v = slice_sum(S[f][g], part, cx, ty);
+            const double v = slice_sum(S[f][g], part, cx, ty) - n * dm[f] * dm[g];
             A[f][g] = v;
             A[g][f] = v;
         }
@@ -119,7 +116,7 @@ __global__ void __launch_bounds__(kCells * kSlices) linreg_fit_kernel(const doub
         model[F * kCells + cx] = icpt;
     }
     __syncthreads();
-    // pass 3: residuals of the fit (root_mean_squared_error, gard.py:441-442)
+    // pass 2: residuals of the fit (root_mean_squared_error, gard.py:441-442)
     double cf[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) cf[f] = model[f * kCells + cx];
