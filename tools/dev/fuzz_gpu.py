@@ -18,7 +18,7 @@ def main(n_cases=40, seed=0):
     ctx = default_context()
     rng = np.random.default_rng(seed)
     for it in range(n_cases):
-        what = rng.choice(["bcsd", "analog", "qm"])
+        what = rng.choice(["bcsd", "analog", "qm", "knn", "cunnane", "linreg"])
         if what == "bcsd":
             kind = int(rng.integers(0, 2))
             G = int(rng.choice([1, 3, 12, 12, 12]))
@@ -68,6 +68,59 @@ def main(n_cases=40, seed=0):
             if k >= F + 2 and not quant:
                 exp = ao.pointwise_analog(X, y, Xq, k, 3, regression=True)
                 assert_close(out, exp, what=f"case {it} analogreg F={F} T={T} k={k}")
+        elif what == "knn":
+            # F > 1 neighbour lists: the feature-0 slab search against brute force, dyadic grids put exact ties everywhere
+            F = int(rng.integers(2, 6))
+            T = int(rng.integers(64, 4000))
+            Tq = int(rng.integers(1, 1500))
+            C = int(rng.integers(1, 4))
+            k = int(rng.integers(1, min(T, 200)))
+            X, Xq = rng.standard_normal((T, F, C)), 1.3 * rng.standard_normal((Tq, F, C))
+            if rng.random() < 0.5:
+                g = float(rng.choice([2, 4, 16]))
+                X, Xq = np.round(X * g) / g, np.round(Xq * g) / g
+            y = rng.standard_normal((T, C))
+            os.environ["SD_ANALOG_SLAB_CLASSES"] = str(int(rng.choice([1, 2, 8])))
+            st = ctx.analog_fit(X, y)
+            _, _, inds, dist = ctx.analog_predict(st, Xq, k, 3, want_neighbors=True)
+            del os.environ["SD_ANALOG_SLAB_CLASSES"]
+            for c in range(C):
+                d, i = ao.knn(X[:, :, c], Xq[:, :, c], k)
+                assert np.array_equal(inds[:, :, c], i), f"case {it} knn indices F={F} T={T} Tq={Tq} k={k}"
+                assert np.array_equal(dist[:, :, c], d), f"case {it} knn distances F={F} T={T} Tq={Tq} k={k}"
+        elif what == "cunnane":
+            n = int(rng.integers(2, 9000))
+            Tp = int(rng.integers(1, 3000))
+            C = int(rng.integers(1, 6))
+            X = np.round(5 + 2 * rng.standard_normal((n, C)), int(rng.choice([1, 3, 12])))
+            Xn = 5 + 2.4 * rng.standard_normal((Tp, C))
+            P = rng.uniform(-0.1, 1.1, (Tp, C))
+            ex = [None, "min", "max", "both", "1to1"][int(rng.integers(0, 5))]
+            ne = int(rng.integers(1, 15))
+            st = ctx.qm_fit(X)
+            fwd, _ = ctx.qm_cunnane(st, 0, Xn, ex, ne)
+            inv, _ = ctx.qm_cunnane(st, 1, P, ex, ne)
+            for c in range(C):
+                cdf = qo.cunnane_fit(X[:, c])
+                exp = qo.cunnane_transform(cdf, Xn[:, c], ex)
+                fin = np.isfinite(exp)
+                assert np.array_equal(fwd[~fin, c], exp[~fin])
+                assert_close(fwd[fin, c], exp[fin], rtol=1e-12, what=f"case {it} cunnane forward n={n} {ex}")
+                assert_close(inv[:, c], qo.cunnane_inverse(cdf, P[:, c], ex, ne), rtol=1e-8, what=f"case {it} cunnane inverse n={n} {ex} {ne}")
+        elif what == "linreg":
+            F = int(rng.integers(1, 9))
+            T = int(rng.integers(F + 2, 5000))
+            Tq = int(rng.integers(1, 1000))
+            C = int(rng.integers(1, 200))
+            X = 280 + 10 * rng.standard_normal((T, F, C))
+            y = np.einsum("tfc,fc->tc", X, rng.standard_normal((F, C))) + rng.standard_normal((T, C))
+            Xq = 280 + 10 * rng.standard_normal((Tq, F, C))
+            st = ctx.linreg_fit(X, y)
+            out, status = ctx.linreg_predict(st, Xq)
+            assert (status == 0).all()
+            exp = ao.pointwise_pure_regression(X, y, Xq)
+            assert_close(out[:, 0], exp[:, 0], rtol=1e-8, scale=float(np.std(y)), what=f"case {it} linreg F={F} T={T} C={C}")
+            assert_close(out[:, 2], exp[:, 2], rtol=1e-8, scale=float(np.std(y)), what=f"case {it} linreg fit error")
         else:
             T = int(rng.integers(21, 9000))
             Tp = int(rng.integers(1, 9000))
