@@ -67,23 +67,30 @@ def cpu_baseline(index, seed, c_full, target_seconds, check=None):
     threads = min(c_oracle.max_threads(), os.cpu_count() or 1)
     gid = (np.asarray(index.month) - 1).astype(np.int32)
 
-    def run(n):
+    def run(n, seconds=0.0):
+        """one pass over n cells, repeated until `seconds` of oracle time have been spent (same sample: it only has to
+        be generated once, by the NumPy mirror of the device generator)"""
         cells = np.arange(n)
         X = synth.tas_field("X_hist", seed, index, cells, c_full)
         y = synth.tas_field("y_obs", seed, index, cells, c_full)
         Xp = synth.tas_field("X_fut", seed, index, cells, c_full)
-        t0 = time.perf_counter()
-        out, st = c_oracle.bcsd_fit_predict(0, X, y, Xp, gid, gid, nthreads=threads)
-        return time.perf_counter() - t0, out
+        spent, reps = 0.0, 0
+        while reps == 0 or (spent < seconds and reps < 16):
+            t0 = time.perf_counter()
+            out, st = c_oracle.bcsd_fit_predict(0, X, y, Xp, gid, gid, nthreads=threads)
+            spent += time.perf_counter() - t0
+            reps += 1
+        return spent, reps, out
 
     n0 = 4 * threads
-    dt, exp = run(n0)
+    dt, _, exp = run(n0)
     parity = check(exp) if check is not None else None
     rate = n0 / dt
     n = int(max(n0, min(rate * target_seconds, 8192)))
-    dt, _ = run(n)
-    return {"value": n / dt, "unit": "cells/s", "cores": threads, "kind": "port",
-            "sample": f"{n} cells x {len(index)} steps, oracle/sd_oracle.c (OpenMP, {threads} threads), {dt:.1f} s"}, parity
+    dt, reps, _ = run(n, target_seconds)
+    return {"value": n * reps / dt, "unit": "cells/s", "cores": threads, "kind": "port",
+            "sample": f"{n} cells x {len(index)} steps x {reps} passes, oracle/sd_oracle.c (OpenMP, {threads} threads), "
+                      f"{dt:.1f} s"}, parity
 
 
 def main():
