@@ -237,7 +237,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "kernel": "+".join(sorted(kern)), "kernel_ms_per_step": kernel_ms,
                 "algorithmic_bytes_per_step": alg_bytes,
-                "per_kernel_avg_ms": kern}
+                "per_kernel_avg_ms": kern, "launches_per_step": launches_per_step}
     line = {
         "metric": "grid-cells downscaled/sec (fit+predict), 40yr daily series",
         "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

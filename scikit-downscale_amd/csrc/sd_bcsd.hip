@@ -373,6 +373,17 @@ bool rs_one_kernel() {
     return e && e[0] == '1';
 }
 
+// longest segment of every group over one or two group tables (host offsets [G+1])
+std::vector<int> group_lengths(const std::vector<int64_t>& a, const std::vector<int64_t>* b, int G) {
+    std::vector<int> n((size_t)G);
+    for (int g = 0; g < G; ++g) {
+        int64_t v = a[g + 1] - a[g];
+        if (b) v = std::max(v, (*b)[g + 1] - (*b)[g]);
+        n[g] = (int)v;
+    }
+    return n;
+}
+
 bool use_rs_path(int nmax, int64_t ld_max) {
     const char* e = getenv("SD_BCSD_PATH");  // "v1" forces the generic LDS-bitonic kernels (A/B testing)
     if (e && e[0] == 'v' && e[1] == '1') return false;
@@ -745,7 +756,7 @@ int sd_bcsd_fit_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_
             p.ord_f = (const int32_t*)gt.order.p; p.off_f = (const int32_t*)gt.off.p;
             p.ys = st->ys; p.x_climo = st->x_climo; p.y_climo = st->y_climo; p.status_fit = st->status;
             p.ablate = rs_ablate();
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_FIT, p, gt.nmax));
+            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_FIT, p, gt.nmax, group_lengths(gt.host_off, nullptr, G).data()));
         } else if (lng) {
             SD_LONG_DISPATCH(long_width(gt.nmax, ctx->lds_max), launch_long_fit, ctx, kind, X_dev, y_dev, ld, gt, G, T, C, return_anoms, st);
         } else
@@ -805,11 +816,12 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
         SD_TRY(sd_workspace(ctx, rank_bytes + shift_bytes, &ws));
         p.ranks = static_cast<uint32_t*>(ws);
         p.shift = shift_bytes ? reinterpret_cast<double*>(static_cast<char*>(ws) + rank_bytes) : nullptr;
+        const std::vector<int> glen = group_lengths(st->goff, &gt.host_off, st->G);
         if (rs_one_kernel()) {
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_BOTH, p, nmax_all));
+            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_BOTH, p, nmax_all, glen.data()));
         } else {
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_RANK, p, nmax_all));
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_APPLY, p, nmax_all));
+            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_RANK, p, nmax_all, glen.data()));
+            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_APPLY, p, nmax_all, glen.data()));
         }
     } else if (lng) {
         SD_LONG_DISPATCH(long_width(gt.nmax, ctx->lds_max), launch_long_predict, ctx, st, Xp_dev, ld, gt, status_p.as<int32_t>(), out_dev, ld_out);
@@ -887,11 +899,12 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
         p.ranks = static_cast<uint32_t*>(ws);
         p.shift = shift_bytes ? reinterpret_cast<double*>(static_cast<char*>(ws) + rank_bytes) : nullptr;
         p.x_climo = reinterpret_cast<double*>(static_cast<char*>(ws) + rank_bytes + shift_bytes);
+        const std::vector<int> glen = group_lengths(gf.host_off, &gp.host_off, G);
         if (rs_one_kernel()) {
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_BOTH, p, nmax_all));
+            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_BOTH, p, nmax_all, glen.data()));
         } else {
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_RANK, p, nmax_all));
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_APPLY, p, nmax_all));
+            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_RANK, p, nmax_all, glen.data()));
+            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_APPLY, p, nmax_all, glen.data()));
         }
     }
     SD_LAUNCH(ctx, "nan_fill_kernel", nan_fill_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, out_dev, ld_out, Tp, C,

@@ -27,6 +27,10 @@ struct Params {
     int identity;  // 1: every group has equal fit / predict length (inverse CDF = identity on ranks)
     long long* trace;  // development: per-phase wall-clock stamps of sampled workgroups (SD_RS_TRACE=1)
     int ablate;  // development knob (SD_RS_ABLATE bitmask): skip phases to measure their marginal cost
+    // set by sd_bcsd_rs_launch: groups served by this launch (0 = all; bit g otherwise) and the per-segment strides of the
+    // hand-off slabs (those of the widest kernel of the call, so that launches of different widths share the slabs)
+    unsigned long long gmask;
+    int slab_nr, slab_k;
 };
 
 }  // namespace sdrs
@@ -35,4 +39,7 @@ bool sd_bcsd_rs_supported(int nmax);
 int sd_bcsd_rs_row_stride(int nmax);
 // workspace bytes of the RANK -> APPLY hand-off slabs (both multiples of 256)
 void sd_bcsd_rs_handoff_bytes(int nmax, int64_t C, int G, size_t* rank_bytes, size_t* shift_bytes);
-int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax);
+// group_len (host, [G], may be NULL): longest segment (fit or predict) of every group.  When the call needs the 21-wide
+// kernels but some groups fit 19 samples per lane (30-day months of a daily series), those groups get their own launch
+// of the narrower, ~10 % cheaper kernels.
+int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax, const int* group_len = nullptr);

@@ -459,7 +459,7 @@ __device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g
         __syncthreads();
         SD_TR(2);
         double u[K];  // u = X - (rolling mean - x_climo) (bcsd.py:247-256); PR maps raw X (bcsd.py:167)
-        double* sh = (kTas && p->shift != nullptr && cell_ok) ? p->shift + (seg * K) * kWave + lane : nullptr;
+        double* sh = (kTas && p->shift != nullptr && cell_ok) ? p->shift + (seg * p->slab_k) * kWave + lane : nullptr;
 #pragma unroll
         for (int cbeg = 0; cbeg < K; cbeg += CH) {
             double mean[CH], xv[CH];
@@ -535,7 +535,7 @@ __device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g
         SD_TR(5);
         if (MODE == MODE_RANK) {
             if (cell_ok) {
-                uint32_t* rk = p->ranks + (seg * NR) * kWave + lane;
+                uint32_t* rk = p->ranks + (seg * p->slab_nr) * kWave + lane;
 #pragma unroll
                 for (int i = 0; i < NR; ++i) rk[i * kWave] = rank2[i];
             }
@@ -554,7 +554,7 @@ __device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g
 #undef SD_DERIVE
 
     if (MODE == MODE_APPLY) {  // issued first: the loads fly while y is sorted
-        const uint32_t* rk = p->ranks + (seg * NR) * kWave + lane;
+        const uint32_t* rk = p->ranks + (seg * p->slab_nr) * kWave + lane;
 #pragma unroll
         for (int i = 0; i < NR; ++i) rank2[i] = cell_ok ? rk[i * kWave] : 0u;
     }
@@ -649,7 +649,7 @@ __device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g
     if (kTas) {
         if (SLAB) {
             if (cell_ok) {
-                const double* sh = p->shift + (seg * K) * kWave + lane;
+                const double* sh = p->shift + (seg * p->slab_k) * kWave + lane;
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
                     double res = sh[i * kWave] + q[i];   // bcsd.py:253,263
@@ -715,7 +715,13 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params) {
     const int xcd = blockIdx.x & 7;
     const int64_t jb = blockIdx.x >> 3;
     const int64_t tile_id = xcd * tx + jb % tx;
-    const int g = (int)(jb / tx);
+    int g = (int)(jb / tx);
+    if (p->gmask != 0ull) {  // this launch serves a subset of the groups: the g-th set bit
+        unsigned long long m = p->gmask;
+        for (int i = 0; i < g; ++i) m &= m - 1;
+        if (m == 0ull) return;
+        g = __builtin_ctzll(m);
+    }
     if (tile_id >= p->ntiles || g >= p->G) return;
     segment_body<K, MODE, KIND, IDENT, SLAB>(p, tile_id, g, smem_raw);
 }
@@ -727,7 +733,7 @@ int launch_koki(sd_ctx* ctx, const Params& p, const char* name) {
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_rs_kernel<K, MODE, OCC, KIND, IDENT, SLAB>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t tx = (p.ntiles + 7) / 8;
-    const int64_t nblocks = 8 * tx * p.G;
+    const int64_t nblocks = 8 * tx * (p.gmask ? __builtin_popcountll(p.gmask) : p.G);
     SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "grid too large");
     Params q = p;
     const bool tracing = getenv("SD_RS_TRACE") != nullptr;
@@ -795,6 +801,7 @@ template <int MODE>
 int launch_mode(sd_ctx* ctx, const Params& p, int nmax, const char* name) {
     if (nmax <= 64 * 5) return launch_k<5, MODE>(ctx, p, name);
     if (nmax <= 64 * 13) return launch_k<13, MODE>(ctx, p, name);
+    if (nmax <= 64 * 19) return launch_k<19, MODE>(ctx, p, name);
     if (nmax <= 64 * 21) return launch_k<21, MODE>(ctx, p, name);
     if (nmax <= 64 * 33) return launch_k<33, MODE>(ctx, p, name);
     return sd_set_error(SD_ERR_UNSUPPORTED, "segment of %d samples exceeds the register-sort path", nmax);
@@ -805,7 +812,7 @@ int launch_mode(sd_ctx* ctx, const Params& p, int nmax, const char* name) {
 // Entry points used by sd_bcsd.hip ---------------------------------------------------------------
 bool sd_bcsd_rs_supported(int nmax) { return nmax >= 1 && nmax <= 64 * 33; }
 
-static int rs_width(int nmax) { return nmax <= 64 * 5 ? 5 : nmax <= 64 * 13 ? 13 : nmax <= 64 * 21 ? 21 : 33; }  // as in launch_mode
+static int rs_width(int nmax) { return nmax <= 64 * 5 ? 5 : nmax <= 64 * 13 ? 13 : nmax <= 64 * 19 ? 19 : nmax <= 64 * 21 ? 21 : 33; }  // as in launch_mode
 
 int sd_bcsd_rs_row_stride(int nmax) {
     const int K = rs_width(nmax);
@@ -823,7 +830,7 @@ void sd_bcsd_rs_handoff_bytes(int nmax, int64_t C, int G, size_t* rank_bytes, si
     *shift_bytes = segs * K * 64 * sizeof(double);
 }
 
-int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax) {
+static int rs_launch_one(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax) {
     switch (mode) {
         case sdrs::MODE_FIT: return sdrs::launch_mode<sdrs::MODE_FIT>(ctx, p, nmax, "bcsd_rs_fit_kernel");
         case sdrs::MODE_RANK: return sdrs::launch_mode<sdrs::MODE_RANK>(ctx, p, nmax, "bcsd_rs_rank_kernel");
@@ -831,4 +838,24 @@ int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax) {
         case sdrs::MODE_BOTH: return sdrs::launch_mode<sdrs::MODE_BOTH>(ctx, p, nmax, "bcsd_rs_rank_apply_kernel");
         default: return sd_set_error(SD_ERR_INVALID, "unknown register-sort mode %d", mode);
     }
+}
+
+int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax, const int* group_len) {
+    sdrs::Params q = p;
+    const int kmax = rs_width(nmax);
+    q.gmask = 0ull;
+    q.slab_nr = (kmax + 1) / 2;
+    q.slab_k = kmax;
+    const char* e = getenv("SD_RS_SPLIT");  // "0": one launch of the widest kernels for every group (A/B testing)
+    if (kmax == 21 && group_len != nullptr && p.G <= 64 && !(e && e[0] == '0')) {
+        unsigned long long narrow = 0ull, wide = 0ull;
+        for (int g = 0; g < p.G; ++g) (group_len[g] <= 64 * 19 ? narrow : wide) |= 1ull << g;
+        if (narrow != 0ull && wide != 0ull) {
+            q.gmask = wide;
+            SD_TRY(rs_launch_one(ctx, mode, q, nmax));
+            q.gmask = narrow;
+            return rs_launch_one(ctx, mode, q, 64 * 19);
+        }
+    }
+    return rs_launch_one(ctx, mode, q, nmax);
 }

@@ -348,6 +348,37 @@ def test_pointwise_downscaler_bcsd_grid():
         PointWiseDownscaler(object())
 
 
+def test_per_group_kernel_width(ctx, monkeypatch):
+    """A 40-year daily series has 31-day months (1 240 samples: 21 per lane) and shorter ones (<= 1 216: 19 per lane):
+    the shorter months get their own launch of the narrower kernels sharing the hand-off slabs.  The result must not
+    depend on the split beyond the summation order of the monthly means (SD_RS_SPLIT=0 = one launch of the widest
+    kernels; sorted states are bit-identical), for the fused entry point, fit -> predict from a state (shifted predict
+    calendar: some months cross the width limit only there), and both kinds."""
+    rng = np.random.default_rng(5)
+    for kind, T, Tp, C in ((0, 14600, 14600, 19), (1, 14600, 14600, 9), (0, 14000, 14900, 11)):
+        index = pd.date_range("1980-01-01", periods=T, freq="D")
+        index_p = pd.date_range("1979-01-01", periods=Tp, freq="D")
+        X, y, Xp = (15 + 8 * rng.standard_normal((n, C)) for n in (T, T, Tp))
+        if kind == 1:
+            X, y, Xp = np.abs(X) * (rng.random(X.shape) > 0.3), np.abs(y) + 0.1, np.abs(Xp) * (rng.random(Xp.shape) > 0.3)
+        gid, gid_p = month_gid(index), month_gid(index_p)
+        dX, dy, dXp = ctx.to_device(X), ctx.to_device(y), ctx.to_device(Xp)
+        res = {}
+        for split in ("1", "0"):
+            monkeypatch.setenv("SD_RS_SPLIT", split)
+            a, sa = ctx.bcsd_fit_predict(kind, dX, dy, gid, 12, dXp, gid_p)
+            st = ctx.bcsd_fit(kind, dX, dy, gid, 12, True)
+            b, sb = ctx.bcsd_predict(st, dXp, gid_p)
+            res[split] = (a.to_host(), b.to_host(), st.export()["y_sorted"])
+            assert (sa == 0).all() and (sb == 0).all()
+        monkeypatch.delenv("SD_RS_SPLIT")
+        assert np.array_equal(res["1"][2], res["0"][2]), (kind, T, Tp)
+        for u, v in zip(res["1"][:2], res["0"][:2]):
+            assert_close(u, v, rtol=1e-13, what=f"width split vs single launch kind={kind}")
+        exp, _ = bo.pointwise_fit_predict(kind, X[:, :2], y[:, :2], Xp[:, :2], gid, gid_p, G=12, return_anoms=True)
+        assert_close(res["1"][0][:, :2], exp, what=f"width split kind={kind}")
+
+
 def test_full_size_grid_is_consistent(ctx):
     """BASELINE config 2 size (100 000 cells x 14 600 steps, 12 months) through a size-independent property: the grid
     is made of identical 8 192-cell blocks, so every block -- whatever tile, workgroup and XCD it lands on -- must
