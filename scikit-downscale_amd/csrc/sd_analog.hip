@@ -1011,7 +1011,7 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                                                               const double* __restrict__ yx_all, const double* __restrict__ Xc,
                                                               const double* __restrict__ yc,
                                                               const int32_t* __restrict__ fit_status, int32_t* status,
-                                                              double* scratch_d, int32_t* scratch_i, PredictArgs pa) {
+                                                              double* scratch_d, int32_t* scratch_i, PredictArgs pa, int qsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* xs = reinterpret_cast<double*>(smem_raw);  // n sorted values + one +inf sentinel
     const int nthr = blockDim.x, tid = threadIdx.x;
@@ -1023,8 +1023,23 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
     int nsteps = 0;  // window refinement: the range p - k .. p holds at most k + 1 candidates
     while ((1 << nsteps) < (k + 1 < n - k + 1 ? k + 1 : n - k + 1)) ++nsteps;
     const double kk = (double)k;
-    int64_t step, end;
-    for (int64_t c = first_cell(C, &step, &end); c < end; c += step) {
+    // qsplit workgroups of one XCD share a cell (each answers 1/qsplit of its queries), so that the XCD works on
+    // fewer cells at a time and the prefix sums of those cells (read at two random places per query) stay in its L2.
+    // Pays for the regression (three prefix arrays: pq, rx), not for the plain mean (the extra LDS fills cost more)
+    int64_t step, end, c0;
+    int part = 0;
+    if (qsplit > 1) {  // (the launcher guarantees gridDim.x % (8 * qsplit) == 0)
+        const int64_t cx = (C + 7) / 8;
+        const int x = blockIdx.x % 8, j = blockIdx.x / 8;
+        part = j % qsplit;
+        step = gridDim.x / 8 / qsplit;
+        end = (x + 1) * cx < C ? (x + 1) * cx : C;
+        c0 = x * cx + j / qsplit;
+    } else {
+        c0 = first_cell(C, &step, &end);
+    }
+    const int64_t qchunk = (Tq + qsplit - 1) / qsplit, q_beg = part * qchunk, q_end = q_beg + qchunk < Tq ? q_beg + qchunk : Tq;
+    for (int64_t c = c0; c < end; c += step) {
         const bool active = fit_status[c] == 0;
         const double* xg = xs_all + c * T;
         const double2* pq = reinterpret_cast<const double2*>(pq_all) + c * (T + 1);
@@ -1039,13 +1054,13 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
             for (int i = tid; i < n; i += nthr) xs[i] = xg[i];
         if (tid == 0) xs[n] = inf;
         __syncthreads();
-        for (int64_t tq0 = tid; tq0 < Tq; tq0 += (int64_t)nthr * kWinQ) {
+        for (int64_t tq0 = q_beg + tid; tq0 < q_end; tq0 += (int64_t)nthr * kWinQ) {
             double q[kWinQ];
             bool has[kWinQ], ok[kWinQ];
 #pragma unroll
             for (int j = 0; j < kWinQ; ++j) {
                 const int64_t tq = tq0 + (int64_t)j * nthr;
-                has[j] = tq < Tq;
+                has[j] = tq < q_end;
                 q[j] = has[j] ? Xq[c * Tq + tq] : 0.0;
                 ok[j] = active && has[j] && sd_finite(q[j]);
                 if (active && has[j] && !ok[j]) atomicOr(&status[c], SDI_NONFINITE);
@@ -1952,6 +1967,10 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
             pw.oc_Tq = Tq;
             int nbc = nb;
             if ((int64_t)nbc > ((cc + 7) / 8) * 8) nbc = (int)(((cc + 7) / 8) * 8);
+            // workgroups per cell in the single-pass kernel (see its qsplit): only when every XCD still gets whole groups
+            const char* eqs = getenv("SD_ANALOG_QSPLIT");
+            int qs = eqs ? atoi(eqs) : (mode == 1 ? 2 : 1);  // measured (ms per 16 384 cells), 1/2/4/8: regression 10.8/8.5/8.7/11.0, mean 5.5/5.7/6.4/8.3
+            if (qs < 1 || nbc % (8 * qs) != 0 || cc < (int64_t)nbc || Tq < 4096) qs = 1;
             if (mean_only) {
                 SD_LAUNCH(ctx, "analog_f1_mean_kernel", analog_f1_mean_kernel, dim3(nbc), dim3(nthr), lds_mean, mode,
                           (const double*)qc.p, Tq, T, cc, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
@@ -1959,7 +1978,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
                           (const double*)st->rx + cb * (T + 1), (const double*)st->xbar + cb, (const double*)st->yx + cb * T,
                           (const double*)st->X + cb * T,
                           (const double*)st->y + cb * T, (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb,
-                          sc_d.as<double>(), sc_i.as<int32_t>(), pw);
+                          sc_d.as<double>(), sc_i.as<int32_t>(), pw, qs);
             } else {
                 SD_LAUNCH(ctx, "analog_f1_window_kernel", analog_f1_window_kernel, dim3(nbc), dim3(nthr), lds, mode,
                           (const double*)qc.p, Tq, Tq, T, cc, npass, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,

@@ -5,7 +5,7 @@ import sys
 
 d = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    k = r["Kernel_Name"].split("(")[0][-48:]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-48:]
     d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 for k, v in d.items():
