@@ -12,8 +12,10 @@
 //         the one-feature regression, is added by analog_rx_kernel on the first AnalogRegression call.  For
 //         F > 1 a copy of the training points sorted by feature 0 (ps, indices xi).
 // predict, F == 1 (one persistent workgroup per cell, queries and outputs through cell-major staging):
-//   analog_f1_mean_kernel   mean_analogs without a threshold, a single analog, AnalogRegression: window search
-//                           over xs in LDS + prefix sums (single pass);
+//   analog_f1_mean3_kernel  mean_analogs without a threshold: window search over xs in LDS, then the two prefix-sum
+//                           components staged through the same LDS array (three generations per cell);
+//   analog_f1_mean_kernel   a single analog, AnalogRegression, weighted / thresholded kinds: window search over xs
+//                           in LDS, prefix sums or the window of yx read from memory (single pass);
 //   analog_f1_window_kernel the other PureAnalog kinds: k-NN window over xs, statistics from yx, both
 //                           LDS-resident per value range;
 //   analog_f1_predict_kernel / f1_walk_query  exact (rdist, index)-ordered two-pointer walk: 'sample_analogs',
@@ -1226,6 +1228,137 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
     }
 }
 
+// F == 1, PureAnalog 'mean_analogs' without a threshold (the BASELINE configuration), k >= 2: the same answer as
+// analog_f1_mean_kernel with the prefix sums staged through LDS as well.  The two 16-byte prefix loads of a query land
+// on random sectors, and reading them from memory made that kernel move 4x its compulsory bytes (PMC: 32.7 GB fetched
+// per 16 384 cells).  Here a thread keeps the window starts of its (up to kPhQ) queries in registers and the LDS array
+// is filled three times per cell -- sorted values (search), then the first, then the second prefix component --
+// so every byte is fetched once, coalesced.
+constexpr int kPhQ = 16;  // queries per thread and LDS generation (1024 threads: series up to 16 384 queries per pass)
+__global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __restrict__ Xq /* [C][Tq] */, int64_t Tq, int64_t T,
+                                                               int64_t C, const double* __restrict__ xs_all,
+                                                               const int32_t* __restrict__ xi_all,
+                                                               const double* __restrict__ pq_all,
+                                                               const double* __restrict__ ybar_all, const double* __restrict__ Xc,
+                                                               const double* __restrict__ yc,
+                                                               const int32_t* __restrict__ fit_status, int32_t* status,
+                                                               double* scratch_d, int32_t* scratch_i, PredictArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* buf = reinterpret_cast<double*>(smem_raw);  // n + 1 doubles
+    const int nthr = blockDim.x, tid = threadIdx.x;
+    const int n = (int)T, k = pa.k;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double* sd = scratch_d + (int64_t)blockIdx.x * k * nthr;
+    int32_t* si = scratch_i + (int64_t)blockIdx.x * k * nthr;
+    int nsteps = 0;  // window refinement: the range p - k .. p holds at most k + 1 candidates
+    while ((1 << nsteps) < (k + 1 < n - k + 1 ? k + 1 : n - k + 1)) ++nsteps;
+    const double kk = (double)k;
+    int64_t step, end;
+    for (int64_t c = first_cell(C, &step, &end); c < end; c += step) {
+        const bool active = fit_status[c] == 0;
+        const double* xg = xs_all + c * T;
+        const double2* pq = reinterpret_cast<const double2*>(pq_all) + c * (T + 1);
+        const double ybar = ybar_all[c];
+        for (int64_t q0 = 0; q0 < Tq; q0 += (int64_t)kPhQ * nthr) {
+            // ---- generation 1: sorted training values -> window start of every query
+            __syncthreads();
+            if (active)
+                for (int i = tid; i < n; i += nthr) buf[i] = xg[i];
+            if (tid == 0) buf[n] = inf;
+            __syncthreads();
+            int Lw[kPhQ];
+            unsigned okmask = 0u, nanmask = 0u, walkmask = 0u;  // bit i: prefix-sum statistics / NaN output / exact walk
+#pragma unroll
+            for (int i0 = 0; i0 < kPhQ; i0 += 2) {
+                double q[2];
+                bool has[2], ok[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int64_t tq = q0 + tid + (int64_t)(i0 + j) * nthr;
+                    has[j] = tq < Tq;
+                    q[j] = has[j] ? Xq[c * Tq + tq] : 0.0;
+                    ok[j] = active && has[j] && sd_finite(q[j]);
+                    if (active && has[j] && !ok[j]) atomicOr(&status[c], SDI_NONFINITE);
+                    if (!ok[j]) q[j] = 0.0;
+                }
+                int lo[2], hi[2], pos[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pos[j] = -1;  // index of the last value known to be < q
+#pragma unroll 1
+                for (int len = n; len > 1;) {
+                    int half = len >> 1;
+                    if ((half & 15) == 0) --half;
+                    len -= half;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) pos[j] += buf[pos[j] + half] < q[j] ? half : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int p = pos[j] + 1 + (buf[pos[j] + 1] < q[j] ? 1 : 0);
+                    lo[j] = p - k > 0 ? p - k : 0;
+                    hi[j] = p < n - k ? p : n - k;
+                }
+#pragma unroll 1
+                for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int mid = (lo[j] + hi[j]) >> 1;
+                        const bool act = lo[j] < hi[j];
+                        const bool right = sq_dist(q[j], buf[mid]) > sq_dist(q[j], buf[mid + k]);
+                        lo[j] = (act && right) ? mid + 1 : lo[j];
+                        hi[j] = (act && !right) ? mid : hi[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int i = i0 + j;
+                    Lw[i] = lo[j];
+                    if (!has[j]) continue;
+                    if (!ok[j]) {
+                        nanmask |= 1u << i;
+                        continue;
+                    }
+                    const int L = lo[j];
+                    const double dL = sq_dist(q[j], buf[L]), dR = sq_dist(q[j], buf[L + k - 1]);
+                    const double worst = dL > dR ? dL : dR;
+                    const bool sep_l = L == 0 || sq_dist(q[j], buf[L - 1]) > worst;
+                    const bool sep_r = L + k == n || sq_dist(q[j], buf[L + k]) > worst;
+                    if (sep_l && sep_r) okmask |= 1u << i;
+                    else walkmask |= 1u << i;  // a tie on the window boundary
+                }
+            }
+#pragma unroll 1
+            for (int i = 0; walkmask >> i; ++i)  // exact (rdist, index)-ordered walk; writes its own output
+                if ((walkmask >> i) & 1u) {
+                    const int64_t tq = q0 + tid + (int64_t)i * nthr;
+                    f1_walk_query(0, pa, n, T, c, tq, Xq[c * Tq + tq], xg, xi_all + c * T, Xc + c * T, yc + c * T, sd, si, nthr);
+                }
+            // ---- generation 2: first prefix component -> window means
+            __syncthreads();
+            for (int i = tid; i <= n; i += nthr) buf[i] = pq[i].x;
+            __syncthreads();
+            double m1[kPhQ];
+#pragma unroll
+            for (int i = 0; i < kPhQ; ++i) m1[i] = (okmask >> i) & 1u ? (buf[Lw[i] + k] - buf[Lw[i]]) / kk : 0.0;
+            // ---- generation 3: second prefix component -> spreads, outputs
+            __syncthreads();
+            for (int i = tid; i <= n; i += nthr) buf[i] = pq[i].y;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < kPhQ; ++i) {
+                const int64_t tq = q0 + tid + (int64_t)i * nthr;
+                if ((okmask >> i) & 1u) {
+                    const double var = (buf[Lw[i] + k] - buf[Lw[i]]) / kk - m1[i] * m1[i];
+                    put_out(pa, tq, c, ybar + m1[i], 1.0, sqrt(var > 0.0 ? var : 0.0));  // gard.py:329-333, 345-346
+                } else if ((nanmask >> i) & 1u) {
+                    put_out(pa, tq, c, nan, nan, nan);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // general F predict: brute force, training rows staged through LDS, per-thread top-k in scratch
 // ------------------------------------------------------------------------------------------------
@@ -1943,9 +2076,12 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
         const size_t lds_mean = sizeof(double) * (size_t)(T + 1);
         const bool mean_only = (mode == 1 ? k >= 3 : (kind == SD_ANALOG_MEAN || kind == SD_ANALOG_WEIGHT || k == 1)) && st->pq != nullptr &&
                                lds_mean <= ctx->lds_max && getenv("SD_ANALOG_NOPREFIX") == nullptr;
-        if (mean_only)
+        if (mean_only) {
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean));
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean));
+        }
         if (mean_only && mode == 1 && st->rx == nullptr) {
             // first regression on this state: the cross-term prefix sums (calls on a context are serialised)
             sd_analog_state* ms = const_cast<sd_analog_state*>(st);
@@ -1971,7 +2107,13 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
             const char* eqs = getenv("SD_ANALOG_QSPLIT");
             int qs = eqs ? atoi(eqs) : (mode == 1 ? 2 : 1);  // measured (ms per 16 384 cells), 1/2/4/8: regression 10.8/8.5/8.7/11.0, mean 5.5/5.7/6.4/8.3
             if (qs < 1 || nbc % (8 * qs) != 0 || cc < (int64_t)nbc || Tq < 4096) qs = 1;
-            if (mean_only) {
+            if (mean_only && mode == 0 && kind == SD_ANALOG_MEAN && !has_thresh && k >= 2 && getenv("SD_ANALOG_NOPHASES") == nullptr) {
+                SD_LAUNCH(ctx, "analog_f1_mean3_kernel", analog_f1_mean3_kernel, dim3(nbc), dim3(nthr), lds_mean, (const double*)qc.p,
+                          Tq, T, cc, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
+                          (const double*)st->pq + 2 * cb * (T + 1), (const double*)st->ybar + cb, (const double*)st->X + cb * T,
+                          (const double*)st->y + cb * T, (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb,
+                          sc_d.as<double>(), sc_i.as<int32_t>(), pw);
+            } else if (mean_only) {
                 SD_LAUNCH(ctx, "analog_f1_mean_kernel", analog_f1_mean_kernel, dim3(nbc), dim3(nthr), lds_mean, mode,
                           (const double*)qc.p, Tq, T, cc, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
                           (const double*)st->pq + 2 * cb * (T + 1), (const double*)st->ybar + cb,
