@@ -1228,7 +1228,7 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
     }
 }
 
-// F == 1, PureAnalog 'mean_analogs' without a threshold (the BASELINE configuration), k >= 2: the same answer as
+// F == 1, PureAnalog 'mean_analogs' without a threshold (the BASELINE configuration) or a single analog: the same answer as
 // analog_f1_mean_kernel with the prefix sums staged through LDS as well.  The two 16-byte prefix loads of a query land
 // on random sectors, and reading them from memory made that kernel move 4x its compulsory bytes (PMC: 32.7 GB fetched
 // per 16 384 cells).  Here a thread keeps the window starts of its (up to kPhQ) queries in registers and the LDS array
@@ -1239,7 +1239,8 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
                                                                int64_t C, const double* __restrict__ xs_all,
                                                                const int32_t* __restrict__ xi_all,
                                                                const double* __restrict__ pq_all,
-                                                               const double* __restrict__ ybar_all, const double* __restrict__ Xc,
+                                                               const double* __restrict__ ybar_all,
+                                                               const double* __restrict__ yx_all, const double* __restrict__ Xc,
                                                                const double* __restrict__ yc,
                                                                const int32_t* __restrict__ fit_status, int32_t* status,
                                                                double* scratch_d, int32_t* scratch_i, PredictArgs pa) {
@@ -1334,6 +1335,26 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
                     const int64_t tq = q0 + tid + (int64_t)i * nthr;
                     f1_walk_query(0, pa, n, T, c, tq, Xq[c * Tq + tq], xg, xi_all + c * T, Xc + c * T, yc + c * T, sd, si, nthr);
                 }
+            if (k == 1) {
+                // a single analog (best_analog, or n_analogs = 1: gard.py:291-296): generation 2 = y in sorted-x order
+                __syncthreads();
+                for (int i = tid; i < n; i += nthr) buf[i] = yx_all[c * T + i];
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < kPhQ; ++i) {
+                    const int64_t tq = q0 + tid + (int64_t)i * nthr;
+                    if ((okmask >> i) & 1u) {
+                        const double a1 = buf[Lw[i]];
+                        const bool exc = !pa.has_thresh || a1 > pa.thresh;  // gard.py:307
+                        put_out(pa, tq, c, (pa.kind == SD_ANALOG_BEST || exc) ? a1 : 0.0,  // masked mean / weight: NaN -> 0 (gard.py:341)
+                                pa.has_thresh ? (exc ? 1.0 : 0.0) : 1.0,                // gard.py:343, 346
+                                exc ? 0.0 : nan);                                        // gard.py:342, 345
+                    } else if ((nanmask >> i) & 1u) {
+                        put_out(pa, tq, c, nan, nan, nan);
+                    }
+                }
+                continue;
+            }
             // ---- generation 2: first prefix component -> window means
             __syncthreads();
             for (int i = tid; i <= n; i += nthr) buf[i] = pq[i].x;
@@ -2107,10 +2128,11 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
             const char* eqs = getenv("SD_ANALOG_QSPLIT");
             int qs = eqs ? atoi(eqs) : (mode == 1 ? 2 : 1);  // measured (ms per 16 384 cells), 1/2/4/8: regression 10.8/8.5/8.7/11.0, mean 5.5/5.7/6.4/8.3
             if (qs < 1 || nbc % (8 * qs) != 0 || cc < (int64_t)nbc || Tq < 4096) qs = 1;
-            if (mean_only && mode == 0 && kind == SD_ANALOG_MEAN && !has_thresh && k >= 2 && getenv("SD_ANALOG_NOPHASES") == nullptr) {
+            if (mean_only && mode == 0 && ((kind == SD_ANALOG_MEAN && !has_thresh) || k == 1) && getenv("SD_ANALOG_NOPHASES") == nullptr) {
                 SD_LAUNCH(ctx, "analog_f1_mean3_kernel", analog_f1_mean3_kernel, dim3(nbc), dim3(nthr), lds_mean, (const double*)qc.p,
                           Tq, T, cc, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
-                          (const double*)st->pq + 2 * cb * (T + 1), (const double*)st->ybar + cb, (const double*)st->X + cb * T,
+                          (const double*)st->pq + 2 * cb * (T + 1), (const double*)st->ybar + cb, (const double*)st->yx + cb * T,
+                          (const double*)st->X + cb * T,
                           (const double*)st->y + cb * T, (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb,
                           sc_d.as<double>(), sc_i.as<int32_t>(), pw);
             } else if (mean_only) {
