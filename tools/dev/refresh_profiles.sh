@@ -14,6 +14,7 @@ timeout 200 python tools/bench_extra.py --workload analog --cells 100000 --out $
 timeout 200 python tools/bench_extra.py --workload analogreg --cells 16384 --out $O/bench_extra.json > /dev/null 2>&1
 for f in 2 3 4; do timeout 200 python tools/bench_extra.py --workload analog --features $f --cells 2048 --out $O/bench_extra.json > /dev/null 2>&1; done
 timeout 200 python tools/bench_extra.py --workload analogreg --features 3 --cells 2048 --out $O/bench_extra.json > /dev/null 2>&1
+timeout 200 python tools/bench_extra.py --workload pure_regression --cells 100000 --out $O/bench_extra.json > /dev/null 2>&1
 for w in qmr ecm; do timeout 200 python tools/bench_extra.py --workload $w --cells 100000 --out $O/bench_extra.json > /dev/null 2>&1; done
 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_torchrun_1.json 2> $O/bench_torchrun_1.err
 rm -rf $O/prof
