@@ -6,7 +6,7 @@ Public names mirror ``skdownscale.pointwise_models`` for the hot path only
 from .bcsd import BcsdGridModel, BcsdPrecipitation, BcsdTemperature
 from .core import GridArray, GridDataset, PointWiseDownscaler
 from .gard import AnalogGridModel, AnalogRegression, PureAnalog, PureRegression, RegressionGridModel
-from .groupers import DAY_GROUPER, MONTH_GROUPER
+from .groupers import DAY_GROUPER, MONTH_GROUPER, PaddedDOYGrouper
 from .quantile import (CunnaneGridModel, CunnaneTransformer, EquidistantCdfMatcher, QmGridModel, QuantileMapper,
                        QuantileMapperGridModel, QuantileMappingReressor)
 
@@ -18,6 +18,7 @@ __all__ = [
     "PureAnalog",
     "MONTH_GROUPER",
     "DAY_GROUPER",
+    "PaddedDOYGrouper",
     "GridArray",
     "GridDataset",
     "BcsdGridModel",

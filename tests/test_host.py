@@ -127,6 +127,34 @@ def test_sharded_gather_world_size_2_gloo(tmp_path):
     assert "GATHER_OK" in res.stdout
 
 
+def test_padded_doy_grouper_matches_the_reference():
+    """groupers.py:19-89 through g12_padded_doy.npz (row positions of all 366 groups and their means, from the real
+    reference), plus the assertion of the reference's own test_paddeddoygrouper (test_pointwise_models.py:302-312)."""
+    import warnings
+
+    from _cases import load
+    from skdownscale_amd import PaddedDOYGrouper
+
+    g = load("g12_padded_doy")
+    for case in range(3):
+        index = pd.date_range(start=str(g[f"start{case}"]), end=str(g[f"end{case}"]))
+        X = pd.DataFrame({"foo": g[f"vals{case}"]}, index=index)
+        pos_of = pd.Series(np.arange(len(index)), index=index)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            grouper = PaddedDOYGrouper(X, offset=int(g[f"offset{case}"]))
+            groups = dict(list(grouper))
+            means = grouper.mean()
+        assert sorted(groups) == list(range(1, 367))
+        rows, off = g[f"rows{case}"], g[f"off{case}"]
+        for k in range(1, 367):
+            assert np.array_equal(pos_of[groups[k].index].values, rows[off[k - 1]:off[k]]), (case, k)
+        assert np.array_equal(means.values[:, 0], g[f"means{case}"]) and list(means.index) == list(range(1, 367))
+    index = pd.date_range(start="1980-01-01", end="1982-12-31")
+    groups = dict(list(PaddedDOYGrouper(pd.DataFrame({"foo": np.arange(len(index), dtype=float)}, index=index))))
+    np.testing.assert_array_equal(np.unique(groups[123].index.dayofyear), np.arange(123 - 15, 123 + 16))
+
+
 def test_pure_regression_argument_checks():
     """PureRegression behaviour that needs no GPU (gard.py:402-412): parameters, refused configurations, fit state."""
     from sklearn.base import clone
