@@ -1954,7 +1954,7 @@ int launch_slab(sd_ctx* ctx, int mode, const sd_analog_state* st, const double* 
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_slab_predict_kernel<F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t nbatch = (Tq + 63) / 64, nblocks = cc * nbatch;
-    const char* eab = getenv("SD_ANALOG_ABLATE");  // timing experiments only (results are wrong): 1 no insertions, 2 no epilogue
+    const char* eab = sd_dev_env("SD_ANALOG_ABLATE");  // timing experiments only (results are wrong): 1 no insertions, 2 no epilogue
     const int ablate = eab ? atoi(eab) : 0;
     sd_scratch dbg;  // 4: count scanned chunks and insertion rounds, printed per launch
     if (ablate & 4) {
@@ -1985,7 +1985,7 @@ int predict_slab(sd_ctx* ctx, int mode, const sd_analog_state* st, const double*
     const int64_t cc_max = C < chunk ? C : chunk;
     const int Kq = sort2_width(Tq, ctx->lds_max);
     // classes of the query order (analog_slab_s2_kernel); a short series would only get waves that straddle classes
-    const char* ecl = getenv("SD_ANALOG_SLAB_CLASSES");
+    const char* ecl = sd_dev_env("SD_ANALOG_SLAB_CLASSES");
     int nclass = ecl ? atoi(ecl) : (int)std::min<int64_t>(8, Tq / 512);
     nclass = nclass < 1 ? 1 : (nclass > 8 ? 8 : nclass);
     sd_scratch qc, qs, qi, key;
@@ -2072,7 +2072,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
     SD_HIP(sc_d.alloc(ctx, sizeof(double) * (size_t)nb * k * nthr));
     SD_HIP(sc_i.alloc(ctx, sizeof(int32_t) * (size_t)nb * k * nthr));
     const bool window = f1 && (mode == 1 || kind != SD_ANALOG_SAMPLE) && !inds && !dist && st->yx != nullptr &&
-                        getenv("SD_ANALOG_WALK") == nullptr;
+                        sd_dev_env("SD_ANALOG_WALK") == nullptr;
     if (window) {
         // fewest value ranges such that xs and yx of a range (+ k entries of margin each side) fit the LDS
         int npass = 1;
@@ -2096,7 +2096,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
         // single pass with only xs in LDS (statistics from the prefix sums, or the window of yx read from memory)
         const size_t lds_mean = sizeof(double) * (size_t)(T + 1);
         const bool mean_only = (mode == 1 ? k >= 3 : (kind == SD_ANALOG_MEAN || kind == SD_ANALOG_WEIGHT || k == 1)) && st->pq != nullptr &&
-                               lds_mean <= ctx->lds_max && getenv("SD_ANALOG_NOPREFIX") == nullptr;
+                               lds_mean <= ctx->lds_max && sd_dev_env("SD_ANALOG_NOPREFIX") == nullptr;
         if (mean_only) {
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean));
@@ -2125,10 +2125,10 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
             int nbc = nb;
             if ((int64_t)nbc > ((cc + 7) / 8) * 8) nbc = (int)(((cc + 7) / 8) * 8);
             // workgroups per cell in the single-pass kernel (see its qsplit): only when every XCD still gets whole groups
-            const char* eqs = getenv("SD_ANALOG_QSPLIT");
+            const char* eqs = sd_dev_env("SD_ANALOG_QSPLIT");
             int qs = eqs ? atoi(eqs) : (mode == 1 ? 2 : 1);  // measured (ms per 16 384 cells), 1/2/4/8: regression 10.8/8.5/8.7/11.0, mean 5.5/5.7/6.4/8.3
             if (qs < 1 || nbc % (8 * qs) != 0 || cc < (int64_t)nbc || Tq < 4096) qs = 1;
-            if (mean_only && mode == 0 && ((kind == SD_ANALOG_MEAN && !has_thresh) || k == 1) && getenv("SD_ANALOG_NOPHASES") == nullptr) {
+            if (mean_only && mode == 0 && ((kind == SD_ANALOG_MEAN && !has_thresh) || k == 1) && sd_dev_env("SD_ANALOG_NOPHASES") == nullptr) {
                 SD_LAUNCH(ctx, "analog_f1_mean3_kernel", analog_f1_mean3_kernel, dim3(nbc), dim3(nthr), lds_mean, (const double*)qc.p,
                           Tq, T, cc, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
                           (const double*)st->pq + 2 * cb * (T + 1), (const double*)st->ybar + cb, (const double*)st->yx + cb * T,
@@ -2162,9 +2162,9 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
                   T, C, (const double*)st->xs, (const int32_t*)st->xi, (const double*)st->X, (const double*)st->y,
                   (const int32_t*)st->status, status_p.as<int32_t>(), sc_d.as<double>(), sc_i.as<int32_t>(), pa);
     } else if (F > 1 && st->ps != nullptr && bf2_lds_bytes(k, F, 2) <= ctx->lds_max && sort2_width(Tq, ctx->lds_max) != 0 &&
-               getenv("SD_ANALOG_NOSLAB") == nullptr) {
+               sd_dev_env("SD_ANALOG_NOSLAB") == nullptr) {
         SD_TRY(predict_slab(ctx, mode, st, Xq, ld, Tq, status_p.as<int32_t>(), pa));
-    } else if (bf2_lds_bytes(k, F, 4) <= ctx->lds_max && getenv("SD_ANALOG_BF1") == nullptr) {
+    } else if (bf2_lds_bytes(k, F, 4) <= ctx->lds_max && sd_dev_env("SD_ANALOG_BF1") == nullptr) {
         int32_t* sp = status_p.as<int32_t>();
         switch (F) {
             case 1: SD_TRY(launch_bf2<1>(ctx, mode, st, Xq, ld, Tq, sp, pa)); break;
@@ -2288,7 +2288,7 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->ybar, sizeof(double) * C));
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            const int K2 = getenv("SD_ANALOG_SORT1") ? 0 : sort2_width(T, ctx->lds_max);
+            const int K2 = sd_dev_env("SD_ANALOG_SORT1") ? 0 : sort2_width(T, ctx->lds_max);
             if (K2 != 0) {
                 const Sort2Args a{st->X, T, 0, st->y, T, C, st->xs, st->xi, st->yx, st->pq, st->ybar};
                 SD_TRY(launch_sort2_width(ctx, K2, a));
@@ -2302,7 +2302,7 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
             }
             SD_HIP(hipStreamSynchronize(ctx->stream));
         }
-        const int Ks = F > 1 && getenv("SD_ANALOG_NOSLAB") == nullptr ? sort2_width(T, ctx->lds_max) : 0;
+        const int Ks = F > 1 && sd_dev_env("SD_ANALOG_NOSLAB") == nullptr ? sort2_width(T, ctx->lds_max) : 0;
         if (Ks != 0) {
             // F > 1: training points in feature-0 order for the slab search (analog_slab_predict_kernel)
             sd_scratch keys;

@@ -352,25 +352,62 @@ int upload_group_table(sd_ctx* ctx, const int32_t* gid, int64_t T, int G, DevGro
 }
 
 
-int rs_ablate() {
-    const char* e = getenv("SD_RS_ABLATE");
-    return e ? atoi(e) : 0;
+// BcsdTemperature takes the fused kernel of sd_bcsd_fz.hip (x side, y side, inverse CDF and shift of a segment in
+// one workgroup pass); the segments it hands back (work list: near-equal shifted samples) and BcsdPrecipitation take
+// RANK + APPLY.  The fused kernel can park the shift in a workspace slab between its x side and its map step
+// (8 more bytes per sample written and read, no second read of the x_fut tile / second rolling mean).
+bool fz_shift_slab() {
+    const char* e = sd_dev_env("SD_FZ_SLAB");
+    return e ? e[0] == '1' : false;
+}
+bool use_fz_path(int kind, int nmax) {
+    const char* e = sd_dev_env("SD_BCSD_FUSED");  // "0": RANK + APPLY for every segment (A/B measurements)
+    if (e && e[0] == '0') return false;
+    return kind == SD_BCSD_TAS && sd_bcsd_fz_supported(nmax);
 }
 
-// Optional RANK -> APPLY shift slab (SD_RS_SHIFT=1): APPLY then skips the second read of the x_fut tile and the
-// rolling mean, at the price of 8.7 more bytes/sample through HBM each way and C*T*8.7 bytes of workspace.
-// Measured on MI355X (100k cells x 14600): 20.7 ms with the slab vs 21.1 ms without -- off by default.
-bool rs_shift_slab() {
-    const char* e = getenv("SD_RS_SHIFT");
-    return e && e[0] == '1';
+// Hand-off / work-list workspace of one predict call, carved from the context workspace.
+struct RsWorkspace {
+    uint32_t* ranks = nullptr;
+    double* shift = nullptr;
+    double* x_climo = nullptr;  // [C][G], only for calls without a state
+    int64_t* worklist = nullptr;
+    int* work_count = nullptr;
+    int work_cap = 0;
+};
+int carve_workspace(sd_ctx* ctx, int nmax, int64_t C, int G, bool fused, bool want_shift, bool want_x_climo, RsWorkspace* w) {
+    size_t rank_bytes = 0, shift_bytes = 0;
+    sd_bcsd_rs_handoff_bytes(nmax, C, G, &rank_bytes, &shift_bytes);
+    if (!want_shift) shift_bytes = 0;
+    const size_t xc_bytes = want_x_climo ? ((sizeof(double) * (size_t)G * (size_t)C + 255) / 256) * 256 : 0;
+    const int64_t items = ((C + 7) / 8) * (int64_t)G;
+    SD_CHECK_ARG(items < ((int64_t)1 << 31), "too many (tile, group) items");
+    const size_t list_bytes = fused ? ((sizeof(int64_t) * (size_t)items + 255) / 256) * 256 : 0;
+    void* ws = nullptr;
+    SD_TRY(sd_workspace(ctx, rank_bytes + shift_bytes + xc_bytes + list_bytes + 256, &ws));
+    char* base = static_cast<char*>(ws);
+    w->ranks = reinterpret_cast<uint32_t*>(base);
+    w->shift = shift_bytes ? reinterpret_cast<double*>(base + rank_bytes) : nullptr;
+    w->x_climo = xc_bytes ? reinterpret_cast<double*>(base + rank_bytes + shift_bytes) : nullptr;
+    if (fused) {
+        w->worklist = reinterpret_cast<int64_t*>(base + rank_bytes + shift_bytes + xc_bytes);
+        w->work_count = reinterpret_cast<int*>(base + rank_bytes + shift_bytes + xc_bytes + list_bytes);
+        w->work_cap = (int)items;
+        SD_HIP(hipMemsetAsync(w->work_count, 0, sizeof(int), ctx->stream));
+    }
+    return SD_OK;
 }
 
-// SD_RS_ONE_KERNEL=1: RANK and APPLY of a segment back to back in one workgroup (ranks stay in registers, the second
-// x_fut read comes from cache, no rank slab).  Spill-free, bit-identical, 32 B/sample of HBM traffic -- and 9 % slower
-// than the two kernels on MI355X (23.1 vs 21.1 ms, 100k cells x 14600), so it is off by default.
-bool rs_one_kernel() {
-    const char* e = getenv("SD_RS_ONE_KERNEL");
-    return e && e[0] == '1';
+// the kernels of one predict call: fused kernel + RANK / APPLY over its work list, or RANK + APPLY over everything
+int run_predict_kernels(sd_ctx* ctx, sdrs::Params& p, bool fused, int nmax_all, const std::vector<int>& glen) {
+    if (fused) {
+        SD_TRY(sd_bcsd_fz_launch(ctx, p, nmax_all, glen.data()));
+        p.use_worklist = 1;
+        p.shift = nullptr;
+    }
+    SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_RANK, p, nmax_all, glen.data()));
+    SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_APPLY, p, nmax_all, glen.data()));
+    return SD_OK;
 }
 
 // longest segment of every group over one or two group tables (host offsets [G+1])
@@ -385,7 +422,7 @@ std::vector<int> group_lengths(const std::vector<int64_t>& a, const std::vector<
 }
 
 bool use_rs_path(int nmax, int64_t ld_max) {
-    const char* e = getenv("SD_BCSD_PATH");  // "v1" forces the generic LDS-bitonic kernels (A/B testing)
+    const char* e = sd_dev_env("SD_BCSD_PATH");  // "v1" forces the generic LDS-bitonic kernels (A/B testing)
     if (e && e[0] == 'v' && e[1] == '1') return false;
     if (ld_max >= ((int64_t)1 << 29)) return false;  // the fast kernels address rows with a 32-bit byte pitch
     return sd_bcsd_rs_supported(nmax);
@@ -677,7 +714,7 @@ int launch_long_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, 
     }
 
 bool use_long_path(int nmax, size_t lds_max) {
-    const char* e = getenv("SD_BCSD_PATH");  // "v1" keeps the generic LDS-bitonic kernels
+    const char* e = sd_dev_env("SD_BCSD_PATH");  // "v1" keeps the generic LDS-bitonic kernels
     if (e && e[0] == 'v' && e[1] == '1') return false;
     return nmax > 64 * 33 && long_width(nmax, lds_max) != 0;
 }
@@ -755,7 +792,6 @@ int sd_bcsd_fit_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_
             p.X = X_dev; p.y = y_dev; p.ld = ld;
             p.ord_f = (const int32_t*)gt.order.p; p.off_f = (const int32_t*)gt.off.p;
             p.ys = st->ys; p.x_climo = st->x_climo; p.y_climo = st->y_climo; p.status_fit = st->status;
-            p.ablate = rs_ablate();
             SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_FIT, p, gt.nmax, group_lengths(gt.host_off, nullptr, G).data()));
         } else if (lng) {
             SD_LONG_DISPATCH(long_width(gt.nmax, ctx->lds_max), launch_long_fit, ctx, kind, X_dev, y_dev, ld, gt, G, T, C, return_anoms, st);
@@ -807,22 +843,14 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
         p.ys = st->ys; p.x_climo = st->x_climo; p.y_climo = st->y_climo;
         p.status_fit = st->status; p.status_p = status_p.as<int32_t>();
         p.identity = (st->goff == gt.host_off) ? 1 : 0;
-        p.ablate = rs_ablate();
         p.from_state = 1;
-        size_t rank_bytes = 0, shift_bytes = 0;
-        sd_bcsd_rs_handoff_bytes(nmax_all, C, st->G, &rank_bytes, &shift_bytes);
-        if (st->kind != SD_BCSD_TAS || !rs_shift_slab()) shift_bytes = 0;
-        void* ws = nullptr;
-        SD_TRY(sd_workspace(ctx, rank_bytes + shift_bytes, &ws));
-        p.ranks = static_cast<uint32_t*>(ws);
-        p.shift = shift_bytes ? reinterpret_cast<double*>(static_cast<char*>(ws) + rank_bytes) : nullptr;
+        const bool fused = use_fz_path(st->kind, nmax_all);
+        RsWorkspace w;
+        SD_TRY(carve_workspace(ctx, nmax_all, C, st->G, fused, fused && fz_shift_slab(), false, &w));
+        p.ranks = w.ranks; p.shift = w.shift;
+        p.worklist = w.worklist; p.work_count = w.work_count; p.work_cap = w.work_cap;
         const std::vector<int> glen = group_lengths(st->goff, &gt.host_off, st->G);
-        if (rs_one_kernel()) {
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_BOTH, p, nmax_all, glen.data()));
-        } else {
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_RANK, p, nmax_all, glen.data()));
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_APPLY, p, nmax_all, glen.data()));
-        }
+        SD_TRY(run_predict_kernels(ctx, p, fused, nmax_all, glen));
     } else if (lng) {
         SD_LONG_DISPATCH(long_width(gt.nmax, ctx->lds_max), launch_long_predict, ctx, st, Xp_dev, ld, gt, status_p.as<int32_t>(), out_dev, ld_out);
     } else
@@ -886,26 +914,17 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
     p.qidx = qt.idx.as<int32_t>(); p.qval = qt.val.as<double>();
     p.status_fit = status_f.as<int32_t>(); p.status_p = status_p.as<int32_t>();
     p.identity = (gf.host_off == gp.host_off) ? 1 : 0;
-    p.ablate = rs_ablate();
     {
-        // Two kernels, no persisted sorted state: RANK writes 2 bytes/sample (rank of every x_fut sample in its
-        // shifted segment) + x_climo; APPLY sorts y_obs on chip, maps the ranks and restores the shift.  (One
-        // monolithic kernel needs > 128 VGPRs; its spills tripled the HBM traffic -- profiles/r01/pmc_*.csv.)
-        size_t rank_bytes = 0, shift_bytes = 0;
-        sd_bcsd_rs_handoff_bytes(nmax_all, C, G, &rank_bytes, &shift_bytes);
-        if (kind != SD_BCSD_TAS || !rs_shift_slab()) shift_bytes = 0;
-        void* ws = nullptr;
-        SD_TRY(sd_workspace(ctx, rank_bytes + shift_bytes + sizeof(double) * (size_t)G * C, &ws));
-        p.ranks = static_cast<uint32_t*>(ws);
-        p.shift = shift_bytes ? reinterpret_cast<double*>(static_cast<char*>(ws) + rank_bytes) : nullptr;
-        p.x_climo = reinterpret_cast<double*>(static_cast<char*>(ws) + rank_bytes + shift_bytes);
+        // No persisted sorted state.  BcsdTemperature: one fused kernel per segment (no hand-off at all); the segments
+        // it hands back, and BcsdPrecipitation: RANK writes 2 bytes/sample (rank of every x_fut sample in its shifted
+        // segment) + x_climo, APPLY sorts y_obs on chip, maps the ranks and restores the shift.
+        const bool fused = use_fz_path(kind, nmax_all);
+        RsWorkspace w;
+        SD_TRY(carve_workspace(ctx, nmax_all, C, G, fused, fused && fz_shift_slab(), true, &w));
+        p.ranks = w.ranks; p.shift = w.shift; p.x_climo = w.x_climo;
+        p.worklist = w.worklist; p.work_count = w.work_count; p.work_cap = w.work_cap;
         const std::vector<int> glen = group_lengths(gf.host_off, &gp.host_off, G);
-        if (rs_one_kernel()) {
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_BOTH, p, nmax_all, glen.data()));
-        } else {
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_RANK, p, nmax_all, glen.data()));
-            SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_APPLY, p, nmax_all, glen.data()));
-        }
+        SD_TRY(run_predict_kernels(ctx, p, fused, nmax_all, glen));
     }
     SD_LAUNCH(ctx, "nan_fill_kernel", nan_fill_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, out_dev, ld_out, Tp, C,
               (const int32_t*)status_f.p, (const int32_t*)status_p.p);

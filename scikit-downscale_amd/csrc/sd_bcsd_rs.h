@@ -1,14 +1,15 @@
-// Register/LDS merge-sort BCSD path (sd_bcsd_rs.hip): parameters and launcher.
+// Register/LDS merge-sort BCSD paths (sd_bcsd_fz.hip: one fused kernel per segment; sd_bcsd_rs.hip: the
+// RANK / APPLY / FIT kernels): parameters and launchers.
 #pragma once
 #include "sd_internal.h"
 
 namespace sdrs {
 
 // MODE_RANK + MODE_APPLY = fit+predict (or predict from a state) as two kernels: RANK ranks every x_fut sample
-// within its shifted segment, APPLY sorts y_obs (or reads the fitted state), maps the ranks and restores the shift.
-// MODE_BOTH = RANK then APPLY of the same segment inside one workgroup: the ranks stay in registers and the second
-// read of the x_fut tile comes from L2 / Infinity Cache (the workgroup fetched it microseconds earlier).
-enum { MODE_FIT = 0, MODE_BOTH = 2, MODE_RANK = 3, MODE_APPLY = 4 };
+// within its shifted segment by an explicit search, APPLY sorts y_obs (or reads the fitted state), maps the ranks and
+// restores the shift.  They serve BcsdPrecipitation, and every BcsdTemperature segment the fused kernel hands back
+// (work list).  MODE_FIT = the y side alone, writing the fitted state.
+enum { MODE_FIT = 0, MODE_RANK = 3, MODE_APPLY = 4 };
 
 struct Params {
     int kind, G, return_anoms, RS;
@@ -22,20 +23,28 @@ struct Params {
     double* ys; double* x_climo; double* y_climo;      // state: [C][Tf], [C][G], [C][G]
     int32_t* status_fit; int32_t* status_p;
     uint32_t* ranks;                                   // RANK -> APPLY: [C*G][(K+1)/2][64] packed 16-bit ranks
-    double* shift;                                     // RANK -> APPLY (TAS, optional): [C*G][K][64] rolling mean - x_climo
-    int from_state;  // RANK/APPLY: 1 = predict from a fitted state (x_climo, y_climo, ys given), 0 = fit on the fly from X, y
-    int identity;  // 1: every group has equal fit / predict length (inverse CDF = identity on ranks)
-    long long* trace;  // development: per-phase wall-clock stamps of sampled workgroups (SD_RS_TRACE=1)
-    int ablate;  // development knob (SD_RS_ABLATE bitmask): skip phases to measure their marginal cost
-    // set by sd_bcsd_rs_launch: groups served by this launch (0 = all; bit g otherwise) and the per-segment strides of the
+    double* shift;                                     // [C*G][K][64] rolling mean - x_climo of every sample (lane layout)
+    int from_state;  // 1 = predict from a fitted state (x_climo, y_climo, ys given), 0 = fit on the fly from X, y
+    int identity;    // 1: every group has equal fit / predict length (inverse CDF = identity on ranks)
+    long long* trace;  // SD_RS_TRACING builds: per-phase wall-clock stamps of sampled workgroups
+    // set by the launchers: groups served by this launch (0 = all; bit g otherwise) and the per-segment strides of the
     // hand-off slabs (those of the widest kernel of the call, so that launches of different widths share the slabs)
     unsigned long long gmask;
     int slab_nr, slab_k;
+    // Work list of (tile, group) items = tile * G + group.  The fused kernel appends the items it cannot serve
+    // (near-equal shifted samples, see sd_bcsd_fz.hip); RANK / APPLY launched with use_worklist walk the list with a
+    // fixed grid instead of covering every (tile, group).
+    int64_t* worklist;
+    int* work_count;  // device counter (items appended, may exceed work_cap: the excess is lost and reported)
+    int work_cap;
+    int use_worklist;
 };
 
 }  // namespace sdrs
 
 bool sd_bcsd_rs_supported(int nmax);
+bool sd_bcsd_fz_supported(int nmax);
+int sd_bcsd_rs_width(int nmax);  // samples per lane (K) of the kernels serving segments of up to nmax samples
 int sd_bcsd_rs_row_stride(int nmax);
 // workspace bytes of the RANK -> APPLY hand-off slabs (both multiples of 256)
 void sd_bcsd_rs_handoff_bytes(int nmax, int64_t C, int G, size_t* rank_bytes, size_t* shift_bytes);
@@ -43,3 +52,6 @@ void sd_bcsd_rs_handoff_bytes(int nmax, int64_t C, int G, size_t* rank_bytes, si
 // kernels but some groups fit 19 samples per lane (30-day months of a daily series), those groups get their own launch
 // of the narrower, ~10 % cheaper kernels.
 int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax, const int* group_len = nullptr);
+// BcsdTemperature fused kernel (sd_bcsd_fz.hip): x side, y side, inverse CDF and shift of a segment in one workgroup
+// pass; segments it cannot serve are appended to p.worklist (the caller then runs RANK + APPLY with use_worklist).
+int sd_bcsd_fz_launch(sd_ctx* ctx, const sdrs::Params& p, int nmax, const int* group_len = nullptr);

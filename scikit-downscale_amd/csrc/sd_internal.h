@@ -15,6 +15,15 @@
 
 // Internal per-cell status is a bitmask (atomicOr from many workgroups, order independent); it is
 // folded into the public SD_CELL_* code with the reference's precedence on the way out.
+// Environment variables that select alternative code paths (A/B measurements) exist only in development builds
+// (-DSD_DEV: `make dev` -> lib/libsd_downscale_dev.so).  The production library never reads the environment.
+#ifdef SD_DEV
+#include <cstdlib>
+static inline const char* sd_dev_env(const char* name) { return getenv(name); }
+#else
+static inline const char* sd_dev_env(const char*) { return nullptr; }
+#endif
+
 #define SDI_MASKED 1
 #define SDI_NONFINITE 2
 #define SDI_BAD_CLIMO 4

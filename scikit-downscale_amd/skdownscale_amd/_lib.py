@@ -86,30 +86,33 @@ SIGNATURES = {
     "sd_qm_state_destroy": [_p],
 }
 
-_lib = None
+_libs = {}
 
 
 class EngineError(RuntimeError):
     """A call into the HIP engine failed (carries sd_last_error())."""
 
 
-def load():
-    """Load (once) and return the ctypes library; raises if it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+DEV_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsd_downscale_dev.so")  # `make dev`: A/B switches (tests, tools)
+
+
+def load(path=None):
+    """Load (once per path) and return the ctypes library; raises if it has not been built."""
+    path = LIB_PATH if path is None else path
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise EngineError(
-            f"HIP engine library not found at {LIB_PATH}: build it with `python __graft_entry__.py` "
+            f"HIP engine library not found at {path}: build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _int
     lib.sd_last_error.argtypes = []
     lib.sd_last_error.restype = C.c_char_p
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 

@@ -155,8 +155,8 @@ class QmState(_State):
 class Context:
     """One GPU + one HIP stream.  Calls on a context are serialised."""
 
-    def __init__(self, device=0):
-        self.lib = _lib.load()
+    def __init__(self, device=0, lib_path=None):
+        self.lib = _lib.load(lib_path)  # lib_path: development library with A/B switches (tests / tools only)
         h = C.c_void_p()
         check(self.lib.sd_ctx_create(int(device), C.byref(h)))
         self.handle = h

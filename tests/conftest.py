@@ -24,3 +24,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def dev_ctx():
+    """Context on the development build of the engine (`make dev`: the SD_* environment switches that select alternative
+    code paths exist only there; the production library never reads the environment)."""
+    from skdownscale_amd import _lib
+    from skdownscale_amd.engine import Context
+
+    if not os.path.exists(_lib.DEV_LIB_PATH):
+        pytest.skip("development library not built (make -C scikit-downscale_amd dev)")
+    return Context(0, lib_path=_lib.DEV_LIB_PATH)

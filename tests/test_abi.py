@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
 def test_missing_library_fails_loudly(monkeypatch):
     from skdownscale_amd import _lib
 
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsd_downscale.so")
     with pytest.raises(_lib.EngineError, match="no CPU fallback"):
         _lib.load()

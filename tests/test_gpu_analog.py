@@ -138,7 +138,7 @@ def test_regression_prefix_path_edges(ctx, case):
     (2, 64, 64, 2, 5, "normal"),         # one chunk
     (3, 200, 100, 4500, 4, "normal"),    # more cells than one staging chunk
 ])
-def test_slab_search_matches_full_scan(ctx, monkeypatch, F, T, Tq, C, k, data):
+def test_slab_search_matches_full_scan(ctx, dev_ctx, monkeypatch, F, T, Tq, C, k, data):
     """F > 1: the feature-0 slab search (training points and queries sorted by feature 0, scan ends when the axis
     distance alone exceeds every k-th distance) selects bit-identical (rdist, index) lists to the full scan and
     to the oracle's brute force."""
@@ -152,14 +152,16 @@ def test_slab_search_matches_full_scan(ctx, monkeypatch, F, T, Tq, C, k, data):
     st = ctx.analog_fit(X, y)
     out, status, inds, dist = ctx.analog_predict(st, Xq, k, 3, want_neighbors=True)
     # the query order (classes by the other features, then feature 0) only groups the work: any class count agrees
+    # (switches of the development library)
     monkeypatch.setenv("SD_ANALOG_SLAB_CLASSES", "8" if Tq < 4096 else "1")
-    out8, _, inds8, dist8 = ctx.analog_predict(st, Xq, k, 3, want_neighbors=True)
+    std = dev_ctx.analog_fit(X, y)
+    out8, _, inds8, dist8 = dev_ctx.analog_predict(std, Xq, k, 3, want_neighbors=True)
     monkeypatch.delenv("SD_ANALOG_SLAB_CLASSES")
     ok8 = np.arange(Tq) != 3
     assert np.array_equal(inds8[ok8], inds[ok8]) and np.array_equal(dist8[ok8], dist[ok8]) and np.array_equal(out8[ok8], out[ok8])
     monkeypatch.setenv("SD_ANALOG_NOSLAB", "1")
-    st0 = ctx.analog_fit(X, y)
-    out0, status0, inds0, dist0 = ctx.analog_predict(st0, Xq, k, 3, want_neighbors=True)
+    st0 = dev_ctx.analog_fit(X, y)
+    out0, status0, inds0, dist0 = dev_ctx.analog_predict(st0, Xq, k, 3, want_neighbors=True)
     monkeypatch.delenv("SD_ANALOG_NOSLAB")
     ok = np.ones(Tq, bool)
     ok[3] = False

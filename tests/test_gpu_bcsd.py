@@ -131,35 +131,60 @@ def test_every_register_sort_width_split_and_fused(ctx, kind, T, Tp, C):
     assert_close(fused.to_host(), exp, what=f"fused {kind} {T}->{Tp}")
 
 
-def test_shift_slab_handoff_is_bit_identical(ctx, monkeypatch):
-    """SD_RS_SHIFT=1: RANK hands the rolling-mean shift to APPLY through the workspace instead of APPLY
-    recomputing it from a second read of x_fut -- same arithmetic, so the two must agree bit for bit,
-    in the fused entry point and in predict-from-state, equal and unequal segment lengths."""
+def test_fused_kernel_variants_agree_bit_for_bit(dev_ctx, monkeypatch):
+    """BcsdTemperature takes the fused kernel (ranks read off position tags carried through the sort).  The
+    development library can switch it off (SD_BCSD_FUSED=0: RANK + APPLY with the explicit rank search for every
+    segment) or let it park the shift in a workspace slab (SD_FZ_SLAB=1) instead of re-reading x_fut: same
+    arithmetic, so all three must agree bit for bit -- fused entry point and predict from a state, equal and unequal
+    segment lengths (identity / table + tail paths), every kernel width."""
+    ctx = dev_ctx
     rng = np.random.default_rng(11)
-    for T, Tp, C in ((3650, 3650, 9), (14600, 14600, 8), (14600, 20000, 5), (14600, 3000, 3)):
+    for T, Tp, C in ((365, 365, 6), (3650, 3650, 9), (14600, 14600, 8), (14600, 20000, 5), (14600, 3000, 3), (9000, 8000, 11)):
         index = pd.date_range("1980-01-01", periods=T, freq="D")
         index_p = pd.date_range("1980-01-01", periods=Tp, freq="D")
         X, y, Xp = (15 + 8 * rng.standard_normal((n, C)) for n in (T, T, Tp))
         gid, gid_p = month_gid(index), month_gid(index_p)
         dX, dy, dXp = ctx.to_device(X), ctx.to_device(y), ctx.to_device(Xp)
-        monkeypatch.delenv("SD_RS_SHIFT", raising=False)
-        a, _ = ctx.bcsd_fit_predict(0, dX, dy, gid, 12, dXp, gid_p)
-        st = ctx.bcsd_fit(0, dX, dy, gid, 12, True)
-        b, _ = ctx.bcsd_predict(st, dXp, gid_p)
-        monkeypatch.setenv("SD_RS_SHIFT", "1")
-        a1, _ = ctx.bcsd_fit_predict(0, dX, dy, gid, 12, dXp, gid_p)
-        b1, _ = ctx.bcsd_predict(st, dXp, gid_p)
-        assert np.array_equal(a.to_host(), a1.to_host()), (T, Tp)
-        assert np.array_equal(b.to_host(), b1.to_host()), (T, Tp)
-        monkeypatch.delenv("SD_RS_SHIFT", raising=False)
-        # SD_RS_ONE_KERNEL=1: RANK and APPLY of a segment in one workgroup, ranks in registers
-        monkeypatch.setenv("SD_RS_ONE_KERNEL", "1")
-        a2, _ = ctx.bcsd_fit_predict(0, dX, dy, gid, 12, dXp, gid_p)
-        b2, _ = ctx.bcsd_predict(st, dXp, gid_p)
-        assert np.array_equal(a.to_host(), a2.to_host()), (T, Tp)
-        assert np.array_equal(b.to_host(), b2.to_host()), (T, Tp)
-        monkeypatch.delenv("SD_RS_ONE_KERNEL", raising=False)
-    monkeypatch.delenv("SD_RS_SHIFT", raising=False)
+        res = {}
+        for name, env in (("fused", {}), ("slab", {"SD_FZ_SLAB": "1"}), ("search", {"SD_BCSD_FUSED": "0"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            a, sa = ctx.bcsd_fit_predict(0, dX, dy, gid, 12, dXp, gid_p)
+            st = ctx.bcsd_fit(0, dX, dy, gid, 12, True)
+            b, sb = ctx.bcsd_predict(st, dXp, gid_p)
+            res[name] = (a.to_host(), b.to_host())
+            assert (sa == 0).all() and (sb == 0).all()
+            for k in env:
+                monkeypatch.delenv(k)
+        for name in ("slab", "search"):
+            assert np.array_equal(res["fused"][0], res[name][0]), (name, T, Tp)
+            assert np.array_equal(res["fused"][1], res[name][1]), (name, T, Tp)
+        exp, _ = bo.pointwise_fit_predict(0, X[:, :2], y[:, :2], Xp[:, :2], gid, gid_p)
+        assert_close(res["fused"][0][:, :2], exp, what=f"fused {T}->{Tp}")
+
+
+def test_fused_kernel_hands_tied_segments_back(ctx):
+    """Exactly tied shifted samples (a constant stretch of x_fut: rolling mean == x, so u == x_climo for every
+    sample of the stretch) cannot be ranked by the position tags: the workgroup appends its (tile, month) to the
+    work list and RANK / APPLY (explicit search, max rank among ties: quantile.py:488) redo it.  Tied and clean cells,
+    tied and clean months are mixed so that both paths write parts of the same output; plus -0.0 / +0.0."""
+    rng = np.random.default_rng(23)
+    T, C = 14600, 43
+    index = pd.date_range("1980-01-01", periods=T, freq="D")
+    gid = month_gid(index)
+    X, y, Xp = (15 + 8 * rng.standard_normal((T, C)) for _ in range(3))
+    for c in (0, 5, 6, 17, 40, 42):  # constant stretches inside one month / across a month boundary
+        t0 = int(rng.integers(100, T - 200))
+        Xp[t0:t0 + 24, c] = Xp[t0, c]
+    Xp[3000:3040, 9] = np.round(Xp[3000:3040, 9])  # a few coarse values: some exact ties after the shift or none
+    Xp[500, 11], Xp[501, 11] = 0.0, -0.0
+    exp, est = bo.pointwise_fit_predict(0, X, y, Xp, gid, gid)
+    out, st = ctx.bcsd_fit_predict(0, ctx.to_device(X), ctx.to_device(y), gid, 12, ctx.to_device(Xp), gid)
+    assert np.array_equal(st, est)
+    assert_close(out.to_host(), exp, what="mixed tied / clean segments")
+    state = ctx.bcsd_fit(0, X, y, gid, 12, True)
+    out2, _ = ctx.bcsd_predict(state, Xp, gid)
+    assert_close(out2, exp, what="mixed tied / clean segments, from a state")
 
 
 @pytest.mark.parametrize("Ct,c0", [(37, 3), (40, 4), (40, 7)])
@@ -194,8 +219,9 @@ def test_cell_shard_views_of_a_resident_grid(ctx, Ct, c0):
         assert_close(got[:, sl], exp, what=f"view fused {kind}")
 
 
-def test_generic_lds_kernels_still_agree(ctx, monkeypatch):
-    """SD_BCSD_PATH=v1 forces the generic LDS-bitonic kernels (fallback for segments > 2 112 samples)."""
+def test_generic_lds_kernels_still_agree(dev_ctx, monkeypatch):
+    """SD_BCSD_PATH=v1 (development library) forces the generic LDS-bitonic kernels (fallback for segments > 2 112 samples)."""
+    ctx = dev_ctx
     monkeypatch.setenv("SD_BCSD_PATH", "v1")
     g = load("g1_tas_small")
     index, index_p, X, y, Xp = tas_inputs(g)
@@ -348,12 +374,13 @@ def test_pointwise_downscaler_bcsd_grid():
         PointWiseDownscaler(object())
 
 
-def test_per_group_kernel_width(ctx, monkeypatch):
+def test_per_group_kernel_width(dev_ctx, monkeypatch):
     """A 40-year daily series has 31-day months (1 240 samples: 21 per lane) and shorter ones (<= 1 216: 19 per lane):
     the shorter months get their own launch of the narrower kernels sharing the hand-off slabs.  The result must not
     depend on the split beyond the summation order of the monthly means (SD_RS_SPLIT=0 = one launch of the widest
     kernels; sorted states are bit-identical), for the fused entry point, fit -> predict from a state (shifted predict
-    calendar: some months cross the width limit only there), and both kinds."""
+    calendar: some months cross the width limit only there), and both kinds.  (The switch exists in the development library.)"""
+    ctx = dev_ctx
     rng = np.random.default_rng(5)
     for kind, T, Tp, C in ((0, 14600, 14600, 19), (1, 14600, 14600, 9), (0, 14000, 14900, 11)):
         index = pd.date_range("1980-01-01", periods=T, freq="D")
