@@ -401,6 +401,7 @@ int carve_workspace(sd_ctx* ctx, int nmax, int64_t C, int G, bool fused, bool wa
 // the kernels of one predict call: fused kernel + RANK / APPLY over its work list, or RANK + APPLY over everything
 int run_predict_kernels(sd_ctx* ctx, sdrs::Params& p, bool fused, int nmax_all, const std::vector<int>& glen) {
     if (fused) {
+        if (const char* e = sd_dev_env("SD_FZ_ABLATE")) p.dev_flags = atoi(e);
         SD_TRY(sd_bcsd_fz_launch(ctx, p, nmax_all, glen.data()));
         p.use_worklist = 1;
         p.shift = nullptr;

@@ -51,14 +51,29 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
     ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();  // Params is the only kernel argument
     constexpr int CH = Chunk<K>::CH;
     constexpr int NR = (K + 1) / 2;
-    double* const tile = reinterpret_cast<double*>(smem_raw);
+#ifdef SD_DEV
+    const int abl = p->dev_flags;  // SD_FZ_ABLATE (low byte): 1 no u merge rounds, 2 no y merge rounds, 4 no x_hist, 8 no shift restore,
+                                   // 16 no store, 32 no y load, 64 no x_fut load (timing only: results are wrong)
+#else
+    constexpr int abl = 0;
+#endif
+    double* const scratch = reinterpret_cast<double*>(smem_raw);  // 64 doubles (column-sum exchange)
+    double* const rcp = scratch + 64;                             // 16 doubles: correctly rounded 1/c, c = 1..9
+    int* const bad_cell = reinterpret_cast<int*>(rcp + 16);       // 8 ints: cell of the tile saw a non-finite sample
+    double* const tile = scratch + kHeadDoubles;
     const int RS = p->RS;
-    double* const scratch = tile + kW * RS;                      // 64 doubles (column-sum exchange)
-    double* const rcp = scratch + 64;                            // 16 doubles: correctly rounded 1/c, c = 1..9
-    int* const bad_cell = reinterpret_cast<int*>(rcp + 16);      // 8 ints: cell of the tile saw a non-finite sample
     fill_rcp_table(rcp);
     if (threadIdx.x >= 32 && threadIdx.x < 32 + kW) bad_cell[threadIdx.x - 32] = 0;
 
+#ifdef SD_DEV
+    if ((abl >> 8) != 0 && blockIdx.x < 512u) {
+        // SD_FZ_ABLATE bits 8.. = T: the first generation of workgroups starts spread over ~T microseconds (hash of the
+        // workgroup id) instead of in lockstep; later generations inherit the offsets
+        const unsigned h = (blockIdx.x * 2654435761u) >> 20;  // 12 bits
+        const unsigned n = (h * (unsigned)(abl >> 8)) >> 12;  // 0 .. T-1 "microseconds"
+        for (unsigned i = 0; i < 2u * n; ++i) __builtin_amdgcn_s_sleep(19);  // ~1216 clocks ~ 0.5 us
+    }
+#endif
     int64_t tile_id;
     int g;
     xcd_tile_of_block(blockIdx.x, p->ntiles, &tile_id, &g);
@@ -97,15 +112,15 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
         if (p->from_state) {
             if (cell_ok) xc = p->x_climo[seg];
             tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
-        } else if (n > 0) {
+        } else if (n > 0 && !(abl & 4)) {
             TileRegs<NR> xh;
             tile_issue<NR>(p->X, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, xh);
-            tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
+            if (!(abl & 64)) tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
             xc = tile_reduce_mean<NR>(xh, n, c0, p->C, scratch, p->status_fit, wave, lane, bad_cell);
-        } else {
+        } else if (!(abl & 64)) {
             tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
         }
-        tile_commit<NR>(xf, m, c0, p->C, tile + kPadFront, RS, p->status_p, bad_cell);
+        if (!(abl & 64)) tile_commit<NR>(xf, m, c0, p->C, tile + kPadFront, RS, p->status_p, bad_cell);
         zero_pads(row, m, lane, CH + 4);
     }
     __syncthreads();
@@ -137,7 +152,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
             __builtin_amdgcn_sched_barrier(0);
         }
         wave_fence();
-        sort_segment<K>(u, row, m, lane);
+        sort_segment<K>(u, row, m, lane, !(abl & 1));
     }
     // ---- ranks off the tags; near-tie detection --------------------------------------------------------
     const int np = (m + K - 1) / K * K;
@@ -165,7 +180,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
         }
         // data at or above the pad range would sort behind pads: hand the segment back as well
         redo |= __double2hiint(row[m - 1]) >= kPadHi;
-        redo = redo && owner && cell_live && bad_cell[wave] == 0;
+        redo = redo && owner && cell_live && bad_cell[wave] == 0 && (abl & 255) == 0;
     }
     // every wave is done with its row; a workgroup with an ambiguous segment leaves the (tile, group) to RANK / APPLY
     if (__syncthreads_or(redo ? 1 : 0)) {
@@ -181,7 +196,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
     if (!p->from_state) {
         if (n > 0) {
             SD_LANE();
-            load_tile<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, tile, RS, p->status_fit);
+            if (!(abl & 32)) load_tile<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, tile, RS, p->status_fit);
             __syncthreads();
             double v[K];
             load_blocked<K>(row, n, lane, 0.0, v);
@@ -192,7 +207,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
 #pragma unroll
             for (int i = 0; i < K; ++i) v[i] = K * lane + i < n ? v[i] : __builtin_inf();
             wave_fence();
-            sort_segment<K>(v, row, n, lane);  // quantile.py:462 np.sort
+            sort_segment<K>(v, row, n, lane, !(abl & 2));  // quantile.py:462 np.sort
         }
     } else {
         SD_LANE();
@@ -205,7 +220,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
     }
 
     TileRegs<NR> xf2;  // SLAB = false: second read of the x_fut tile, in flight during the map step
-    if (!SLAB) tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf2);
+    if (!SLAB && !(abl & 8)) tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf2);
 
     // ---- map ranks through the fitted inverse CDF (quantile.py:523-545), scatter to time positions -----
     {
@@ -282,7 +297,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
             }
         }
         wave_fence();
-    } else {
+    } else if (!(abl & 8)) {
         __syncthreads();  // all rows read: free again
         tile_commit<NR>(xf2, m, c0, p->C, tile + kPadFront, RS, p->status_p);
         SD_LANE();
@@ -313,13 +328,13 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
     }
     __syncthreads();
     const bool vec_o = (p->ld_out % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->out) & 15) == 0);
-    store_tile(p->out, p->ld_out, p->ord_p + begp, m, c0, p->C, vec_o, tile, RS);
+    if (!(abl & 16)) store_tile(p->out, p->ld_out, p->ord_p + begp, m, c0, p->C, vec_o, tile, RS);
 #undef SD_LANE
 }
 
 template <int K, bool IDENT, bool SLAB>
 int launch_kis(sd_ctx* ctx, const Params& p) {
-    const size_t lds = ((size_t)kW * p.RS + 64 + 16 + 8) * sizeof(double);
+    const size_t lds = ((size_t)kW * p.RS + kHeadDoubles) * sizeof(double);
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fz_kernel<K, IDENT, SLAB>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t tx = (p.ntiles + 7) / 8;

@@ -38,6 +38,7 @@ struct Params {
     int* work_count;  // device counter (items appended, may exceed work_cap: the excess is lost and reported)
     int work_cap;
     int use_worklist;
+    int dev_flags;  // development library only (SD_FZ_ABLATE): phases skipped to time the rest; results are then wrong
 };
 
 }  // namespace sdrs

@@ -39,10 +39,10 @@ __device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g
     constexpr bool kTas = KIND == SD_BCSD_TAS;
     constexpr int CH = Chunk<K>::CH;
     constexpr int NR = (K + 1) / 2;
-    double* const tile = reinterpret_cast<double*>(smem_raw);
+    double* const scratch = reinterpret_cast<double*>(smem_raw);  // 64 doubles
+    const double* const rcp = scratch + 64;                       // 16 doubles: correctly rounded 1/c, c = 1..9
+    double* const tile = scratch + kHeadDoubles;
     const int RS = p->RS;
-    double* const scratch = tile + kW * RS;  // 64 doubles
-    const double* const rcp = scratch + 64;  // 16 doubles: correctly rounded 1/c, c = 1..9
     const int64_t c0 = tile_id * kW;
     const int t_ = tid_now();
     const int wave = t_ / kWave, lane = t_ % kWave;
@@ -163,6 +163,13 @@ __device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g
         return;
     }
 
+    if (MODE == MODE_FIT && p->X != nullptr && n > 0) {
+        // x climatology of the fitted state (bcsd.py:222); BcsdPrecipitation only validates X (bcsd.py:130-147)
+        TileRegs<NR> xh;
+        tile_issue<NR>(p->X, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, xh);
+        xc = tile_reduce_mean<NR>(xh, n, c0, p->C, scratch, p->status_fit, wave, lane);
+        if (kTas && lane == 0 && cell_ok) p->x_climo[seg] = xc;
+    }
     if (MODE == MODE_APPLY) {  // issued first: the loads fly while y is sorted
         if (kTas && cell_ok) xc = p->x_climo[seg];
         const uint32_t* rk = p->ranks + (seg * p->slab_nr) * kWave + lane;
@@ -291,7 +298,7 @@ template <int K, int MODE, int OCC, int KIND, bool IDENT>
 __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();  // Params is the only kernel argument
-    fill_rcp_table(reinterpret_cast<double*>(smem_raw) + kW * p->RS + 64);
+    fill_rcp_table(reinterpret_cast<double*>(smem_raw) + 64);
     if (p->use_worklist) {
         // segments handed back by the fused kernel: a fixed grid walks the list
         int count = *p->work_count;
@@ -314,7 +321,7 @@ __global__ void __launch_bounds__(kThreads, OCC) bcsd_rs_kernel(const Params) {
 
 template <int K, int MODE, int OCC, int KIND, bool IDENT>
 int launch_koki(sd_ctx* ctx, const Params& p, const char* name) {
-    const size_t lds = ((size_t)kW * p.RS + 64 + 16) * sizeof(double);
+    const size_t lds = ((size_t)kW * p.RS + sdw::kHeadDoubles) * sizeof(double);
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_rs_kernel<K, MODE, OCC, KIND, IDENT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t tx = (p.ntiles + 7) / 8;

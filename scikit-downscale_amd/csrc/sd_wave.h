@@ -13,6 +13,10 @@ constexpr int kWave = 64;
 constexpr int kW = 8;          // cells per workgroup
 constexpr int kThreads = 512;  // 8 waves
 constexpr int kRowsPerPass = kThreads / 4;  // 4 lanes (16 B each) cover the 8 cells of one row
+// LDS layout of a workgroup: [column-sum exchange: 64 doubles][1/c table: 16][per-cell flags: 8][tile: kW rows of RS].
+// The small areas come first so that no row starts at LDS address 0: the searches keep "address of element - 1"
+// positions and compare them as unsigned numbers.
+constexpr int kHeadDoubles = 64 + 16 + 8;
 
 // The thread index behind an opaque barrier: keeps the compiler from hoisting everything derived from it to the
 // top of the kernel (and keeping it alive in registers across the sorts).
@@ -125,7 +129,7 @@ __device__ __forceinline__ void merge_rounds(double* row, int np, int lane) {
 // sort the wave's segment: v[] = K consecutive samples per lane (pads sort last), result in row[0..n); the
 // row must have ceil(n / K) * K + 1 slots (the pads of the last run are stored and sorted like data).
 template <int K>
-__device__ __forceinline__ void sort_segment(double (&v)[K], double* row, int n, int lane) {
+__device__ __forceinline__ void sort_segment(double (&v)[K], double* row, int n, int lane, bool rounds = true) {
     sort_registers<K>(v);
     const int np = (n + K - 1) / K * K;
     if (K * lane < np) {
@@ -134,7 +138,7 @@ __device__ __forceinline__ void sort_segment(double (&v)[K], double* row, int n,
         for (int i = 0; i < K; ++i) dst[i] = v[i];
     }
     wave_fence();
-    merge_rounds<K>(row, np, lane);
+    if (rounds) merge_rounds<K>(row, np, lane);  // rounds == false: timing experiments of the development library only
 }
 
 // ---- tile movement ------------------------------------------------------------------------------
