@@ -127,6 +127,9 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
 
     // ---- shifted series, tagged with the time position ------------------------------------------------
     double* const slab0 = SLAB ? p->shift + (seg * p->slab_k) * kWave : nullptr;
+    const int np = (m + K - 1) / K * K;
+    unsigned pos2[NR];  // two 16-bit tags (8 * time position) per register
+    bool redo = false;
     {
         SD_LANE();
         double* const slab = slab0 + lane;
@@ -152,30 +155,20 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
             __builtin_amdgcn_sched_barrier(0);
         }
         wave_fence();
-        sort_segment<K>(u, row, m, lane, !(abl & 1));
-    }
-    // ---- ranks off the tags; near-tie detection --------------------------------------------------------
-    const int np = (m + K - 1) / K * K;
-    unsigned pos2[NR];  // two 16-bit tags (8 * time position) per register
-    bool redo = false;
-    {
-        SD_LANE();
+        sort_segment<K, true>(u, row, m, lane, !(abl & 1));  // u[] <- the sorted values of the positions this lane owns
+        // ---- ranks off the tags; near-tie detection ----------------------------------------------------
         const bool owner = K * lane < np;  // this lane owns sorted positions K*lane .. K*lane + K - 1
-        const double* srow = row + (owner ? K * lane : 0);
-        double s[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) s[i] = srow[i];
         long long key[K];  // upper 48 bits
 #pragma unroll
-        for (int i = 0; i < K; ++i) key[i] = __double_as_longlong(s[i]) & ~(long long)kTagMask;
+        for (int i = 0; i < K; ++i) key[i] = __double_as_longlong(u[i]) & ~(long long)kTagMask;
 #pragma unroll
         for (int i = 0; i + 1 < K; ++i) redo |= key[i] == key[i + 1];
         const long long knext = __shfl_down(key[0], 1, kWave);
         redo |= (K * (lane + 1) < np) && key[K - 1] == knext;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const unsigned e = (unsigned)__double2loint(s[2 * i]) & kTagMask;
-            const unsigned o = 2 * i + 1 < K ? (unsigned)__double2loint(s[2 * i + 1]) << 16 : 0u;
+            const unsigned e = (unsigned)__double2loint(u[2 * i]) & kTagMask;
+            const unsigned o = 2 * i + 1 < K ? (unsigned)__double2loint(u[2 * i + 1]) << 16 : 0u;
             pos2[i] = e | o;
         }
         // data at or above the pad range would sort behind pads: hand the segment back as well
@@ -193,6 +186,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
 
     // ---- y: climatology + sorted segment in the wave's row ------------------------------------------
     double yc = 0.0;
+    double t[K];  // IDENT: the sorted observations of the positions this lane owns (rank r <-> r-th sorted observation)
     if (!p->from_state) {
         if (n > 0) {
             SD_LANE();
@@ -207,7 +201,11 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
 #pragma unroll
             for (int i = 0; i < K; ++i) v[i] = K * lane + i < n ? v[i] : __builtin_inf();
             wave_fence();
-            sort_segment<K>(v, row, n, lane, !(abl & 2));  // quantile.py:462 np.sort
+            sort_segment<K, IDENT>(v, row, n, lane, !(abl & 2));  // quantile.py:462 np.sort
+            if (IDENT) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) t[i] = v[i];
+            }
         }
     } else {
         SD_LANE();
@@ -217,6 +215,11 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
             for (int i = lane; i < n; i += kWave) row[i] = src[i];
         }
         wave_fence();
+        if (IDENT) {
+            const double* srow = row + (K * lane < np ? K * lane : 0);
+#pragma unroll
+            for (int i = 0; i < K; ++i) t[i] = srow[i];
+        }
     }
 
     TileRegs<NR> xf2;  // SLAB = false: second read of the x_fut tile, in flight during the map step
@@ -226,12 +229,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
     {
         SD_LANE();
         const bool owner = K * lane < np;
-        double t[K];
-        const double* srow = row + (owner ? K * lane : 0);
-        if (IDENT) {
-#pragma unroll
-            for (int i = 0; i < K; ++i) t[i] = srow[i];  // rank r <-> r-th sorted observation
-        } else {
+        if (!IDENT) {
             double slo = 0.0, ilo = 0.0, shi = 0.0, ihi = 0.0;
             if (m > n && n > 0) {  // tails are reachable only when the predict segment is longer
                 const int e = n < 10 ? n : 10;
@@ -267,11 +265,10 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
         wave_fence();  // every lane has read what it needs of the sorted row
         if (owner) {
             const unsigned rowb = lds_addr(row);
-            typedef __attribute__((address_space(3))) double lds_double_t;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const unsigned tag = (i & 1) ? (pos2[i >> 1] >> 16) : (pos2[i >> 1] & kTagMask);
-                *reinterpret_cast<lds_double_t*>((uintptr_t)(rowb + tag)) = t[i];
+                lds_store_f64(rowb + tag, t[i]);
             }
         }
         wave_fence();

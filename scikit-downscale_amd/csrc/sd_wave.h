@@ -49,7 +49,17 @@ __device__ __forceinline__ unsigned lds_addr(const void* generic_ptr_into_lds) {
 }
 
 // ---- wave-level merge sort of row[0..n): runs of K per lane -> fully sorted, in place ------------
-// Round r merges pairs of runs of length K << r.  Every lane owns K consecutive output positions of
+// Round 0 (lane pairs) runs in registers, rounds 1..5 through the wave's LDS row.
+//
+// Round 0: odd lanes work on negated values, so that every lane executes the same instructions: after the register
+// sort a lane holds its run ascending *in its own domain*; it fetches register j of its neighbour (DPP quad_perm
+// [1,0,3,2], sign flipped = the neighbour's value seen from the own domain, which is the neighbour's run in
+// descending order) and keeps z[j] = min(own[j], fetched[j]): the even lane is left with the K smallest of the 2K
+// values, the odd lane with the negated K largest, both as an ascending-then-descending sequence that the pruned
+// bitonic merger sorts.  The pair's run of 2K goes to LDS in true order (odd lanes store back to front).  Compared
+// with a first round through LDS this saves the store of the unmerged runs, the co-rank search and the window loads.
+//
+// Rounds r >= 1 merge pairs of runs of length K << r.  Every lane owns K consecutive output positions of
 // its pair: it finds its co-rank (merge path) by binary search, loads the matching windows of A and B
 // (exactly one LDS read per element, all independent), merges them in registers and the wave writes
 // the K outputs back in place.  LDS requests of one wave are served in order: no barrier needed.
@@ -59,16 +69,33 @@ __device__ __forceinline__ unsigned lds_addr(const void* generic_ptr_into_lds) {
 // wave-uniform stride sequence len -> len - len/2 for every lane (starting from the longest possible range, L + 1
 // candidates); a probe past the lane's own range is switched off by one address comparison (t <= hi0), whatever it
 // reads.  Positions are LDS byte addresses of A[base - 1]; the B probe sits at S - t.  Per step: add, subtract,
-// two reads, two compares, one select (the previous lo/hi bisection: 11 vector instructions).
-template <int K>
-__device__ __forceinline__ void merge_rounds(double* row, int np, int lane) {
-    // np = number of slots being sorted, a multiple of K: the +inf pads that fill the last lane's run are
+// two reads, two compares, one select.
+//
+// KEEP: the K sorted values of the positions a lane owns (K * lane ...) are also returned in v[] (taken from the
+// registers of the last round; segments of at most 2K slots read them back).
+typedef __attribute__((address_space(3))) double lds_double_t;
+__device__ __forceinline__ void lds_store_f64(unsigned addr, double x) { *reinterpret_cast<lds_double_t*>((uintptr_t)addr) = x; }
+
+__device__ __forceinline__ double flip_sign(double x, int mask) {  // mask = 0 or 0x80000000
+    return __hiloint2double(__double2hiint(x) ^ mask, __double2loint(x));
+}
+// the value the neighbouring lane (lane ^ 1) holds in x, negated
+__device__ __forceinline__ double neighbour_negated(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xF, 0xF, true) ^ (int)0x80000000;
+    return __hiloint2double(hi, lo);
+}
+
+template <int K, bool KEEP>
+__device__ __forceinline__ void merge_rounds(double* row, int np, int lane, double (&v)[K]) {
+    // np = number of slots being sorted, a multiple of K: the pads that fill the last lane's run are
     // ordinary elements (they sort to the end), so every participating lane merges exactly K outputs and
     // no per-element validity test is needed; lanes past np sit out (one divergent branch per round).
     constexpr MergeNet<K> net{};
     const unsigned rowb = lds_addr(row);
+    double w[K];
 #pragma unroll 1
-    for (int r = 0; r < 6; ++r) {
+    for (int r = 1; r < 6; ++r) {
         const int L = K << r;
         if (L >= np) break;  // wave-uniform: a single run left
         const int gl = lane & ((2 << r) - 1);  // lane within its merge group
@@ -98,7 +125,6 @@ __device__ __forceinline__ void merge_rounds(double* row, int np, int lane) {
         const int inext = __shfl_down(lo, 1, kWave);
         const int ihi = (d + K >= LA + LB) ? LA : inext;  // co-rank of the end of this lane's window
         const int acnt = ihi - lo;                         // elements taken from A; K - acnt from B
-        double w[K];
         if (busy) {
             const double* pa = row + a0 + lo;                       // A window, ascending: pa[s], s < acnt
             const double* pq = row + a1 + (d - lo) + (K - acnt) - 1 + acnt;  // B window read backwards: pq[-s], s >= acnt
@@ -124,21 +150,51 @@ __device__ __forceinline__ void merge_rounds(double* row, int np, int lane) {
         }
         wave_fence();
     }
+    if (KEEP) {
+        if (np > 2 * K) {  // the last round covered the whole row: its registers are the lane's sorted positions
+#pragma unroll
+            for (int s = 0; s < K; ++s) v[s] = w[net.out[s]];
+        } else {
+            const double* src = row + (K * lane < np ? K * lane : 0);
+#pragma unroll
+            for (int s = 0; s < K; ++s) v[s] = src[s];
+        }
+    }
 }
 
-// sort the wave's segment: v[] = K consecutive samples per lane (pads sort last), result in row[0..n); the
-// row must have ceil(n / K) * K + 1 slots (the pads of the last run are stored and sorted like data).
-template <int K>
+// sort the wave's segment: v[] = K consecutive samples per lane (pads sort last: every lane, also those past the
+// segment, must hold K values that are >= all data), result in row[0..n); the row must have ceil(n / K) * K + 1
+// slots (the pads of the last run are stored and sorted like data).
+template <int K, bool KEEP = false>
 __device__ __forceinline__ void sort_segment(double (&v)[K], double* row, int n, int lane, bool rounds = true) {
-    sort_registers<K>(v);
+    constexpr MergeNet<K> net{};
     const int np = (n + K - 1) / K * K;
-    if (K * lane < np) {
-        double* dst = row + K * lane;
+    const int neg = (lane & 1) << 31;
 #pragma unroll
-        for (int i = 0; i < K; ++i) dst[i] = v[i];
+    for (int i = 0; i < K; ++i) v[i] = flip_sign(v[i], neg);
+    sort_registers<K>(v);
+    double z[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) z[j] = vmin(v[j], neighbour_negated(v[j]));
+#pragma unroll
+    for (int c = 0; c < net.n; ++c) {
+        const double mn = vmin(z[net.a[c]], z[net.b[c]]);
+        const double mx = vmax(z[net.a[c]], z[net.b[c]]);
+        z[net.a[c]] = mn;
+        z[net.b[c]] = mx;
+    }
+    if (K * lane < np) {
+        // even lane: positions K*lane + s; odd lane (negated, so back to front): K*lane + K-1 - s
+        unsigned a = lds_addr(row) + 8u * (unsigned)(K * lane) + ((lane & 1) ? 8u * (K - 1) : 0u);
+        const unsigned step = (lane & 1) ? (unsigned)-8 : 8u;
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            lds_store_f64(a, flip_sign(z[net.out[s]], neg));
+            a += step;
+        }
     }
     wave_fence();
-    if (rounds) merge_rounds<K>(row, np, lane);  // rounds == false: timing experiments of the development library only
+    if (rounds) merge_rounds<K, KEEP>(row, np, lane, v);  // rounds == false: timing experiments of the development library only
 }
 
 // ---- tile movement ------------------------------------------------------------------------------
