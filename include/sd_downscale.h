@@ -132,6 +132,22 @@ int sd_bcsd_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, cons
 int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_dev, int64_t ld,
                         const int32_t* group_id_p, int64_t Tp, double* out_dev, int64_t ld_out, int32_t* cell_status);
 /* fused fit+predict for resident fields: one pass, no persisted state. */
+/* Fit on explicitly listed groups: group_order[group_offsets[G]] = time indices group by group (a time step may belong
+ * to several groups, or to none: the +-15-day day-of-year windows of time_grouper='daily_nasa-nex', groupers.py:19-89,
+ * bcsd.py:36-38,50-55), group_offsets[G+1].  The state's series length (sd_bcsd_state_info T, y_sorted of the export)
+ * is the number of listed entries. */
+int sd_bcsd_fit_groups(sd_ctx* ctx, int kind, const double* X, const double* y, const int32_t* group_order,
+                       const int64_t* group_offsets, int G, int64_t T, int64_t C, int return_anoms, sd_bcsd_state** out);
+int sd_bcsd_fit_groups_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_dev, int64_t ld, const int32_t* group_order,
+                           const int64_t* group_offsets, int G, int64_t T, int64_t C, int return_anoms, sd_bcsd_state** out);
+/* Predict with a climate-trend grouper of its own (bcsd.py:247-267): the 9-sample rolling mean runs over the groups of
+ * trend_group_id (climate_trend, G_trend groups), the climatologies and the quantile mapping use group_id_p (groups of
+ * the fitted state).  BcsdPrecipitation has no trend: same as sd_bcsd_predict. */
+int sd_bcsd_predict_trend(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, const int32_t* group_id_p,
+                          const int32_t* trend_group_id, int G_trend, int64_t Tp, double* out, int32_t* cell_status);
+int sd_bcsd_predict_trend_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_dev, int64_t ld, const int32_t* group_id_p,
+                              const int32_t* trend_group_id, int G_trend, int64_t Tp, double* out_dev, int64_t ld_out,
+                              int32_t* cell_status);
 int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_dev, int64_t ld,
                             const int32_t* group_id, int G, int64_t T, int64_t C, int return_anoms,
                             const double* Xp_dev, int64_t ld_p, const int32_t* group_id_p, int64_t Tp,

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstdlib>
 
+#include <cstring>
+
 #include "sd_bcsd_rs.h"
 #include "sd_internal.h"
 #include "sd_sortnet.h"
@@ -316,6 +318,50 @@ __global__ void __launch_bounds__(256) nan_fill_kernel(double* __restrict__ out,
         for (int64_t t = threadIdx.x >> 5; t < Tp; t += 8) out[t * ld + c] = nan;
 }
 
+// ---- predict with a climate-trend grouper that differs from the time grouper (bcsd.py:247-267) ----
+// One thread per cell (256 adjacent cells per workgroup: 2 KB row fragments), one trend group per blockIdx.y: the
+// 9-sample centred rolling mean (min_periods=1) walks the group's time steps in order; window sums are taken in the
+// same fixed order as in the tile kernels.
+__global__ void __launch_bounds__(256) bcsd_trend_shift_kernel(const double* __restrict__ X, int64_t ld, const int32_t* __restrict__ ord,
+                                                               const int32_t* __restrict__ off, const int32_t* __restrict__ gid_qm,
+                                                               int G, const double* __restrict__ x_climo, int64_t C,
+                                                               double* __restrict__ shift, double* __restrict__ u) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int beg = off[blockIdx.y], m = off[blockIdx.y + 1] - beg;
+    const int32_t* o = ord + beg;
+    double w[9];  // w[d] = sample j - 4 + d (0 outside the group)
+#pragma unroll
+    for (int d = 0; d < 9; ++d) w[d] = (d >= 4 && d - 4 < m) ? X[(int64_t)o[d - 4] * ld + c] : 0.0;
+    for (int j = 0; j < m; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) s += w[d];
+        const int lo = j - 4 > 0 ? j - 4 : 0, hi = j + 5 < m ? j + 5 : m;
+        const double mean = s / (double)(hi - lo);
+        const int64_t t = o[j];
+        const double sh = mean - x_climo[c * G + gid_qm[t]];  // bcsd.py:253
+        shift[t * C + c] = sh;
+        u[t * C + c] = w[4] - sh;  // bcsd.py:256
+#pragma unroll
+        for (int d = 0; d < 8; ++d) w[d] = w[d + 1];
+        w[8] = j + 5 < m ? X[(int64_t)o[j + 5] * ld + c] : 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(256) bcsd_trend_restore_kernel(double* __restrict__ out, int64_t ld_out, const double* __restrict__ shift,
+                                                                 const int32_t* __restrict__ gid_qm, int G, const double* __restrict__ y_climo,
+                                                                 int return_anoms, int64_t Tp, int64_t C) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t t1 = min((int64_t)(blockIdx.y + 1) * 64, Tp);
+    for (int64_t t = (int64_t)blockIdx.y * 64; t < t1; ++t) {
+        double v = shift[t * C + c] + out[t * ld_out + c];            // bcsd.py:263
+        if (return_anoms) v = v - y_climo[c * G + gid_qm[t]];           // bcsd.py:266-267
+        out[t * ld_out + c] = v;
+    }
+}
+
 int pick_tile_width(size_t lds_max, int nmax, int tiles, int* W, int* stride) {
     // LDS need: tiles * W * stride * 8 (+ W*64*8 staging when tiles == 2)
     const int st = nmax | 1;  // odd stride: rows of different cells start on different banks
@@ -330,27 +376,84 @@ int pick_tile_width(size_t lds_max, int nmax, int tiles, int* W, int* stride) {
     return sd_set_error(SD_ERR_UNSUPPORTED, "BCSD segment of %d samples does not fit the %zu-byte LDS", nmax, lds_max);
 }
 
-struct DevGroupTable {
-    sd_scratch order, off;
+struct DevPtr {
+    void* p = nullptr;
+};
+struct DevGroupTable {  // borrowed from the context's group-table cache (valid until the next upload_group_table calls evict it)
+    DevPtr order, off;
     int nmax = 0;
     std::vector<int64_t> host_off;
+    sd_scratch own_order, own_off;  // explicit tables (upload_explicit_table) are owned by the call
 };
 
-int upload_group_table(sd_ctx* ctx, const int32_t* gid, int64_t T, int G, DevGroupTable* d) {
-    sd_group_table gt;
-    SD_TRY(sd_build_group_table(gid, T, G, &gt));
-    SD_CHECK_ARG(T < (int64_t)1 << 31, "T too large");
-    std::vector<int32_t> off32(gt.off.begin(), gt.off.end());
-    SD_HIP(d->order.alloc(ctx, sizeof(int32_t) * T));
-    SD_HIP(d->off.alloc(ctx, sizeof(int32_t) * (G + 1)));
-    SD_HIP(hipMemcpyAsync(d->order.p, gt.order.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(hipMemcpyAsync(d->off.p, off32.data(), sizeof(int32_t) * (G + 1), hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
-    d->nmax = gt.nmax;
-    d->host_off = gt.off;
+// Explicit group table: `order` lists time indices group by group (a time step may belong to several groups: the +-15
+// day windows of time_grouper='daily_nasa-nex', groupers.py:19-89), off[G+1] delimits the groups.
+int upload_explicit_table(sd_ctx* ctx, const int32_t* order, const int64_t* off, int G, int64_t T, DevGroupTable* d) {
+    SD_CHECK_ARG(off[0] == 0, "group_offsets[0] must be 0");
+    const int64_t N = off[G];
+    SD_CHECK_ARG(N > 0 && N < (int64_t)1 << 31, "group table: %lld entries", (long long)N);
+    d->host_off.assign(off, off + G + 1);
+    d->nmax = 0;
+    for (int g = 0; g < G; ++g) {
+        SD_CHECK_ARG(off[g + 1] >= off[g], "group_offsets must not decrease");
+        d->nmax = std::max(d->nmax, (int)(off[g + 1] - off[g]));
+    }
+    for (int64_t i = 0; i < N; ++i) SD_CHECK_ARG(order[i] >= 0 && order[i] < T, "group_order[%lld] = %d outside [0,%lld)", (long long)i, order[i], (long long)T);
+    std::vector<int32_t> off32(off, off + G + 1);
+    SD_HIP(d->own_order.alloc(ctx, sizeof(int32_t) * (size_t)N));
+    SD_HIP(d->own_off.alloc(ctx, sizeof(int32_t) * (size_t)(G + 1)));
+    SD_HIP(hipMemcpyAsync(d->own_order.p, order, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(hipMemcpyAsync(d->own_off.p, off32.data(), sizeof(int32_t) * (size_t)(G + 1), hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    d->order.p = d->own_order.p;
+    d->off.p = d->own_off.p;
     return SD_OK;
 }
 
+constexpr size_t kGtCacheEntries = 8;
+
+int upload_group_table(sd_ctx* ctx, const int32_t* gid, int64_t T, int G, DevGroupTable* d) {
+    SD_CHECK_ARG(T < (int64_t)1 << 31, "T too large");
+    sd_gt_cache_entry* hit = nullptr;
+    for (auto& e : ctx->gt_cache)
+        if (e.G == G && (int64_t)e.gid.size() == T && memcmp(e.gid.data(), gid, sizeof(int32_t) * (size_t)T) == 0) hit = &e;
+    if (hit == nullptr) {
+        sd_group_table gt;
+        SD_TRY(sd_build_group_table(gid, T, G, &gt));
+        std::vector<int32_t> off32(gt.off.begin(), gt.off.end());
+        if (ctx->gt_cache.size() >= kGtCacheEntries) {  // replace the least recently used entry (no call is in flight: calls synchronise)
+            size_t lru = 0;
+            for (size_t i = 1; i < ctx->gt_cache.size(); ++i)
+                if (ctx->gt_cache[i].last_use < ctx->gt_cache[lru].last_use) lru = i;
+            SD_HIP(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->gt_cache[lru].order);
+            (void)hipFree(ctx->gt_cache[lru].off);
+            ctx->gt_cache.erase(ctx->gt_cache.begin() + (long)lru);
+        }
+        sd_gt_cache_entry e;
+        e.G = G;
+        e.gid.assign(gid, gid + T);
+        e.nmax = gt.nmax;
+        e.host_off = gt.off;
+        SD_HIP(hipMalloc((void**)&e.order, sizeof(int32_t) * (size_t)T));
+        hipError_t rc = hipMalloc((void**)&e.off, sizeof(int32_t) * (size_t)(G + 1));
+        if (rc != hipSuccess) {
+            (void)hipFree(e.order);
+            SD_HIP(rc);
+        }
+        ctx->gt_cache.push_back(std::move(e));
+        hit = &ctx->gt_cache.back();
+        SD_HIP(hipMemcpyAsync(hit->order, gt.order.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(hipMemcpyAsync(hit->off, off32.data(), sizeof(int32_t) * (G + 1), hipMemcpyHostToDevice, ctx->stream));
+        SD_HIP(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+    }
+    hit->last_use = ++ctx->gt_clock;
+    d->order.p = hit->order;
+    d->off.p = hit->off;
+    d->nmax = hit->nmax;
+    d->host_off = hit->host_off;
+    return SD_OK;
+}
 
 // BcsdTemperature takes the fused kernel of sd_bcsd_fz.hip (x side, y side, inverse CDF and shift of a segment in
 // one workgroup pass); the segments it hands back (work list: near-equal shifted samples) and BcsdPrecipitation take
@@ -741,6 +844,13 @@ int alloc_state(sd_ctx* ctx, int kind, int G, int64_t T, int64_t C, int return_a
 
 }  // namespace
 
+static int fit_with_table(sd_ctx* ctx, int kind, const double* X_dev, const double* y_dev, int64_t ld, const DevGroupTable& gt, int G,
+                          int64_t T_rows, int64_t C, int return_anoms, sd_bcsd_state** out);
+static int predict_with_table(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_dev, int64_t ld, const DevGroupTable& gt, int64_t Tp,
+                              double* out_dev, int64_t ld_out, int32_t* status_p);
+static int finish_predict(sd_ctx* ctx, const sd_bcsd_state* st, const int32_t* status_p, int64_t Tp, double* out_dev, int64_t ld_out,
+                          int32_t* cell_status);
+
 extern "C" {
 
 int sd_bcsd_state_destroy(sd_bcsd_state* st) {
@@ -769,6 +879,77 @@ int sd_bcsd_fit_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_
     SD_HIP(hipSetDevice(ctx->device));
     DevGroupTable gt;
     SD_TRY(upload_group_table(ctx, group_id, T, G, &gt));
+    return fit_with_table(ctx, kind, X_dev, y_dev, ld, gt, G, T, C, return_anoms, out);
+}
+
+}  // extern "C"
+
+// the kernels of a predict call on an uploaded predict group table (status_p: device [C], zeroed)
+static int predict_with_table(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_dev, int64_t ld, const DevGroupTable& gt, int64_t Tp,
+                              double* out_dev, int64_t ld_out, int32_t* status_p) {
+    const int64_t C = st->C;
+    int W = 0, stride = 0;
+    const int nmax_all = gt.nmax > st->nmax ? gt.nmax : st->nmax;
+    const bool rs = use_rs_path(nmax_all, ld > ld_out ? ld : ld_out);
+    const bool lng = !rs && use_long_path(nmax_all, ctx->lds_max) && long_width(gt.nmax, ctx->lds_max) != 0;
+    if (!rs && !lng) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 2, &W, &stride));
+    QTables qt;
+    if (rs) {
+        const bool identity = st->goff == gt.host_off;  // equal fit / predict group lengths: no inverse-CDF tables needed
+        if (!identity) SD_TRY(build_q_tables(ctx, st->goff, gt.host_off, st->G, &qt));
+        sdrs::Params p = {};
+        p.kind = st->kind; p.G = st->G; p.return_anoms = st->return_anoms; p.RS = sd_bcsd_rs_row_stride(nmax_all);
+        p.C = C; p.Tf = st->T; p.ntiles = (C + 7) / 8;
+        p.Xp = Xp_dev; p.ld_p = ld; p.out = out_dev; p.ld_out = ld_out;
+        p.off_f = (const int32_t*)st->goff_dev;
+        p.ord_p = (const int32_t*)gt.order.p; p.off_p = (const int32_t*)gt.off.p;
+        p.qidx = qt.idx.as<int32_t>(); p.qval = qt.val.as<double>();
+        p.ys = st->ys; p.x_climo = st->x_climo; p.y_climo = st->y_climo;
+        p.status_fit = st->status; p.status_p = status_p;
+        p.identity = identity ? 1 : 0;
+        p.from_state = 1;
+        const bool fused = use_fz_path(st->kind, nmax_all);
+        RsWorkspace w;
+        SD_TRY(carve_workspace(ctx, nmax_all, C, st->G, fused, fused && fz_shift_slab(), false, &w));
+        p.ranks = w.ranks; p.shift = w.shift;
+        p.worklist = w.worklist; p.work_count = w.work_count; p.work_cap = w.work_cap;
+        const std::vector<int> glen = group_lengths(st->goff, &gt.host_off, st->G);
+        SD_TRY(run_predict_kernels(ctx, p, fused, nmax_all, glen));
+        SD_HIP(hipStreamSynchronize(ctx->stream));  // the inverse-CDF tables go back to the block cache
+    } else if (lng) {
+        SD_LONG_DISPATCH(long_width(gt.nmax, ctx->lds_max), launch_long_predict, ctx, st, Xp_dev, ld, gt, status_p, out_dev, ld_out);
+    } else
+    switch (W) {
+        case 8: SD_TRY(launch_predict<8>(ctx, st, Xp_dev, ld, gt, stride, status_p, out_dev, ld_out)); break;
+        case 4: SD_TRY(launch_predict<4>(ctx, st, Xp_dev, ld, gt, stride, status_p, out_dev, ld_out)); break;
+        case 2: SD_TRY(launch_predict<2>(ctx, st, Xp_dev, ld, gt, stride, status_p, out_dev, ld_out)); break;
+        default: SD_TRY(launch_predict<1>(ctx, st, Xp_dev, ld, gt, stride, status_p, out_dev, ld_out)); break;
+    }
+    return SD_OK;
+}
+
+// cells that are masked / failed in fit or non-finite in predict -> NaN columns; public status codes to the host
+static int finish_predict(sd_ctx* ctx, const sd_bcsd_state* st, const int32_t* status_p, int64_t Tp, double* out_dev, int64_t ld_out,
+                          int32_t* cell_status) {
+    const int64_t C = st->C;
+    sd_scratch status_pub;
+    SD_LAUNCH(ctx, "nan_fill_kernel", nan_fill_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, out_dev, ld_out, Tp, C,
+              (const int32_t*)st->status, status_p);
+    if (cell_status) {
+        SD_HIP(status_pub.alloc(ctx, sizeof(int32_t) * C));
+        SD_LAUNCH(ctx, "status_public_kernel", status_public_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
+                  (const int32_t*)st->status, status_p, C, status_pub.as<int32_t>());
+        SD_HIP(hipMemcpyAsync(cell_status, status_pub.p, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+// fit on an uploaded group table; the state's series length is the table's entry count (= T unless groups overlap)
+static int fit_with_table(sd_ctx* ctx, int kind, const double* X_dev, const double* y_dev, int64_t ld, const DevGroupTable& gt, int G,
+                          int64_t T_rows, int64_t C, int return_anoms, sd_bcsd_state** out) {
+    const int64_t T = gt.host_off[G];
+    (void)T_rows;
     int W = 0, stride = 0;
     const bool rs = use_rs_path(gt.nmax, ld);
     const bool lng = !rs && use_long_path(gt.nmax, ctx->lds_max);
@@ -815,6 +996,8 @@ int sd_bcsd_fit_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_
     return SD_OK;
 }
 
+extern "C" {
+
 int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_dev, int64_t ld,
                         const int32_t* group_id_p, int64_t Tp, double* out_dev, int64_t ld_out, int32_t* cell_status) {
     SD_CHECK_ARG(ctx && st && Xp_dev && group_id_p && out_dev, "sd_bcsd_predict: NULL argument");
@@ -823,55 +1006,47 @@ int sd_bcsd_predict_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_d
     const int64_t C = st->C;
     DevGroupTable gt;
     SD_TRY(upload_group_table(ctx, group_id_p, Tp, st->G, &gt));
-    int W = 0, stride = 0;
-    const int nmax_all = gt.nmax > st->nmax ? gt.nmax : st->nmax;
-    const bool rs = use_rs_path(nmax_all, ld > ld_out ? ld : ld_out);
-    const bool lng = !rs && use_long_path(nmax_all, ctx->lds_max) && long_width(gt.nmax, ctx->lds_max) != 0;
-    if (!rs && !lng) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 2, &W, &stride));
-    sd_scratch status_p, status_pub;
+    sd_scratch status_p;
     SD_HIP(status_p.alloc(ctx, sizeof(int32_t) * C));
     SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
-    QTables qt;
-    if (rs) {
-        SD_TRY(build_q_tables(ctx, st->goff, gt.host_off, st->G, &qt));
-        sdrs::Params p = {};
-        p.kind = st->kind; p.G = st->G; p.return_anoms = st->return_anoms; p.RS = sd_bcsd_rs_row_stride(nmax_all);
-        p.C = C; p.Tf = st->T; p.ntiles = (C + 7) / 8;
-        p.Xp = Xp_dev; p.ld_p = ld; p.out = out_dev; p.ld_out = ld_out;
-        p.off_f = (const int32_t*)st->goff_dev;
-        p.ord_p = (const int32_t*)gt.order.p; p.off_p = (const int32_t*)gt.off.p;
-        p.qidx = qt.idx.as<int32_t>(); p.qval = qt.val.as<double>();
-        p.ys = st->ys; p.x_climo = st->x_climo; p.y_climo = st->y_climo;
-        p.status_fit = st->status; p.status_p = status_p.as<int32_t>();
-        p.identity = (st->goff == gt.host_off) ? 1 : 0;
-        p.from_state = 1;
-        const bool fused = use_fz_path(st->kind, nmax_all);
-        RsWorkspace w;
-        SD_TRY(carve_workspace(ctx, nmax_all, C, st->G, fused, fused && fz_shift_slab(), false, &w));
-        p.ranks = w.ranks; p.shift = w.shift;
-        p.worklist = w.worklist; p.work_count = w.work_count; p.work_cap = w.work_cap;
-        const std::vector<int> glen = group_lengths(st->goff, &gt.host_off, st->G);
-        SD_TRY(run_predict_kernels(ctx, p, fused, nmax_all, glen));
-    } else if (lng) {
-        SD_LONG_DISPATCH(long_width(gt.nmax, ctx->lds_max), launch_long_predict, ctx, st, Xp_dev, ld, gt, status_p.as<int32_t>(), out_dev, ld_out);
-    } else
-    switch (W) {
-        case 8: SD_TRY(launch_predict<8>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;
-        case 4: SD_TRY(launch_predict<4>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;
-        case 2: SD_TRY(launch_predict<2>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;
-        default: SD_TRY(launch_predict<1>(ctx, st, Xp_dev, ld, gt, stride, status_p.as<int32_t>(), out_dev, ld_out)); break;
-    }
-    // cells that are masked / failed in fit or non-finite in predict -> NaN rows
-    SD_LAUNCH(ctx, "nan_fill_kernel", nan_fill_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, out_dev, ld_out, Tp, C,
-              (const int32_t*)st->status, (const int32_t*)status_p.p);
-    if (cell_status) {
-        SD_HIP(status_pub.alloc(ctx, sizeof(int32_t) * C));
-        SD_LAUNCH(ctx, "status_public_kernel", status_public_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
-                  (const int32_t*)st->status, (const int32_t*)status_p.p, C, status_pub.as<int32_t>());
-        SD_HIP(hipMemcpyAsync(cell_status, status_pub.p, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    SD_HIP(hipStreamSynchronize(ctx->stream));
-    return SD_OK;
+    SD_TRY(predict_with_table(ctx, st, Xp_dev, ld, gt, Tp, out_dev, ld_out, status_p.as<int32_t>()));
+    return finish_predict(ctx, st, status_p.as<int32_t>(), Tp, out_dev, ld_out, cell_status);
+}
+
+int sd_bcsd_predict_trend_dev(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp_dev, int64_t ld, const int32_t* group_id_p,
+                              const int32_t* trend_group_id, int G_trend, int64_t Tp, double* out_dev, int64_t ld_out,
+                              int32_t* cell_status) {
+    SD_CHECK_ARG(ctx && st && Xp_dev && group_id_p && trend_group_id && out_dev, "sd_bcsd_predict_trend: NULL argument");
+    SD_CHECK_ARG(Tp > 0 && G_trend > 0 && ld >= st->C && ld_out >= st->C, "sd_bcsd_predict_trend: bad sizes");
+    if (st->kind != SD_BCSD_TAS)  // BcsdPrecipitation has no climate-trend shift (bcsd.py:149-170)
+        return sd_bcsd_predict_dev(ctx, st, Xp_dev, ld, group_id_p, Tp, out_dev, ld_out, cell_status);
+    SD_HIP(hipSetDevice(ctx->device));
+    const int64_t C = st->C;
+    DevGroupTable gq, gr;
+    SD_TRY(upload_group_table(ctx, group_id_p, Tp, st->G, &gq));
+    SD_TRY(upload_group_table(ctx, trend_group_id, Tp, G_trend, &gr));
+    sd_scratch status_p, u, shift, gidq;
+    SD_HIP(status_p.alloc(ctx, sizeof(int32_t) * C));
+    SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
+    SD_HIP(u.alloc(ctx, sizeof(double) * (size_t)Tp * (size_t)C));
+    SD_HIP(shift.alloc(ctx, sizeof(double) * (size_t)Tp * (size_t)C));
+    SD_HIP(gidq.alloc(ctx, sizeof(int32_t) * (size_t)Tp));
+    SD_HIP(hipMemcpyAsync(gidq.p, group_id_p, sizeof(int32_t) * (size_t)Tp, hipMemcpyHostToDevice, ctx->stream));
+    // shift = rolling mean over the trend groups - x_climo of the sample's quantile-mapping group (bcsd.py:247-253),
+    // u = X - shift (bcsd.py:256)
+    SD_LAUNCH(ctx, "bcsd_trend_shift_kernel", bcsd_trend_shift_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)G_trend), dim3(256), 0,
+              Xp_dev, ld, (const int32_t*)gr.order.p, (const int32_t*)gr.off.p, (const int32_t*)gidq.p, st->G,
+              (const double*)st->x_climo, C, shift.as<double>(), u.as<double>());
+    // quantile mapping of u by the time grouper's groups (bcsd.py:260): the precipitation path of the kernels (no shift)
+    sd_bcsd_state qm = *st;
+    qm.kind = SD_BCSD_PR;
+    qm.return_anoms = 0;
+    SD_TRY(predict_with_table(ctx, &qm, u.as<double>(), C, gq, Tp, out_dev, ld_out, status_p.as<int32_t>()));
+    // restore the shift (bcsd.py:263), remove the target climatology (bcsd.py:266-267)
+    SD_LAUNCH(ctx, "bcsd_trend_restore_kernel", bcsd_trend_restore_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)((Tp + 63) / 64)),
+              dim3(256), 0, out_dev, ld_out, shift.as<double>(), (const int32_t*)gidq.p, st->G, (const double*)st->y_climo,
+              st->return_anoms, Tp, C);
+    return finish_predict(ctx, st, status_p.as<int32_t>(), Tp, out_dev, ld_out, cell_status);
 }
 
 int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_dev, int64_t ld,
@@ -901,7 +1076,8 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
     SD_HIP(status_p.alloc(ctx, sizeof(int32_t) * C));
     SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
     QTables qt;
-    SD_TRY(build_q_tables(ctx, gf.host_off, gp.host_off, G, &qt));
+    const bool identity = gf.host_off == gp.host_off;  // equal fit / predict group lengths: no inverse-CDF tables needed
+    if (!identity) SD_TRY(build_q_tables(ctx, gf.host_off, gp.host_off, G, &qt));
     const double* first = X_dev ? X_dev : y_dev;
     SD_LAUNCH(ctx, "bcsd_mask_kernel", bcsd_mask_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, first, C,
               status_f.as<int32_t>());
@@ -914,7 +1090,7 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
     p.ord_p = (const int32_t*)gp.order.p; p.off_p = (const int32_t*)gp.off.p;
     p.qidx = qt.idx.as<int32_t>(); p.qval = qt.val.as<double>();
     p.status_fit = status_f.as<int32_t>(); p.status_p = status_p.as<int32_t>();
-    p.identity = (gf.host_off == gp.host_off) ? 1 : 0;
+    p.identity = identity ? 1 : 0;
     {
         // No persisted sorted state.  BcsdTemperature: one fused kernel per segment (no hand-off at all); the segments
         // it hands back, and BcsdPrecipitation: RANK writes 2 bytes/sample (rank of every x_fut sample in its shifted
@@ -966,6 +1142,53 @@ int sd_bcsd_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, cons
     SD_HIP(dout.alloc(ctx, bytes));
     SD_HIP(hipMemcpyAsync(dX.p, Xp, bytes, hipMemcpyHostToDevice, ctx->stream));
     SD_TRY(sd_bcsd_predict_dev(ctx, st, dX.as<double>(), st->C, group_id_p, Tp, dout.as<double>(), st->C, cell_status));
+    SD_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_bcsd_fit_groups_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_dev, int64_t ld, const int32_t* group_order,
+                           const int64_t* group_offsets, int G, int64_t T, int64_t C, int return_anoms, sd_bcsd_state** out) {
+    SD_CHECK_ARG(ctx && y_dev && group_order && group_offsets && out, "sd_bcsd_fit_groups: NULL argument");
+    SD_CHECK_ARG(kind == SD_BCSD_TAS || kind == SD_BCSD_PR, "sd_bcsd_fit_groups: unknown kind %d", kind);
+    SD_CHECK_ARG(kind == SD_BCSD_PR || X_dev, "sd_bcsd_fit_groups: BcsdTemperature needs X");
+    SD_CHECK_ARG(T > 0 && C > 0 && G > 0 && ld >= C, "sd_bcsd_fit_groups: bad sizes T=%lld C=%lld G=%d ld=%lld", (long long)T,
+                 (long long)C, G, (long long)ld);
+    *out = nullptr;
+    SD_HIP(hipSetDevice(ctx->device));
+    DevGroupTable gt;
+    SD_TRY(upload_explicit_table(ctx, group_order, group_offsets, G, T, &gt));
+    return fit_with_table(ctx, kind, X_dev, y_dev, ld, gt, G, T, C, return_anoms, out);
+}
+
+int sd_bcsd_fit_groups(sd_ctx* ctx, int kind, const double* X, const double* y, const int32_t* group_order,
+                       const int64_t* group_offsets, int G, int64_t T, int64_t C, int return_anoms, sd_bcsd_state** out) {
+    SD_CHECK_ARG(ctx && y && group_order && group_offsets && out, "sd_bcsd_fit_groups: NULL argument");
+    SD_CHECK_ARG(T > 0 && C > 0, "sd_bcsd_fit_groups: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_scratch dX, dy;
+    const size_t bytes = sizeof(double) * (size_t)T * (size_t)C;
+    if (X) {
+        SD_HIP(dX.alloc(ctx, bytes));
+        SD_HIP(hipMemcpyAsync(dX.p, X, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    SD_HIP(dy.alloc(ctx, bytes));
+    SD_HIP(hipMemcpyAsync(dy.p, y, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return sd_bcsd_fit_groups_dev(ctx, kind, dX.as<double>(), dy.as<double>(), C, group_order, group_offsets, G, T, C, return_anoms, out);
+}
+
+int sd_bcsd_predict_trend(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, const int32_t* group_id_p,
+                          const int32_t* trend_group_id, int G_trend, int64_t Tp, double* out, int32_t* cell_status) {
+    SD_CHECK_ARG(ctx && st && Xp && group_id_p && trend_group_id && out, "sd_bcsd_predict_trend: NULL argument");
+    SD_CHECK_ARG(Tp > 0, "sd_bcsd_predict_trend: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_scratch dX, dout;
+    const size_t bytes = sizeof(double) * (size_t)Tp * (size_t)st->C;
+    SD_HIP(dX.alloc(ctx, bytes));
+    SD_HIP(dout.alloc(ctx, bytes));
+    SD_HIP(hipMemcpyAsync(dX.p, Xp, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_bcsd_predict_trend_dev(ctx, st, dX.as<double>(), st->C, group_id_p, trend_group_id, G_trend, Tp, dout.as<double>(), st->C,
+                                     cell_status));
     SD_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(hipStreamSynchronize(ctx->stream));
     return SD_OK;

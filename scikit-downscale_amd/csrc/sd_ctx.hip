@@ -15,6 +15,14 @@ int sd_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
+void sd_gt_cache_clear(sd_ctx* ctx) {
+    for (auto& e : ctx->gt_cache) {
+        if (e.order) (void)hipFree(e.order);
+        if (e.off) (void)hipFree(e.off);
+    }
+    ctx->gt_cache.clear();
+}
+
 extern "C" {
 
 int sd_version(void) { return SD_VERSION; }
@@ -66,6 +74,7 @@ int sd_ctx_destroy(sd_ctx* ctx) {
     (void)hipEventDestroy(ctx->p0);
     (void)hipEventDestroy(ctx->p1);
     if (ctx->ws_ptr) (void)hipFree(ctx->ws_ptr);
+    sd_gt_cache_clear(ctx);
     sd_pool_trim(ctx);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -75,6 +84,8 @@ int sd_ctx_destroy(sd_ctx* ctx) {
 int sd_ctx_release_cached(sd_ctx* ctx) {
     SD_CHECK_ARG(ctx, "ctx is NULL");
     SD_HIP(hipSetDevice(ctx->device));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    sd_gt_cache_clear(ctx);
     sd_pool_trim(ctx);
     if (ctx->ws_ptr) {
         SD_HIP(hipFree(ctx->ws_ptr));

@@ -33,6 +33,18 @@ struct sd_prof_entry {
     int64_t launches = 0;
 };
 
+// Device copies of group tables (time indices ordered by (group, time) + offsets) are cached per context: a fit /
+// predict pair, or repeated calls on the same calendar, upload them once (keyed by the group ids themselves).
+struct sd_gt_cache_entry {
+    std::vector<int32_t> gid;
+    int G = 0;
+    int32_t* order = nullptr;  // device [T]
+    int32_t* off = nullptr;    // device [G+1]
+    int nmax = 0;
+    std::vector<int64_t> host_off;
+    uint64_t last_use = 0;
+};
+
 struct sd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -51,7 +63,10 @@ struct sd_ctx {
     std::multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_live;
     size_t pool_cached = 0, pool_cap = 0;
+    std::vector<sd_gt_cache_entry> gt_cache;  // at most kGtCacheEntries, least recently used entry replaced
+    uint64_t gt_clock = 0;
 };
+void sd_gt_cache_clear(sd_ctx* ctx);
 
 // Device memory through the context's block cache (exact-size reuse).  Blocks go back with sd_pool_release;
 // the cache is bounded by pool_cap (a quarter of the device memory) and emptied by sd_ctx_release_cached /

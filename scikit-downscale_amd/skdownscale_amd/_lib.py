@@ -54,6 +54,10 @@ SIGNATURES = {
     "sd_bcsd_fit_dev": [_p, _int, _p, _p, _i64, _p, _int, _i64, _i64, _int, C.POINTER(_p)],
     "sd_bcsd_predict": [_p, _p, _p, _p, _i64, _p, _p],
     "sd_bcsd_predict_dev": [_p, _p, _p, _i64, _p, _i64, _p, _i64, _p],
+    "sd_bcsd_fit_groups": [_p, _int, _p, _p, _p, _p, _int, _i64, _i64, _int, C.POINTER(_p)],
+    "sd_bcsd_fit_groups_dev": [_p, _int, _p, _p, _i64, _p, _p, _int, _i64, _i64, _int, C.POINTER(_p)],
+    "sd_bcsd_predict_trend": [_p, _p, _p, _p, _p, _int, _i64, _p, _p],
+    "sd_bcsd_predict_trend_dev": [_p, _p, _p, _i64, _p, _p, _int, _i64, _p, _i64, _p],
     "sd_bcsd_fit_predict_dev": [_p, _int, _p, _p, _i64, _p, _int, _i64, _i64, _int, _p, _i64, _p, _i64, _p, _i64, _p],
     "sd_bcsd_state_info": [_p, C.POINTER(_int), C.POINTER(_int), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int)],
     "sd_bcsd_state_status": [_p, _p],

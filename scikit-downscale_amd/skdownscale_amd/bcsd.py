@@ -20,7 +20,7 @@ from sklearn.exceptions import NotFittedError
 from . import _lib
 from .base import TimeSynchronousDownscaler
 from .engine import DeviceArray, default_context
-from .groupers import DAY_GROUPER, MONTH_GROUPER, group_keys
+from .groupers import DAY_GROUPER, MONTH_GROUPER, PaddedDOYGrouper, group_keys, padded_doy_table
 
 Cdf = collections.namedtuple("Cdf", ["pp", "vals"])  # quantile.py:20
 FittedCunnane = collections.namedtuple("FittedCunnane", ["cdf_"])
@@ -43,12 +43,12 @@ class _FittedQuantileMapper:
 
 def check_supported(model):
     """Raise NotImplementedError for configurations outside the engine's hot path."""
-    if not callable(model.time_grouper) or isinstance(model.time_grouper, type):
+    tg = model.time_grouper
+    if not (tg is PaddedDOYGrouper or (callable(tg) and not isinstance(tg, type))):
         raise NotImplementedError(
-            f"time_grouper={model.time_grouper!r}: only callable group-key functions (e.g. MONTH_GROUPER) run on the "
-            "HIP engine; 'daily_nasa-nex' / pandas frequency strings are not supported yet")
-    if model.climate_trend is not model.time_grouper:
-        raise NotImplementedError("climate_trend must be the same grouper as time_grouper on the HIP engine")
+            f"time_grouper={tg!r}: callable group-key functions (e.g. MONTH_GROUPER) and 'daily_nasa-nex' run on the HIP engine")
+    if not callable(model.climate_trend) or isinstance(model.climate_trend, type):
+        raise NotImplementedError(f"climate_trend={model.climate_trend!r}: only callable group-key functions run on the HIP engine")
     qm = model.qm_kwargs or {}
     extra = set(qm) - {"detrend", "lt_kwargs", "qt_kwargs"}
     if extra:
@@ -64,12 +64,21 @@ def check_supported(model):
 
 
 class BcsdGridModel:
-    """Batched BCSD over the cell axis: fields are [T, C] (cells fastest), numpy or DeviceArray."""
+    """Batched BCSD over the cell axis: fields are [T, C] (cells fastest), numpy or DeviceArray.
 
-    def __init__(self, kind, return_anoms=True, grouper=MONTH_GROUPER, ctx=None):
+    ``grouper``: the time grouper (group-key function -> one group per key, ``timestep='monthly'`` in the reference's
+    terms) or ``PaddedDOYGrouper`` (``timestep='daily'``: 366 overlapping +-15-day day-of-year groups in fit,
+    bcsd.py:50-55).  ``trend_grouper`` (``climate_trend``): groups of the 9-sample rolling mean in BcsdTemperature.predict
+    (bcsd.py:247-250).  ``day_grouper`` (``climate_trend_grouper``): what the daily time step groups by in predict
+    (bcsd.py:51-53) -- its keys select fitted day-of-year groups, which is the reference's behaviour."""
+
+    def __init__(self, kind, return_anoms=True, grouper=MONTH_GROUPER, ctx=None, trend_grouper=None, day_grouper=DAY_GROUPER):
         self.kind = kind
         self.return_anoms = bool(return_anoms)
         self.grouper = grouper
+        self.trend_grouper = grouper if trend_grouper is None else trend_grouper
+        self.day_grouper = day_grouper
+        self.daily = grouper is PaddedDOYGrouper
         self.ctx = ctx or default_context()
         self.state = None
         self.keys = None
@@ -80,7 +89,7 @@ class BcsdGridModel:
         return gid.astype(np.int32)
 
     def group_ids_predict(self, index):
-        keys = group_keys(index, self.grouper)
+        keys = group_keys(index, self.day_grouper if self.daily else self.grouper)
         pos = np.searchsorted(self.keys, keys)
         pos = np.clip(pos, 0, len(self.keys) - 1)
         bad = self.keys[pos] != keys
@@ -89,15 +98,33 @@ class BcsdGridModel:
         return pos.astype(np.int32)
 
     def fit(self, X, y, index):
-        gid = self.group_ids_fit(index)
-        self.state = self.ctx.bcsd_fit(self.kind, X, y, gid, len(self.keys), self.return_anoms)
+        if self.daily:
+            order, offsets = padded_doy_table(index)
+            if (np.diff(offsets) == 0).any():  # QuantileMapper.fit on an empty group (bcsd.py:66-67 -> sklearn check_array)
+                raise ValueError("Found array with 0 sample(s) (shape=(0, 1)) while a minimum of 1 is required by QuantileMapper.")
+            self.keys = np.arange(1, 367)
+            self.state = self.ctx.bcsd_fit_groups(self.kind, X, y, order, offsets, self.return_anoms)
+        else:
+            gid = self.group_ids_fit(index)
+            self.state = self.ctx.bcsd_fit(self.kind, X, y, gid, len(self.keys), self.return_anoms)
         self.status_ = self.state.status()
         return self
 
     def predict(self, Xp, index_p, out=None):
         if self.state is None:
             raise NotFittedError("This BCSD grid model is not fitted yet.")
-        return self.ctx.bcsd_predict(self.state, Xp, self.group_ids_predict(index_p), out=out)
+        if self.daily and self.return_anoms:
+            # the reference divides / subtracts the climatology over the overlapping day-of-year groups of the result and
+            # then finds 31x too many rows (bcsd.py:170-185, 266-267 with 271-281): mirrored, not repaired
+            if self.kind == _lib.BCSD_TAS:
+                raise ValueError("shape of climo is not equal to input array")
+            n_rows = int(padded_doy_table(index_p)[1][-1])
+            raise ValueError(f"Result shape ({n_rows}, 1) does not match input shape ({len(index_p)}, 1)")
+        gid_p = self.group_ids_predict(index_p)
+        if self.kind == _lib.BCSD_TAS and (self.daily or self.trend_grouper is not self.grouper):
+            tkeys, gid_t = np.unique(group_keys(index_p, self.trend_grouper), return_inverse=True)
+            return self.ctx.bcsd_predict_trend(self.state, Xp, gid_p, gid_t.astype(np.int32), len(tkeys), out=out)
+        return self.ctx.bcsd_predict(self.state, Xp, gid_p, out=out)
 
     def export(self):
         e = self.state.export()
@@ -121,9 +148,26 @@ class BcsdBase(TimeSynchronousDownscaler):
         self.qm_kwargs = qm_kwargs
 
     # ---- helpers -------------------------------------------------------------------------------
+    def _pre_fit(self):
+        """bcsd.py:34-44: 'daily_nasa-nex' swaps the grouper class in (and stays swapped, as in the reference)."""
+        if isinstance(self.time_grouper, str):
+            if self.time_grouper == "daily_nasa-nex":
+                self.time_grouper = PaddedDOYGrouper
+                self.timestep = "daily"
+            else:
+                raise KeyError(self.time_grouper)  # the reference's df.groupby(<frequency string>) looks for a column of that name
+        else:
+            self.time_grouper_ = self.time_grouper
+            self.timestep = "monthly"
+
+    def _new_grid(self):
+        return BcsdGridModel(self._kind, self.return_anoms, self.time_grouper, trend_grouper=self.climate_trend,
+                             day_grouper=self.climate_trend_grouper)
+
     def _fit_engine(self, X2, y2, index):
+        self._pre_fit()
         check_supported(self)
-        grid = BcsdGridModel(self._kind, self.return_anoms, self.time_grouper)
+        grid = self._new_grid()
         grid.fit(X2, y2, index)
         self._grid = grid
         self._adopt(grid.export(), 0)
@@ -162,7 +206,7 @@ class BcsdBase(TimeSynchronousDownscaler):
         xc = self._x_climo.values.reshape(1, -1) if self._kind == _lib.BCSD_TAS else np.zeros((1, len(keys)))
         exported = dict(info=info, y_sorted=np.concatenate(vals).reshape(1, T), x_climo=xc,
                         y_climo=self.y_climo_.values.reshape(1, -1), status=np.zeros(1, np.int32), group_offsets=off)
-        grid = BcsdGridModel(self._kind, self.return_anoms, self.time_grouper)
+        grid = self._new_grid()
         grid.keys = keys
         grid.state = grid.ctx.bcsd_import(exported)
         return grid

@@ -159,7 +159,11 @@ class PointWiseDownscaler:
     def _batched(self):
         m = self._model
         if isinstance(m, BcsdBase):
-            check_supported(m)
+            # every cell's copy runs _pre_fit in the reference ('daily_nasa-nex' swaps the grouper class in, bcsd.py:34-44);
+            # the prototype stays untouched
+            self._bcsd_proto = copy.deepcopy(m)
+            self._bcsd_proto._pre_fit()
+            check_supported(self._bcsd_proto)
             return "bcsd"
         if isinstance(m, (PureAnalog, AnalogRegression)):
             if isinstance(m, AnalogRegression) and (m.thresh is not None or m.lr_kwargs):
@@ -189,11 +193,16 @@ class PointWiseDownscaler:
         feature_dim = kws["feature_dim"]
         Xg, _ = self._to_feature_x(X, feature_dim)
         yg = None
-        if args:
-            yg, _ = _to_grid(args[0], feature_dim)
-            yg = yg.transpose(self._dim, ...)
-        T, F = Xg.shape[:2]
         spatial_dims, spatial_shape = Xg.dims[2:], Xg.shape[2:]
+        if args:
+            # the reference selects y[index] by dimension *name* for every cell of X (core.py:86-93): align y to X's cell order
+            yg, _ = _to_grid(args[0], feature_dim)
+            if set(yg.dims) != {self._dim, *spatial_dims}:
+                raise ValueError(f"y has dims {yg.dims}; expected {(self._dim,) + tuple(spatial_dims)} (the spatial dims of X, no feature dim)")
+            yg = yg.transpose(self._dim, *spatial_dims)
+            if tuple(yg.shape[1:]) != tuple(spatial_shape) or yg.shape[0] != Xg.shape[0]:
+                raise ValueError(f"y has sizes {yg.sizes}, X has {Xg.sizes}")
+        T, F = Xg.shape[:2]
         C = int(np.prod(spatial_shape, dtype=np.int64)) if spatial_shape else 1
         Xv = np.ascontiguousarray(Xg.values, dtype=np.float64).reshape(T, F, C)
         mask = ~np.isnan(Xv[0, 0, :])  # core.py:35-37
@@ -222,7 +231,7 @@ class PointWiseDownscaler:
             if F != 1:
                 msg = "BCSD only supports up to 4 features, found {}" if m._kind == _lib.BCSD_TAS else "BCSD only supports 1 feature, found {}"
                 raise ValueError(msg.format(F))
-            gm = BcsdGridModel(m._kind, m.return_anoms, m.time_grouper)
+            gm = self._bcsd_proto._new_grid()
             gm.fit(Xv[:, 0, :], yv, index)
             self._raise_for_status(gm.status_, Xv[:, 0, :], yv)
         elif kind == "qm":
@@ -279,6 +288,17 @@ class PointWiseDownscaler:
                 models[c] = mod.fit(xdf, **fit_kwargs)
         return _BatchedModels("loop", models, mask, spatial_dims, spatial_shape, coords)
 
+    def _align_to_fitted(self, Xg, feature_dim):
+        """Bring the spatial dims of a predict / transform input into the fitted order (the reference looks the fitted models
+        up by dimension name, core.py:110-141): same dim names required, any order accepted."""
+        fitted = tuple(self._models.spatial_dims)
+        if set(Xg.dims[2:]) != set(fitted):
+            raise ValueError(f"spatial dims {Xg.dims[2:]} do not match the fitted grid's {fitted}")
+        Xg = Xg.transpose(self._dim, feature_dim, *fitted)
+        if tuple(Xg.shape[2:]) != tuple(self._models.spatial_shape):
+            raise ValueError(f"spatial shape {Xg.shape[2:]} does not match the fitted grid {self._models.spatial_shape}")
+        return Xg
+
     # ------------------------------------------------------------------------------------------
     def predict(self, X, **kwargs):
         """Predict for every fitted cell (core.py:266-338); masked cells stay NaN."""
@@ -287,11 +307,10 @@ class PointWiseDownscaler:
         kws = {"along_dim": self._dim, "feature_dim": DEFAULT_FEATURE_DIM} | kwargs
         feature_dim = kws["feature_dim"]
         Xg, was_x = self._to_feature_x(X, feature_dim)
+        Xg = self._align_to_fitted(Xg, feature_dim)
         T, F = Xg.shape[:2]
         spatial_dims, spatial_shape = Xg.dims[2:], Xg.shape[2:]
         C = int(np.prod(spatial_shape, dtype=np.int64)) if spatial_shape else 1
-        if tuple(spatial_shape) != tuple(self._models.spatial_shape):
-            raise ValueError(f"spatial shape {spatial_shape} does not match the fitted grid {self._models.spatial_shape}")
         Xv = np.ascontiguousarray(Xg.values, dtype=np.float64).reshape(T, F, C)
         index = _time_index(Xg, self._dim)
         n_outputs = getattr(self._model, "n_outputs", 1)  # core.py:294-298
@@ -362,11 +381,10 @@ class PointWiseDownscaler:
         kws = {"feature_dim": DEFAULT_FEATURE_DIM} | kwargs
         feature_dim = kws.pop("feature_dim")
         Xg, was_x = self._to_feature_x(X, feature_dim)
+        Xg = self._align_to_fitted(Xg, feature_dim)
         T, F = Xg.shape[:2]
         spatial_shape = Xg.shape[2:]
         C = int(np.prod(spatial_shape, dtype=np.int64)) if spatial_shape else 1
-        if tuple(spatial_shape) != tuple(self._models.spatial_shape):
-            raise ValueError(f"spatial shape {spatial_shape} does not match the fitted grid {self._models.spatial_shape}")
         if kind != "loop":  # one batched launch for the whole grid
             if F != 1:
                 raise ValueError(f"{type(self._model).__name__}.{direction}() only supports a single feature")

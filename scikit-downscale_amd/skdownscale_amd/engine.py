@@ -233,9 +233,33 @@ class Context:
         return out
 
     # ---- BCSD ----
+    @staticmethod
+    def _field2(name, a, T=None, Cc=None):
+        """[T, C] field (numpy or DeviceArray) with the expected sizes: the C ABI takes raw pointers and cannot check them."""
+        if a is None:
+            return None
+        if not isinstance(a, DeviceArray):
+            a = _lib.as_f64(a)
+        if len(a.shape) != 2 or (T is not None and a.shape[0] != T) or (Cc is not None and a.shape[1] != Cc):
+            raise ValueError(f"{name}: expected a [{'T' if T is None else T}, {'C' if Cc is None else Cc}] field, got shape {tuple(a.shape)}")
+        return a
+
+    @staticmethod
+    def _group_ids(name, gid, T, G):
+        gid = _lib.as_i32(gid)
+        if gid.shape != (T,):
+            raise ValueError(f"{name}: expected {T} group ids, got shape {gid.shape}")
+        if T and (gid.min() < 0 or gid.max() >= G):
+            raise ValueError(f"{name}: group ids must lie in [0, {G})")
+        return gid
+
     def bcsd_fit(self, kind, X, y, gid, G, return_anoms=True):
         """X, y: numpy [T,C] (host path) or DeviceArray [T,C] (resident path); X may be None for PR."""
-        gid = _lib.as_i32(gid)
+        y = self._field2("y", y)
+        X = self._field2("X", X, *y.shape)
+        if X is not None and isinstance(X, DeviceArray) != isinstance(y, DeviceArray):
+            raise ValueError("X and y must both be host arrays or both be DeviceArrays")
+        gid = self._group_ids("group_id", gid, y.shape[0], G)
         h = C.c_void_p()
         if isinstance(y, DeviceArray):
             T, Cc = y.shape
@@ -249,9 +273,53 @@ class Context:
             check(self.lib.sd_bcsd_fit(self.handle, kind, ptr(X), ptr(y), ptr(gid), G, T, Cc, int(return_anoms), C.byref(h)))
         return BcsdState(self, h.value, self.lib.sd_bcsd_state_destroy)
 
+    def bcsd_fit_groups(self, kind, X, y, order, offsets, return_anoms=True):
+        """Fit on explicitly listed (possibly overlapping) groups: ``order`` = time indices group by group,
+        ``offsets[G+1]`` (time_grouper='daily_nasa-nex': bcsd.py:36-38,50-55)."""
+        y = self._field2("y", y)
+        X = self._field2("X", X, *y.shape)
+        T, Cc = y.shape
+        order = _lib.as_i32(order)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        G = len(offsets) - 1
+        if G < 1 or offsets[0] != 0 or offsets[-1] != len(order) or (np.diff(offsets) < 0).any():
+            raise ValueError("group offsets must start at 0, not decrease and end at len(order)")
+        if len(order) and (order.min() < 0 or order.max() >= T):
+            raise ValueError(f"group order entries must lie in [0, {T})")
+        h = C.c_void_p()
+        if isinstance(y, DeviceArray):
+            assert X is None or X.ld == y.ld
+            check(self.lib.sd_bcsd_fit_groups_dev(self.handle, kind, None if X is None else X.vptr, y.vptr, y.ld, ptr(order),
+                                                  ptr(offsets), G, T, Cc, int(return_anoms), C.byref(h)))
+        else:
+            check(self.lib.sd_bcsd_fit_groups(self.handle, kind, ptr(X), ptr(y), ptr(order), ptr(offsets), G, T, Cc,
+                                              int(return_anoms), C.byref(h)))
+        return BcsdState(self, h.value, self.lib.sd_bcsd_state_destroy)
+
+    def bcsd_predict_trend(self, state, Xp, gid_p, gid_trend, G_trend, out=None):
+        """Predict with a climate-trend grouper of its own: rolling mean over ``gid_trend`` groups, climatologies and
+        quantile mapping over ``gid_p`` (groups of the state) -- bcsd.py:247-267."""
+        info = state.info()
+        Xp = self._field2("X", Xp, None, info["C"])
+        Tp, Cc = Xp.shape
+        gid_p = self._group_ids("group_id", gid_p, Tp, info["G"])
+        gid_trend = self._group_ids("trend_group_id", gid_trend, Tp, G_trend)
+        status = np.empty(Cc, dtype=np.int32)
+        if isinstance(Xp, DeviceArray):
+            out = self.empty((Tp, Cc)) if out is None else out
+            check(self.lib.sd_bcsd_predict_trend_dev(self.handle, state.vptr, Xp.vptr, Xp.ld, ptr(gid_p), ptr(gid_trend), G_trend, Tp,
+                                                     out.vptr, out.ld, ptr(status)))
+        else:
+            out = np.empty((Tp, Cc))
+            check(self.lib.sd_bcsd_predict_trend(self.handle, state.vptr, ptr(Xp), ptr(gid_p), ptr(gid_trend), G_trend, Tp, ptr(out),
+                                                 ptr(status)))
+        return out, status
+
     def bcsd_predict(self, state, Xp, gid_p, out=None):
-        gid_p = _lib.as_i32(gid_p)
-        Cc = state.info()["C"]
+        info = state.info()
+        Xp = self._field2("X", Xp, None, info["C"])
+        gid_p = self._group_ids("group_id", gid_p, Xp.shape[0], info["G"])
+        Cc = info["C"]
         status = np.empty(Cc, dtype=np.int32)
         if isinstance(Xp, DeviceArray):
             Tp = Xp.shape[0]
@@ -266,10 +334,15 @@ class Context:
 
     def bcsd_fit_predict(self, kind, X, y, gid, G, Xp, gid_p, return_anoms=True, out=None):
         """Fused resident path (DeviceArrays only)."""
-        gid, gid_p = _lib.as_i32(gid), _lib.as_i32(gid_p)
+        y = self._field2("y", y)
+        X = self._field2("X", X, *y.shape)
+        Xp = self._field2("Xp", Xp, None, y.shape[1])
         T, Cc = y.shape
         Tp = Xp.shape[0]
+        gid, gid_p = self._group_ids("group_id", gid, T, G), self._group_ids("group_id_p", gid_p, Tp, G)
         out = self.empty((Tp, Cc)) if out is None else out
+        if tuple(out.shape) != (Tp, Cc):
+            raise ValueError(f"out: expected shape {(Tp, Cc)}, got {tuple(out.shape)}")
         status = np.empty(Cc, dtype=np.int32)
         assert X is None or X.ld == y.ld
         check(self.lib.sd_bcsd_fit_predict_dev(self.handle, kind, None if X is None else X.vptr, y.vptr, y.ld, ptr(gid), G, T,

@@ -33,9 +33,8 @@ class PaddedDOYGrouper:
     """Day-of-year groups padded by +-``offset`` days (groupers.py:19-89): iterating yields ``(doy, rows)`` for doy = 1..366,
     where ``rows`` are the samples of ``df`` whose day of year lies in the 2*offset+1 day window centred on ``doy`` --
     evaluated separately on the 366-day calendar of leap years and the 365-day calendar of the other years (windows wrap
-    around the year end), leap-year rows first.  Host-side helper: the BCSD estimators of this package do not take it yet
-    (``time_grouper='daily_nasa-nex'`` raises NotImplementedError; the reference's predict path for it groups by
-    day-of-month, SURVEY.md section 8 note N3)."""
+    around the year end), leap-year rows first.  ``time_grouper='daily_nasa-nex'`` of the BCSD estimators swaps this class
+    in (bcsd.py:36-38); the engine gets the same groups as one table through ``padded_doy_table``."""
 
     def __init__(self, df, offset=15):
         self.n = 1
@@ -51,8 +50,7 @@ class PaddedDOYGrouper:
         """days of year of the window around day n on an ndays-day calendar, as the reference builds it from the wrapped
         calendar (groupers.py:36-63): offset days before, n itself, and the days after (one fewer when n lies beyond
         the calendar, i.e. n = 366 on the 365-day calendar)"""
-        base = np.arange(1, ndays + 1)
-        wrapped = np.concatenate([base[-self.offset:], base, base[: self.offset]])
+        wrapped = np.pad(np.arange(1, ndays + 1), self.offset, mode="wrap")  # groupers.py:36-39
         i = n - 1
         return np.concatenate([wrapped[i:i + self.offset], [n], wrapped[n + self.offset:i + 2 * self.offset + 1]])
 
@@ -80,3 +78,23 @@ class PaddedDOYGrouper:
         for key, rows in self:
             means[key - 1] = rows.mean().values[0]
         return pd.DataFrame(means, index=np.arange(1, self.max + 1))
+
+
+def padded_doy_table(index, offset=15):
+    """The 366 groups of ``PaddedDOYGrouper`` on ``index`` as one table for the engine: ``order`` = row positions group
+    by group (leap-year rows first inside a group, like the reference's ``pd.concat``), ``offsets[367]``.  Vectorised:
+    no DataFrame is sliced."""
+    idx = pd.DatetimeIndex(index)
+    doy = np.asarray(idx.dayofyear)
+    leap = np.asarray(idx.is_leap_year)
+    rows = np.arange(len(idx))
+    probe = PaddedDOYGrouper(pd.DataFrame({"v": np.zeros(0)}, index=pd.DatetimeIndex([])), offset=offset)
+    order, offsets = [], [0]
+    for n in range(1, 367):
+        days_leap, days_noleap = probe._window(n, 366), probe._window(n, 365)
+        if len(set(days_noleap)) != 2 * offset + 1 and n != 366:
+            raise ValueError("no leap day groups do not contain the correct set of days")  # groupers.py:67-68
+        sel = np.concatenate([rows[leap & np.isin(doy, days_leap)], rows[~leap & np.isin(doy, days_noleap)]])
+        order.append(sel)
+        offsets.append(offsets[-1] + len(sel))
+    return np.concatenate(order).astype(np.int32), np.asarray(offsets, dtype=np.int64)

@@ -38,6 +38,20 @@ def pr_inputs(g):
     return synth.daily_calendar(T), synth.daily_calendar(Tp), X, y, Xp
 
 
+def nasanex_inputs(g, case):
+    """inputs of tests/golden/g13_nasanex.npz (make_golden.py:g13_nasanex): tas and positive pr fields on two calendars"""
+    import pandas as pd
+
+    index = pd.date_range(str(g[f"start{case}"]), str(g[f"end{case}"]))
+    index_p = pd.date_range(str(g[f"pstart{case}"]), str(g[f"pend{case}"]))
+    cells = np.arange(int(g[f"C{case}"]))
+    seed, c_full = 20, 1000
+    tas = tuple(synth.tas_field(n, seed, i, cells, c_full) for n, i in (("X_hist", index), ("y_obs", index), ("X_fut", index_p)))
+    pr = (synth.pr_field("X_hist", seed, len(index), cells, c_full), synth.pr_field("y_obs", seed, len(index), cells, c_full) + 0.25,
+          synth.pr_field("X_fut", seed, len(index_p), cells, c_full))
+    return index, index_p, tas, pr
+
+
 def analog_inputs(g):
     T, Tq, C, F, seed, c_full = (int(g[k]) for k in ("T", "Tq", "C", "F", "seed", "c_full"))
     return synth.analog_fields(seed, T, np.arange(C), c_full, n_query=Tq, n_features=F)

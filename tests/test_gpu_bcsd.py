@@ -332,9 +332,98 @@ def test_estimators_ndarray_input_and_errors():
             BcsdTemperature().fit(X, g["y"])
         with pytest.raises(ValueError, match="Invalid value in target climatology"):
             BcsdPrecipitation().fit(g["P"], np.zeros_like(g["yP"]))
-    with pytest.raises(NotImplementedError):
+    # 100 days leave most day-of-year groups empty: the reference's QuantileMapper.fit refuses an empty group (bcsd.py:66-67)
+    with pytest.raises(ValueError, match="Found array with 0 sample"):
         BcsdTemperature(time_grouper="daily_nasa-nex").fit(pd.DataFrame(g["X"], index=pd.date_range("2000", periods=100)),
                                                          pd.DataFrame(g["y"], index=pd.date_range("2000", periods=100)))
+    with pytest.raises(KeyError):  # a pandas frequency string ends in df.groupby('M') in the reference (bcsd.py:39-41, 49)
+        BcsdTemperature(time_grouper="M").fit(pd.DataFrame(g["X"], index=pd.date_range("2000", periods=100)),
+                                              pd.DataFrame(g["y"], index=pd.date_range("2000", periods=100)))
+
+
+def test_BcsdTemperature_nasanex():
+    """The reference's test (test_pointwise_models.py:315-320) restated: fit with time_grouper='daily_nasa-nex' swaps the
+    grouper class in; plus what the reference's fitted object exposes."""
+    from skdownscale_amd import BcsdTemperature, PaddedDOYGrouper
+
+    rng = np.random.default_rng(0)
+    index = pd.date_range(start="1980-01-01", end="1982-12-31")
+    X = pd.DataFrame({"foo": rng.random(len(index))}, index=index)
+    y = pd.DataFrame({"foo": rng.random(len(index))}, index=index)
+    model_nasanex = BcsdTemperature(time_grouper="daily_nasa-nex", return_anoms=False).fit(X, y)
+    assert issubclass(model_nasanex.time_grouper, PaddedDOYGrouper)
+    assert model_nasanex.timestep == "daily"
+    assert model_nasanex.y_climo_.shape == (366, 1) and list(model_nasanex.y_climo_.index[:3]) == [1, 2, 3]
+    assert len(model_nasanex.quantile_mappers_) == 366
+    assert model_nasanex.quantile_mappers_[366].x_cdf_fit_.cdf_.vals.shape == (89,)
+    assert model_nasanex.predict(X).shape == (len(index), 1)
+
+
+def test_bcsd_daily_nasanex_golden(ctx):
+    """g13_nasanex.npz (from the reference): 366 padded day-of-year groups in fit (bcsd.py:36-38,50-55), predict by
+    day-of-month keys with the 9-sample rolling mean over months (bcsd.py:247-267), the exceptions of return_anoms=True,
+    the monthly model with a day-of-month climate-trend grouper -- estimators, engine and PointWiseDownscaler."""
+    from _cases import nasanex_inputs
+    from skdownscale_amd import BcsdPrecipitation, BcsdTemperature, PointWiseDownscaler
+    from skdownscale_amd.core import GridArray
+    from skdownscale_amd.groupers import DAY_GROUPER, padded_doy_table
+
+    g = load("g13_nasanex")
+    for case in (0, 1):
+        index, index_p, (X, y, Xp), (P, yP, Pp) = nasanex_inputs(g, case)
+        C = X.shape[1]
+        order, offsets = padded_doy_table(index)
+        gq, gt = np.asarray(index_p.day, dtype=np.int32) - 1, np.asarray(index_p.month, dtype=np.int32) - 1
+        # engine, all cells at once
+        st = ctx.bcsd_fit_groups(0, X, y, order, offsets, return_anoms=False)
+        e = st.export()
+        assert e["info"]["T"] == len(order) and np.array_equal(e["group_offsets"], offsets)
+        np.testing.assert_allclose(e["y_climo"].T, g[f"y_climo{case}"], rtol=1e-12)
+        np.testing.assert_allclose(e["x_climo"].T, g[f"x_climo{case}"], rtol=1e-12)
+        for k in (1, 59, 60, 200, 366):
+            assert np.array_equal(e["y_sorted"][:, offsets[k - 1]:offsets[k]].T, g[f"cdf{case}_{k}"])
+        out, status = ctx.bcsd_predict_trend(st, Xp, gq, gt, 12)
+        assert (status == 0).all()
+        assert_close(out, g[f"tas_out{case}"], what=f"daily tas (engine) case {case}")
+        dout, _ = ctx.bcsd_predict_trend(ctx.bcsd_fit_groups(0, ctx.to_device(X), ctx.to_device(y), order, offsets, False),
+                                         ctx.to_device(Xp), gq, gt, 12)
+        assert np.array_equal(dout.to_host(), out)
+        stp = ctx.bcsd_fit_groups(1, P, yP, order, offsets, return_anoms=False)
+        np.testing.assert_allclose(stp.export()["y_climo"].T, g[f"pr_y_climo{case}"], rtol=1e-12)
+        pout, _ = ctx.bcsd_predict(stp, Pp, gq)
+        assert_close(pout, g[f"pr_out{case}"], what=f"daily pr (engine) case {case}")
+        # estimators, one cell
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = BcsdTemperature(time_grouper="daily_nasa-nex", return_anoms=False).fit(pd.DataFrame(X[:, :1], index=index),
+                                                                                       pd.DataFrame(y[:, :1], index=index))
+            assert_close(m.predict(pd.DataFrame(Xp[:, :1], index=index_p)).values[:, 0], g[f"tas_out{case}"][:, 0], what="estimator")
+            np.testing.assert_allclose(m.y_climo_.values[:, 0], g[f"y_climo{case}"][:, 0], rtol=1e-12)
+            assert np.array_equal(m.quantile_mappers_[60].x_cdf_fit_.cdf_.vals, g[f"cdf{case}_60"][:, 0])
+            m = BcsdTemperature(time_grouper="daily_nasa-nex").fit(pd.DataFrame(X[:, :1], index=index), pd.DataFrame(y[:, :1], index=index))
+            with pytest.raises(ValueError) as ei:
+                m.predict(pd.DataFrame(Xp[:, :1], index=index_p))
+            assert str(ei.value) == str(g[f"tas_anoms_error{case}"])
+            mp = BcsdPrecipitation(time_grouper="daily_nasa-nex", return_anoms=False).fit(pd.DataFrame(P[:, :1], index=index),
+                                                                                          pd.DataFrame(yP[:, :1], index=index))
+            assert_close(mp.predict(pd.DataFrame(Pp[:, :1], index=index_p)).values[:, 0], g[f"pr_out{case}"][:, 0], what="pr estimator")
+            mp = BcsdPrecipitation(time_grouper="daily_nasa-nex").fit(pd.DataFrame(P[:, :1], index=index), pd.DataFrame(yP[:, :1], index=index))
+            with pytest.raises(ValueError) as ei:
+                mp.predict(pd.DataFrame(Pp[:, :1], index=index_p))
+            assert str(ei.value) == str(g[f"pr_anoms_error{case}"])
+            mt = BcsdTemperature(climate_trend=DAY_GROUPER).fit(pd.DataFrame(X[:, :1], index=index), pd.DataFrame(y[:, :1], index=index))
+            assert_close(mt.predict(pd.DataFrame(Xp[:, :1], index=index_p)).values[:, 0], g[f"tas_daytrend_out{case}"][:, 0],
+                         what="day-of-month climate trend")
+            # the grid driver batches the same configurations
+            pw = PointWiseDownscaler(BcsdTemperature(time_grouper="daily_nasa-nex", return_anoms=False))
+            pw.fit(GridArray(X, ("time", "point"), {"time": index}), GridArray(y, ("time", "point"), {"time": index}))
+            got = pw.predict(GridArray(Xp, ("time", "point"), {"time": index_p}))
+            assert_close(got.values, g[f"tas_out{case}"], what="PointWiseDownscaler daily")
+            assert isinstance(pw._model.time_grouper, str)  # the prototype is not modified (each cell's copy is, in the reference)
+            pw = PointWiseDownscaler(BcsdTemperature(climate_trend=DAY_GROUPER))
+            pw.fit(GridArray(X, ("time", "point"), {"time": index}), GridArray(y, ("time", "point"), {"time": index}))
+            got = pw.predict(GridArray(Xp, ("time", "point"), {"time": index_p}))
+            assert_close(got.values, g[f"tas_daytrend_out{case}"], what="PointWiseDownscaler day-of-month trend")
 
 
 def test_estimator_pickle_roundtrip():

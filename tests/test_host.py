@@ -71,7 +71,13 @@ def test_unsupported_configurations_raise():
 
     check_supported(BcsdTemperature())
     check_supported(BcsdTemperature(qm_kwargs={"qt_kwargs": {"n_endpoints": 10}}))
-    for bad in (BcsdTemperature(time_grouper="daily_nasa-nex"), BcsdTemperature(qm_kwargs={"detrend": True}),
+    nasanex = BcsdTemperature(time_grouper="daily_nasa-nex")
+    nasanex._pre_fit()  # swaps PaddedDOYGrouper in (bcsd.py:36-38)
+    check_supported(nasanex)
+    from skdownscale_amd.groupers import DAY_GROUPER
+
+    check_supported(BcsdTemperature(climate_trend=DAY_GROUPER))
+    for bad in (BcsdTemperature(time_grouper="M"), BcsdTemperature(qm_kwargs={"detrend": True}),
                 BcsdTemperature(qm_kwargs={"qt_kwargs": {"extrapolate": None}})):
         with pytest.raises(NotImplementedError):
             check_supported(bad)

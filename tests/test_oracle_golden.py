@@ -196,3 +196,32 @@ def test_pure_regression_oracle_matches_golden():
         assert_close(coef, g[f"coef{case}"], rtol=1e-9, what="coef")
         assert abs(icpt - float(g[f"intercept{case}"])) <= 1e-9 * (1 + abs(icpt))
         assert abs(err - float(g[f"fit_error{case}"])) <= 1e-9 * (1 + err) + 1e-12
+
+
+def test_bcsd_daily_nasanex_and_separate_trend_grouper():
+    """g13_nasanex.npz (from the reference): fit on the 366 padded day-of-year groups (bcsd.py:36-38,50-55, groupers.py:19-89),
+    predict by day-of-month keys with the rolling mean over months (bcsd.py:247-267, return_anoms=False), and the monthly
+    model with a day-of-month climate-trend grouper."""
+    from _cases import nasanex_inputs
+
+    g = load("g13_nasanex")
+    for case in (0, 1):
+        index, index_p, (X, y, Xp), (P, yP, Pp) = nasanex_inputs(g, case)
+        table = bo.padded_doy_table(index)
+        gq, gt = np.asarray(index_p.day) - 1, np.asarray(index_p.month) - 1
+        for c in range(X.shape[1]):
+            st, status = bo.bcsd_fit_cell(bo.TAS, X[:, c], y[:, c], None, table=table, return_anoms=False)
+            assert status == 0
+            np.testing.assert_allclose(st["y_climo"], g[f"y_climo{case}"][:, c], rtol=1e-12)
+            np.testing.assert_allclose(st["x_climo"], g[f"x_climo{case}"][:, c], rtol=1e-12)
+            for k in (1, 59, 60, 200, 366):
+                assert np.array_equal(st["ys"][st["off"][k - 1]:st["off"][k]], g[f"cdf{case}_{k}"][:, c])
+            out, _ = bo.bcsd_predict_trend_cell(st, Xp[:, c], gq, gt, return_anoms=False)
+            assert_close(out, g[f"tas_out{case}"][:, c], what=f"daily tas case {case} cell {c}")
+            stm, _ = bo.bcsd_fit_cell(bo.TAS, X[:, c], y[:, c], bo.month_group_id(index))
+            out, _ = bo.bcsd_predict_trend_cell(stm, Xp[:, c], bo.month_group_id(index_p), gq)
+            assert_close(out, g[f"tas_daytrend_out{case}"][:, c], what=f"day-of-month trend case {case} cell {c}")
+            stp, status = bo.bcsd_fit_cell(bo.PR, P[:, c], yP[:, c], None, table=table, return_anoms=False)
+            np.testing.assert_allclose(stp["y_climo"], g[f"pr_y_climo{case}"][:, c], rtol=1e-12)
+            out, _ = bo.bcsd_predict_cell(stp, Pp[:, c], gq, return_anoms=False)
+            assert_close(out, g[f"pr_out{case}"][:, c], what=f"daily pr case {case} cell {c}")
