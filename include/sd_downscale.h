@@ -75,6 +75,7 @@ extern "C" {
 #define SD_EXTRAP_MIN 1      /* lower tail extended */
 #define SD_EXTRAP_MAX 2      /* upper tail extended */
 #define SD_EXTRAP_BOTH 3
+#define SD_EXTRAP_1TO1 4     /* regressors only: samples beyond the fitted X range keep their offset to it (quantile.py:277-310) */
 
 /* synthetic field kinds (sd_synth_fill) */
 #define SD_SYNTH_GAUSS 0
@@ -186,15 +187,16 @@ int sd_analog_state_destroy(sd_analog_state* st);
 
 /* ---- quantile-mapping regressors ----------------------------------------------------------------
  * Replace core.py:86-96 / 137-141 looping QuantileMappingReressor (quantile.py:160-395) or
- * EquidistantCdfMatcher (quantile.py:556-636) per cell, for extrapolate in {None, '1to1'}
- * (one_to_one = 0 / 1).  X, y: [T, C] float64, cells contiguous; the whole series is one segment.
- * model: SD_QM_REGRESSOR / SD_QM_EDCDF_DIFFERENCE / SD_QM_EDCDF_RATIO.  Series up to 19 456 samples. */
+ * EquidistantCdfMatcher (quantile.py:556-636) per cell.  X, y: [T, C] float64, cells contiguous; the whole series is one
+ * segment.  model: SD_QM_REGRESSOR / SD_QM_EDCDF_DIFFERENCE / SD_QM_EDCDF_RATIO.  extrapolate: SD_EXTRAP_NONE (None),
+ * SD_EXTRAP_MIN / MAX / BOTH (synthetic end points at -+1e20 from a least-squares line through the n_endpoints outermost
+ * points, quantile.py:312-387) or SD_EXTRAP_1TO1.  Series up to 19 456 samples. */
 int sd_qm_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int64_t C, sd_qm_state** out);
 int sd_qm_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t ld, int64_t T, int64_t C,
                   sd_qm_state** out);
-int sd_qm_predict(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_one, const double* Xp, int64_t Tp,
+int sd_qm_predict(sd_ctx* ctx, const sd_qm_state* st, int model, int extrapolate, int n_endpoints, const double* Xp, int64_t Tp,
                   double* out, int32_t* cell_status);
-int sd_qm_predict_dev(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_one, const double* Xp_dev,
+int sd_qm_predict_dev(sd_ctx* ctx, const sd_qm_state* st, int model, int extrapolate, int n_endpoints, const double* Xp_dev,
                       int64_t ld, int64_t Tp, double* out_dev, int64_t ld_out, int32_t* cell_status);
 /* CunnaneTransformer.transform / inverse_transform (quantile.py:465-545) on the sorted X of a fitted state
  * (sd_qm_fit accepts y = NULL for this use).  X: [Tp, C]; out: [Tp, C].

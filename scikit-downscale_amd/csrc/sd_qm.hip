@@ -1,15 +1,19 @@
 // Quantile-mapping regressors of the reference (skdownscale/pointwise_models/quantile.py), batched over the cell
-// axis: QuantileMappingReressor (160-395) and EquidistantCdfMatcher (556-636), extrapolate in {None, '1to1'}.
+// axis: QuantileMappingReressor (160-395) and EquidistantCdfMatcher (556-636), every extrapolate mode.
 //
 // fit    : per cell np.sort(X), np.sort(y) (quantile.py:217-218 via 352-356) -> xs[C][T], ys[C][T]
 // predict: QMR  x -> p = interp(x, xs, pp) -> interp(p, pp, ys)                       (quantile.py:247-249, 268-269)
 //          ECM  rank r of x among the new series -> p = pp_m[r] -> interp(p, pp, ys) + (x - interp(p, pp, xs))
 //               (or * x / interp(p, pp, xs))                                          (quantile.py:612-623)
 //          '1to1': samples beyond the fitted X range keep their offset to it          (quantile.py:277-310)
-// pp = Cunnane plotting positions (quantile.py:23-43); the extended CDFs of the reference only duplicate their end
-// points for these two extrapolate modes, which np.interp's clamping makes equivalent to the plain arrays.  The
-// modes 'min' / 'max' / 'both' interpolate across synthetic end points at +-1e20 (a cancellation that leaves
-// ~1e5 of absolute rounding noise in the reference's own outputs): not offered (SD_ERR_UNSUPPORTED upstream).
+// pp = Cunnane plotting positions (quantile.py:23-43).  The reference works on extended CDFs of n + 2 points
+// (quantile.py:312-387).  For extrapolate None / '1to1' the two extra points duplicate the ends, which np.interp's
+// clamping makes equivalent to the plain arrays.  For 'min' / 'max' / 'both' the extra points are synthetic: position
+// -+1e20 and the value of the least-squares line through the n_endpoints outermost (position, value) pairs there
+// (~ -+1e21).  Samples inside the fitted range never touch them (same brackets, same results as None); samples beyond
+// it are interpolated across them with the reference's own formula, slope * (x - xp[j]) + fp[j], an ill-conditioned
+// expression (the 1e20 cancels: ~1e4 of absolute rounding noise in the position, ~1e5 in the result -- in the
+// reference's outputs as well).
 // np.interp arithmetic is spelled out: last xp <= x, exact hit -> fp[j], slope * (x - xp[j]) + fp[j] otherwise.
 #include <algorithm>
 #include <cstdlib>
@@ -181,10 +185,43 @@ constexpr double kAlpha = 0.4, kBeta = 0.4;
 __device__ __forceinline__ double pp_denom(int n) { return ((double)n + 1.0 - kAlpha) - kBeta; }
 __device__ __forceinline__ double pp_at(int i, double denom) { return ((double)(i + 1) - kAlpha) / denom; }
 
-// np.interp(p, pp_grid(n), f[0..n)): the abscissae are the Cunnane positions, so the bracket index is analytic
-__device__ __forceinline__ double interp_on_grid(double p, int n, double denom, const double* __restrict__ f) {
-    if (p <= pp_at(0, denom)) return f[0];  // left clamp / exact hit of the first node
-    if (p >= pp_at(n - 1, denom)) return f[n - 1];
+constexpr double kSyntheticMin = -1e20, kSyntheticMax = 1e20;  // quantile.py:17-18
+// value of the least-squares line through (pp[first + i], f[first + i]), i < e, at position x0: sklearn's
+// LinearRegression().fit(...).predict(x0) = x0 * slope + (mean_y - mean_x * slope) (quantile.py:366-385)
+__device__ inline double ols_value_at(const double* __restrict__ f, int first, int e, double denom, double x0) {
+    double xm = 0.0, ym = 0.0;
+    for (int i = 0; i < e; ++i) {
+        xm += pp_at(first + i, denom);
+        ym += f[first + i];
+    }
+    xm /= (double)e;
+    ym /= (double)e;
+    double sxx = 0.0, sxy = 0.0;
+    for (int i = 0; i < e; ++i) {
+        const double dx = pp_at(first + i, denom) - xm;
+        sxx += dx * dx;
+        sxy += dx * (f[first + i] - ym);
+    }
+    const double slope = sxx > 0.0 ? sxy / sxx : 0.0;
+    return (ym - slope * xm) + slope * x0;
+}
+
+// np.interp(p, pp_grid(n), f[0..n)): the abscissae are the Cunnane positions, so the bracket index is analytic.
+// ext_lo / ext_hi: the grid is preceded / followed by a synthetic node (kSyntheticMin, f_lo) / (kSyntheticMax, f_hi).
+__device__ __forceinline__ double interp_on_grid(double p, int n, double denom, const double* __restrict__ f, bool ext_lo = false,
+                                                 double f_lo = 0.0, bool ext_hi = false, double f_hi = 0.0) {
+    if (p <= pp_at(0, denom)) {  // left clamp / exact hit of the first node
+        if (!ext_lo || p == pp_at(0, denom)) return f[0];
+        if (p <= kSyntheticMin) return f_lo;
+        const double slope = (f[0] - f_lo) / (pp_at(0, denom) - kSyntheticMin);
+        return slope * (p - kSyntheticMin) + f_lo;
+    }
+    if (p >= pp_at(n - 1, denom)) {
+        if (!ext_hi || p == pp_at(n - 1, denom)) return f[n - 1];
+        if (p >= kSyntheticMax) return f_hi;
+        const double slope = (f_hi - f[n - 1]) / (kSyntheticMax - pp_at(n - 1, denom));
+        return slope * (p - pp_at(n - 1, denom)) + f[n - 1];
+    }
     int j = (int)floor(p * denom + kAlpha) - 1;
     j = j < 0 ? 0 : (j > n - 2 ? n - 2 : j);
     while (j > 0 && pp_at(j, denom) > p) --j;      // guard the analytic index by one step either way
@@ -197,7 +234,7 @@ __device__ __forceinline__ double interp_on_grid(double p, int n, double denom, 
 
 // model: 0 QuantileMappingReressor, 1 EquidistantCdfMatcher 'difference', 2 'ratio'.  One workgroup per cell;
 // QMR keeps the cell's sorted fit X in LDS for the value -> position search.
-__global__ void __launch_bounds__(1024) qm_map_kernel(int model, int one_to_one, const double* __restrict__ qc /* [C][Tp] */,
+__global__ void __launch_bounds__(1024) qm_map_kernel(int model, int mode, int n_end, const double* __restrict__ qc /* [C][Tp] */,
                                                       const int32_t* __restrict__ rank /* [C][Tp] or null */,
                                                       const double* __restrict__ xs_all, const double* __restrict__ ys_all,
                                                       int64_t T, int64_t Tp, int64_t C, double* __restrict__ oc /* [C][Tp] */) {
@@ -213,6 +250,11 @@ __global__ void __launch_bounds__(1024) qm_map_kernel(int model, int one_to_one,
             for (int i = tid; i < n; i += nthr) xl[i] = xs[i];
         __syncthreads();
         const double x_min = xs[0], x_max = xs[n - 1], y_min = ys[0], y_max = ys[n - 1];
+        // synthetic end points of the extended CDFs (quantile.py:366-385); every thread computes the same four numbers
+        const bool ext_lo = (mode & SD_EXTRAP_MIN) != 0, ext_hi = (mode & SD_EXTRAP_MAX) != 0, one_to_one = (mode & SD_EXTRAP_1TO1) != 0;
+        const int e = n_end < n ? n_end : n;
+        const double vx_lo = ext_lo ? ols_value_at(xs, 0, e, dn, kSyntheticMin) : 0.0, vy_lo = ext_lo ? ols_value_at(ys, 0, e, dn, kSyntheticMin) : 0.0;
+        const double vx_hi = ext_hi ? ols_value_at(xs, n - e, e, dn, kSyntheticMax) : 0.0, vy_hi = ext_hi ? ols_value_at(ys, n - e, e, dn, kSyntheticMax) : 0.0;
         for (int64_t tq = tid; tq < Tp; tq += nthr) {
             const double x = qc[c * Tp + tq];
             double res;
@@ -220,9 +262,19 @@ __global__ void __launch_bounds__(1024) qm_map_kernel(int model, int one_to_one,
                 // p = np.interp(x, xs, pp): j = last index with xs[j] <= x
                 double p;
                 if (x < x_min) {
-                    p = pp_at(0, dn);
+                    if (ext_lo) {  // bracket (synthetic node, first value); below the synthetic node: left = -inf (quantile.py:245)
+                        const double slope = (pp_at(0, dn) - kSyntheticMin) / (x_min - vx_lo);
+                        p = x < vx_lo ? -__builtin_inf() : slope * (x - vx_lo) + kSyntheticMin;
+                    } else {
+                        p = pp_at(0, dn);
+                    }
                 } else if (x >= x_max) {
-                    p = pp_at(n - 1, dn);
+                    if (ext_hi && x > x_max) {
+                        const double slope = (kSyntheticMax - pp_at(n - 1, dn)) / (vx_hi - x_max);
+                        p = x > vx_hi ? __builtin_inf() : slope * (x - x_max) + pp_at(n - 1, dn);
+                    } else {
+                        p = pp_at(n - 1, dn);
+                    }
                 } else {
                     int pos = -1;  // last index known to hold a value <= x
                     for (int len = n; len > 1;) {
@@ -240,11 +292,11 @@ __global__ void __launch_bounds__(1024) qm_map_kernel(int model, int one_to_one,
                         p = slope * (x - x0) + pp_at(j, dn);
                     }
                 }
-                res = interp_on_grid(p, n, dn, ys);  // quantile.py:268-269
+                res = interp_on_grid(p, n, dn, ys, ext_lo, vy_lo, ext_hi, vy_hi);  // quantile.py:268-269
             } else {
                 const double p = pp_at(rank[c * Tp + tq], dm);  // plotting position of x within the new series
-                const double x_train = interp_on_grid(p, n, dn, xs);  // quantile.py:613
-                const double y_map = interp_on_grid(p, n, dn, ys);
+                const double x_train = interp_on_grid(p, n, dn, xs, ext_lo, vx_lo, ext_hi, vx_hi);  // quantile.py:613
+                const double y_map = interp_on_grid(p, n, dn, ys, ext_lo, vy_lo, ext_hi, vy_hi);
                 res = model == 1 ? y_map + (x - x_train) : y_map * (x / x_train);  // quantile.py:616-623
             }
             if (one_to_one) {  // quantile.py:277-310 (fit X and y have the same length)
@@ -476,9 +528,12 @@ int sd_qm_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int64_t 
     return sd_qm_fit_dev(ctx, dX.as<double>(), y ? dy.as<double>() : nullptr, C, T, C, out);
 }
 
-int sd_qm_predict_dev(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_one, const double* Xp_dev, int64_t ld,
+int sd_qm_predict_dev(sd_ctx* ctx, const sd_qm_state* st, int model, int extrapolate, int n_endpoints, const double* Xp_dev, int64_t ld,
                       int64_t Tp, double* out_dev, int64_t ld_out, int32_t* cell_status) {
     SD_CHECK_ARG(ctx && st && Xp_dev && out_dev, "sd_qm_predict: NULL argument");
+    SD_CHECK_ARG(extrapolate == SD_EXTRAP_1TO1 || (extrapolate >= SD_EXTRAP_NONE && extrapolate <= SD_EXTRAP_BOTH),
+                 "sd_qm_predict: unknown extrapolate code %d", extrapolate);
+    SD_CHECK_ARG(n_endpoints >= 2, "Invalid number of n_endpoints, must be >= 2");
     SD_CHECK_ARG(model >= SD_QM_REGRESSOR && model <= SD_QM_EDCDF_RATIO, "sd_qm_predict: unknown model %d", model);
     SD_CHECK_ARG(st->ys, "sd_qm_predict: the state was fitted without y");
     SD_CHECK_ARG(Tp > 0 && ld >= st->C && ld_out >= st->C, "sd_qm_predict: bad sizes");
@@ -503,7 +558,7 @@ int sd_qm_predict_dev(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qm_map_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(lds_map ? lds_map : 8)));
     const int nb = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * (lds_map > ctx->lds_max / 2 ? 1 : 2));
-    SD_LAUNCH(ctx, "qm_map_kernel", qm_map_kernel, dim3(nb), dim3(1024), lds_map ? lds_map : 8, model, one_to_one,
+    SD_LAUNCH(ctx, "qm_map_kernel", qm_map_kernel, dim3(nb), dim3(1024), lds_map ? lds_map : 8, model, extrapolate, n_endpoints,
               (const double*)qc.p, (const int32_t*)rk.p, (const double*)st->xs, (const double*)st->ys, T, Tp, C, oc.as<double>());
     SD_LAUNCH(ctx, "qm_untranspose_kernel", qm_untranspose_kernel, grid, dim3(256), 0, (const double*)oc.p, Tp, C, out_dev, ld_out,
               (const int32_t*)st->status, (const int32_t*)status_p.p);
@@ -517,7 +572,7 @@ int sd_qm_predict_dev(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_
     return SD_OK;
 }
 
-int sd_qm_predict(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_one, const double* Xp, int64_t Tp, double* out,
+int sd_qm_predict(sd_ctx* ctx, const sd_qm_state* st, int model, int extrapolate, int n_endpoints, const double* Xp, int64_t Tp, double* out,
                   int32_t* cell_status) {
     SD_CHECK_ARG(ctx && st && Xp && out, "sd_qm_predict: NULL argument");
     SD_CHECK_ARG(Tp > 0, "sd_qm_predict: bad sizes");
@@ -527,7 +582,7 @@ int sd_qm_predict(sd_ctx* ctx, const sd_qm_state* st, int model, int one_to_one,
     SD_HIP(dX.alloc(ctx, bytes));
     SD_HIP(dout.alloc(ctx, bytes));
     SD_HIP(hipMemcpyAsync(dX.p, Xp, bytes, hipMemcpyHostToDevice, ctx->stream));
-    SD_TRY(sd_qm_predict_dev(ctx, st, model, one_to_one, dX.as<double>(), st->C, Tp, dout.as<double>(), st->C, cell_status));
+    SD_TRY(sd_qm_predict_dev(ctx, st, model, extrapolate, n_endpoints, dX.as<double>(), st->C, Tp, dout.as<double>(), st->C, cell_status));
     SD_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(hipStreamSynchronize(ctx->stream));
     return SD_OK;

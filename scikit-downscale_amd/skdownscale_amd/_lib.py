@@ -20,7 +20,8 @@ CELL_OK, CELL_MASKED, CELL_NONFINITE, CELL_BAD_CLIMO = 0, 1, 2, 3
 ANALOG_BEST, ANALOG_SAMPLE, ANALOG_WEIGHT, ANALOG_MEAN = 0, 1, 2, 3
 QM_REGRESSOR, QM_EDCDF_DIFFERENCE, QM_EDCDF_RATIO = 0, 1, 2
 CUNNANE_FORWARD, CUNNANE_INVERSE = 0, 1
-EXTRAP_CODES = {None: 0, "1to1": 0, "min": 1, "max": 2, "both": 3}  # SD_EXTRAP_*
+EXTRAP_CODES = {None: 0, "1to1": 0, "min": 1, "max": 2, "both": 3}  # SD_EXTRAP_* (CunnaneTransformer: '1to1' clamps like None)
+QM_EXTRAP_CODES = {None: 0, "min": 1, "max": 2, "both": 3, "1to1": 4}  # regressors (sd_qm_predict)
 SYNTH_GAUSS, SYNTH_PRECIP = 0, 1
 
 _p = C.c_void_p
@@ -81,8 +82,8 @@ SIGNATURES = {
     "sd_linreg_state_destroy": [_p],
     "sd_qm_fit": [_p, _p, _p, _i64, _i64, C.POINTER(_p)],
     "sd_qm_fit_dev": [_p, _p, _p, _i64, _i64, _i64, C.POINTER(_p)],
-    "sd_qm_predict": [_p, _p, _int, _int, _p, _i64, _p, _p],
-    "sd_qm_predict_dev": [_p, _p, _int, _int, _p, _i64, _i64, _p, _i64, _p],
+    "sd_qm_predict": [_p, _p, _int, _int, _int, _p, _i64, _p, _p],
+    "sd_qm_predict_dev": [_p, _p, _int, _int, _int, _p, _i64, _i64, _p, _i64, _p],
     "sd_qm_cunnane": [_p, _p, _int, _int, _int, _p, _i64, _p, _p],
     "sd_qm_cunnane_dev": [_p, _p, _int, _int, _int, _p, _i64, _i64, _p, _i64, _p],
     "sd_qm_state_info": [_p, C.POINTER(_i64), C.POINTER(_i64)],

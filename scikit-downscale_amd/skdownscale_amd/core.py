@@ -239,7 +239,7 @@ class PointWiseDownscaler:
                 raise ValueError(f"Found array with {F} features (shape=({T}, {F})) while a maximum of 1 is required")
             if T < 2 * m.n_endpoints + 1:
                 raise ValueError(f"Found array with {T} sample(s) (shape=({T}, 1)) while a minimum of {2 * m.n_endpoints + 1} is required.")
-            gm = QmGridModel(m._engine_code(), m.extrapolate)
+            gm = QmGridModel(m._engine_code(), m.extrapolate, n_endpoints=m.n_endpoints)
             gm.fit(Xv[:, 0, :], yv)
             gm.status_ = gm.state.export()["status"]
             self._raise_for_status(gm.status_, Xv[:, 0, :], yv)

@@ -393,19 +393,23 @@ class Context:
                                          ptr(status)))
         return out, status
 
-    def qm_predict(self, state, model, Xp, one_to_one=False, out=None):
+    def qm_predict(self, state, model, Xp, extrapolate=None, n_endpoints=10, out=None):
+        """extrapolate: None, 'min', 'max', 'both' or '1to1' (``True`` is accepted for '1to1')."""
+        extrapolate = "1to1" if extrapolate is True else (None if extrapolate is False else extrapolate)
+        if extrapolate not in _lib.QM_EXTRAP_CODES:
+            raise ValueError(f"unknown value for extrapolate: {extrapolate}")
+        code = _lib.QM_EXTRAP_CODES[extrapolate]
         Cc = state.info()["C"]
+        Xp = self._field2("X", Xp, None, Cc)
         status = np.empty(Cc, dtype=np.int32)
+        Tp = Xp.shape[0]
         if isinstance(Xp, DeviceArray):
-            Tp = Xp.shape[0]
             out = self.empty((Tp, Cc)) if out is None else out
-            check(self.lib.sd_qm_predict_dev(self.handle, state.vptr, int(model), int(bool(one_to_one)), Xp.vptr, Xp.ld, Tp,
+            check(self.lib.sd_qm_predict_dev(self.handle, state.vptr, int(model), code, int(n_endpoints), Xp.vptr, Xp.ld, Tp,
                                              out.vptr, out.ld, ptr(status)))
         else:
-            Xp = _lib.as_f64(Xp)
-            Tp = Xp.shape[0]
             out = np.empty((Tp, Cc))
-            check(self.lib.sd_qm_predict(self.handle, state.vptr, int(model), int(bool(one_to_one)), ptr(Xp), Tp, ptr(out),
+            check(self.lib.sd_qm_predict(self.handle, state.vptr, int(model), code, int(n_endpoints), ptr(Xp), Tp, ptr(out),
                                          ptr(status)))
         return out, status
 

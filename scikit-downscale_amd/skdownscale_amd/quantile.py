@@ -1,10 +1,11 @@
 """Quantile-mapping regressors with the reference's surface, computed by the HIP engine.
 
 Mirrors ``skdownscale/pointwise_models/quantile.py``: ``QuantileMappingReressor`` (160-395) and
-``EquidistantCdfMatcher`` (556-636).  The arithmetic runs in ``csrc/sd_qm.hip`` through the C ABI for
-``extrapolate`` in ``{None, '1to1'}``.  ``'min'`` / ``'max'`` / ``'both'`` are refused: the reference evaluates
-``np.interp`` across synthetic end points at +-1e20 there (quantile.py:17-18, 338-346), a cancellation that
-leaves ~1e5 of absolute rounding noise in its own outputs, so no parity can be defined for those samples.
+``EquidistantCdfMatcher`` (556-636), every ``extrapolate`` mode.  The arithmetic runs in ``csrc/sd_qm.hip`` through the
+C ABI.  With ``'min'`` / ``'max'`` / ``'both'`` the reference interpolates samples *beyond the fitted range* across
+synthetic end points at +-1e20 (quantile.py:17-18, 338-346): a cancellation that leaves ~1e5 of absolute rounding noise
+in its own outputs; the engine evaluates the same expression (same noise level, not the same noise).  Samples inside the
+fitted range are unaffected by the mode.
 """
 from __future__ import annotations
 
@@ -38,10 +39,6 @@ def check_max_features(array, n=1):
 def check_extrapolate(extrapolate):
     if extrapolate not in (None, "1to1", "min", "max", "both"):
         raise ValueError(f"unknown value for extrapolate: {extrapolate}")  # quantile.py:348-349
-    if extrapolate in ("min", "max", "both"):
-        raise NotImplementedError(
-            f"extrapolate={extrapolate!r}: interpolation across the synthetic +-1e20 end points is ill-conditioned in the "
-            "reference itself; only extrapolate=None and '1to1' run on the HIP engine")
 
 
 FittedCunnane = collections.namedtuple("FittedCunnane", ["cdf_"])
@@ -232,10 +229,11 @@ class QuantileMapperGridModel:
 class QmGridModel:
     """Batched quantile-mapping regressor over the cell axis: X, y [T, C], Xp [Tp, C] (numpy or DeviceArray)."""
 
-    def __init__(self, model, extrapolate=None, ctx=None):
+    def __init__(self, model, extrapolate=None, ctx=None, n_endpoints=10):
         check_extrapolate(extrapolate)
         self.model = int(model)
-        self.one_to_one = extrapolate == "1to1"
+        self.extrapolate = extrapolate
+        self.n_endpoints = int(n_endpoints)
         self.ctx = ctx or default_context()
         self.state = None
 
@@ -246,7 +244,7 @@ class QmGridModel:
     def predict(self, Xp, out=None):
         if self.state is None:
             raise NotFittedError("This quantile-mapping grid model is not fitted yet.")
-        return self.ctx.qm_predict(self.state, self.model, Xp, self.one_to_one, out=out)
+        return self.ctx.qm_predict(self.state, self.model, Xp, self.extrapolate, self.n_endpoints, out=out)
 
 
 class QuantileMappingReressor(RegressorMixin, BaseEstimator):
@@ -254,8 +252,9 @@ class QuantileMappingReressor(RegressorMixin, BaseEstimator):
 
     Parameters
     ----------
-    extrapolate : {None, '1to1'} (the reference's 'min', 'max', 'both' are refused, see the module docstring)
-    n_endpoints : int, kept for the reference's minimum-sample rule (2 * n_endpoints + 1 samples to fit)
+    extrapolate : {None, 'min', 'max', 'both', '1to1'} -- how the CDFs are extended at the tails
+    n_endpoints : int, points of the least-squares lines behind the synthetic end points of 'min' / 'max' / 'both'
+        (and the reference's minimum-sample rule: 2 * n_endpoints + 1 samples to fit)
     """
 
     _fit_attributes = ["_X_cdf", "_y_cdf"]
@@ -275,18 +274,33 @@ class QuantileMappingReressor(RegressorMixin, BaseEstimator):
         y = check_array(y, dtype="numeric", ensure_min_samples=2 * self.n_endpoints + 1, ensure_2d=False)
         X = check_max_features(X, n=1)
         check_extrapolate(self.extrapolate)
-        self._grid = QmGridModel(self._engine_code(), self.extrapolate)
+        self._grid = QmGridModel(self._engine_code(), self.extrapolate, n_endpoints=self.n_endpoints)
         self._grid.fit(np.asarray(X, dtype=np.float64).reshape(-1, 1), np.asarray(y, dtype=np.float64).reshape(-1, 1))
         e = self._grid.state.export()
         self._X_cdf = self._extended(e["x_sorted"][0])
         self._y_cdf = self._extended(e["y_sorted"][0])
         return self
 
-    @staticmethod
-    def _extended(vals):
-        """quantile.py:312-387 for extrapolate in (None, '1to1'): both end points duplicated."""
+    def _extended(self, vals):
+        """The fitted attribute of quantile.py:312-387: n + 2 (position, value) pairs.  None / '1to1' duplicate the end
+        points; 'min' / 'max' / 'both' put synthetic ones at -+1e20 on the least-squares line through the n_endpoints
+        outermost points (attribute only: predictions compute their own in the kernel)."""
         pp = plotting_positions(len(vals))
-        return Cdf(np.concatenate([pp[:1], pp, pp[-1:]]), np.concatenate([vals[:1], vals, vals[-1:]]))
+        pp = np.concatenate([pp[:1], pp, pp[-1:]])
+        vals = np.concatenate([vals[:1], vals, vals[-1:]])
+
+        def line_at(s, x0):
+            xm, ym = pp[s].mean(), vals[s].mean()
+            slope = np.sum((pp[s] - xm) * (vals[s] - ym)) / np.sum((pp[s] - xm) ** 2)
+            return (ym - slope * xm) + slope * x0
+
+        if self.extrapolate in ("min", "both"):
+            pp[0] = -1e20
+            vals[0] = line_at(slice(1, self.n_endpoints + 1), pp[0])
+        if self.extrapolate in ("max", "both"):
+            pp[-1] = 1e20
+            vals[-1] = line_at(slice(-self.n_endpoints - 1, -1), pp[-1])
+        return Cdf(pp, vals)
 
     def predict(self, X, **kwargs):
         if not hasattr(self, "_X_cdf"):
@@ -294,7 +308,7 @@ class QuantileMappingReressor(RegressorMixin, BaseEstimator):
                 f"This {type(self).__name__} instance is not fitted yet. Call 'fit' with appropriate arguments before using this estimator.")
         X = check_array(X, ensure_2d=True)
         if not hasattr(self, "_grid"):
-            self._grid = QmGridModel(self._engine_code(), self.extrapolate)
+            self._grid = QmGridModel(self._engine_code(), self.extrapolate, n_endpoints=self.n_endpoints)
             n = len(self._X_cdf.vals) - 2
             self._grid.fit(self._X_cdf.vals[1:-1].reshape(n, 1), self._y_cdf.vals[1:-1].reshape(n, 1))
         out, _ = self._grid.predict(np.asarray(X[:, :1], dtype=np.float64))

@@ -22,14 +22,24 @@ def test_bcsd_argument_errors(ctx):
         ctx.bcsd_fit(7, X, y, gid, 12, True)  # unknown kind
     bad = gid.copy()
     bad[5] = 12  # group id out of range
-    with pytest.raises(ValueError, match="sd_downscale"):
+    with pytest.raises(ValueError, match="group ids must lie"):  # the wrapper checks what the C ABI cannot (buffer sizes) and what it can
         ctx.bcsd_fit(0, X, y, bad, 12, True)
+    import ctypes
+
+    h = ctypes.c_void_p()
+    rc = ctx.lib.sd_bcsd_fit(ctx.handle, 0, X.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p),
+                             bad.ctypes.data_as(ctypes.c_void_p), 12, 100, 3, 1, ctypes.byref(h))
+    assert rc == 1 and b"outside" in ctx.lib.sd_last_error()  # ... and so does the C ABI itself
+    with pytest.raises(ValueError, match="expected a \\[100, 3\\] field"):
+        ctx.bcsd_fit(0, X[:50], y, gid, 12, True)
     with pytest.raises(ValueError, match="sd_downscale"):
         ctx.bcsd_fit(0, None, y, gid, 12, True)  # BcsdTemperature needs X
     st = ctx.bcsd_fit(0, X, y, gid, 12, True)
     bad_p = np.full(50, -1, dtype=np.int32)
-    with pytest.raises(ValueError, match="sd_downscale"):
+    with pytest.raises(ValueError, match="group ids must lie"):
         ctx.bcsd_predict(st, rng.standard_normal((50, 3)), bad_p)
+    with pytest.raises(ValueError, match="expected a"):
+        ctx.bcsd_predict(st, rng.standard_normal((50, 4)), gid[:50])
     # a NULL state / context is an argument error, not a crash
     rc = ctx.lib.sd_bcsd_state_info(None, None, None, None, None, None)
     assert rc == 1 and b"NULL" in ctx.lib.sd_last_error() or rc == 1

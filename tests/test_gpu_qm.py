@@ -18,27 +18,58 @@ def ctx():
     return default_context()
 
 
+def noise_floor(X, y, ex, ne):
+    """Absolute rounding noise of the reference's (and the engine's) expression for samples *beyond the fitted range* under
+    extrapolate 'min' / 'max' / 'both': positions and values are interpolated across synthetic nodes at +-1e20 whose values
+    are ~1e20 * (slope of the tail line), so every such result carries a few ulps of the node value.  256 ulps of the
+    largest synthetic y value of the cell; 0 for the other modes."""
+    if ex not in ("min", "max", "both"):
+        return np.zeros(X.shape[1])
+    out = np.zeros(X.shape[1])
+    for c in range(X.shape[1]):
+        (_, vx), (_, vy) = qo.qm_fit(X[:, c], y[:, c], ex, ne)
+        out[c] = 256 * np.finfo(float).eps * max(abs(vy[0]), abs(vy[-1]), abs(vx[0]), abs(vx[-1]))
+    return out
+
+
+def check_against(out, exp, X, Xp, floor, what):
+    """samples inside the fitted X range: the north-star tolerance; beyond it: the noise floor of the expression"""
+    inside = (Xp >= X.min(axis=0)) & (Xp <= X.max(axis=0))
+    for c in range(X.shape[1]):
+        assert_close(out[inside[:, c], c], exp[inside[:, c], c], scale=float(np.std(exp[inside[:, c], c])), what=f"{what} cell {c} (in range)")
+        if floor[c] > 0:
+            o, e = out[~inside[:, c], c], exp[~inside[:, c], c]
+            # (the 'ratio' kind divides cancellation residues: 0/0 and x/0 turn up on either side)
+            both = np.isfinite(o) & np.isfinite(e)
+            err = np.abs(o[both] - e[both])
+            assert (err <= floor[c]).all(), f"{what} cell {c}: beyond the fitted range, max err {err.max():.3e} > noise floor {floor[c]:.3e}"
+        else:
+            assert_close(out[~inside[:, c], c], exp[~inside[:, c], c], scale=float(np.std(exp[:, c])), what=f"{what} cell {c} (beyond the range)")
+
+
 @pytest.mark.parametrize("case", [0, 1, 2])
 @pytest.mark.parametrize("resident", [False, True])
 def test_goldens_from_the_reference(ctx, case, resident):
-    """g9_qm.npz: QuantileMappingReressor / EquidistantCdfMatcher outputs of the real reference, extrapolate None and
-    '1to1', predict series equal / longer and shifted up / shorter and shifted down (n_endpoints does not enter)."""
+    """g9_qm.npz: QuantileMappingReressor / EquidistantCdfMatcher outputs of the real reference for every extrapolate mode
+    and n_endpoints 10 / 2; predict series equal / longer and shifted up / shorter and shifted down."""
     g = load("g9_qm")
     X, y, Xp = g[f"X{case}"], g[f"y{case}"], g[f"Xp{case}"]
     st = ctx.qm_fit(ctx.to_device(X), ctx.to_device(y)) if resident else ctx.qm_fit(X, y)
-    for ex in (None, "1to1"):
-        for name, code in MODELS.items():
-            out, status = ctx.qm_predict(st, code, ctx.to_device(Xp) if resident else Xp, ex == "1to1")
-            out = out.to_host() if resident else out
-            assert (status == 0).all()
-            for ne in (10, 2):
-                assert_close(out, g[f"out{case}_{name}_{ex}_{ne}"], what=f"{name} case {case} extrapolate={ex}")
+    for ex in (None, "1to1", "min", "max", "both"):
+        for ne in (10, 2):
+            floor = noise_floor(X, y, ex, ne)
+            for name, code in MODELS.items():
+                out, status = ctx.qm_predict(st, code, ctx.to_device(Xp) if resident else Xp, ex, ne)
+                out = out.to_host() if resident else out
+                assert (status == 0).all()
+                check_against(out, g[f"out{case}_{name}_{ex}_{ne}"], X, Xp, floor, f"{name} case {case} extrapolate={ex} n_endpoints={ne}")
 
 
 @pytest.mark.parametrize("T,Tp,C", [(21, 21, 1), (365, 400, 5), (3000, 2999, 7), (14600, 14600, 4), (14600, 9000, 3), (5000, 19000, 2)])
 def test_vs_oracle_sizes_and_ties(ctx, T, Tp, C):
     """Every sort width (1 ... 19 samples per thread), ties in fit and predict series (quantized data: the stable
-    (value, index) order defines the ranks of EquidistantCdfMatcher), values outside the fitted range."""
+    (value, index) order defines the ranks of EquidistantCdfMatcher), values outside the fitted range, every
+    extrapolate mode."""
     rng = np.random.default_rng(T + Tp)
     X = np.round(10 + 3 * rng.standard_normal((T, C)), 2)
     y = np.round(12 + 4 * rng.standard_normal((T, C)), 2) + 20.0
@@ -47,12 +78,37 @@ def test_vs_oracle_sizes_and_ties(ctx, T, Tp, C):
     st = ctx.qm_fit(X, y)
     e = st.export()
     assert np.array_equal(e["x_sorted"], np.sort(X, axis=0).T) and np.array_equal(e["y_sorted"], np.sort(y, axis=0).T)
-    for ex in (None, "1to1"):
-        out, _ = ctx.qm_predict(st, 0, Xp, ex == "1to1")
-        assert_close(out, qo.pointwise_qm("qmr", X, y, Xp, ex), what=f"qmr {ex}")
+    ne = 10 if T >= 21 else 2
+    for ex in (None, "1to1", "min", "max", "both"):
+        floor = noise_floor(X, y, ex, ne)
+        out, _ = ctx.qm_predict(st, 0, Xp, ex, ne)
+        check_against(out, qo.pointwise_qm("qmr", X, y, Xp, ex, ne), X, Xp, floor, f"qmr {ex}")
         for kind, code in (("difference", 1), ("ratio", 2)):
-            out, _ = ctx.qm_predict(st, code, Xp, ex == "1to1")
-            assert_close(out, qo.pointwise_qm("ecm", X, y, Xp, ex, kind=kind), what=f"ecm {kind} {ex}")
+            out, _ = ctx.qm_predict(st, code, Xp, ex, ne)
+            check_against(out, qo.pointwise_qm("ecm", X, y, Xp, ex, ne, kind=kind), X, Xp, floor, f"ecm {kind} {ex}")
+
+
+def test_linear_model_quantile_mapping_parametrisations():
+    """The reference's smoke test (test_pointwise_models.py:111-141) for its ten quantile-mapping parametrisations, on the
+    same 365-day sine; beyond the length check the outputs are compared with the oracle (every sample is inside the
+    fitted range here, so all modes are well conditioned)."""
+    import pandas as pd
+
+    from skdownscale_amd import EquidistantCdfMatcher, QuantileMappingReressor
+
+    n = 365
+    index = pd.date_range("2019-01-01", periods=n)
+    X = pd.DataFrame({"foo": np.sin(np.linspace(-10 * np.pi, 10 * np.pi, n)) * 10}, index=index)
+    y = X + 2
+    for ex in (None, "min", "max", "both", "1to1"):
+        for model, name in ((QuantileMappingReressor(extrapolate=ex), "qmr"), (EquidistantCdfMatcher(extrapolate=ex), "ecm")):
+            model.fit(X, y)
+            y_hat = model.predict(X)
+            assert len(y_hat) == len(X)
+            exp = qo.pointwise_qm(name, X.values, y.values, X.values, ex)[:, 0]
+            assert_close(y_hat, exp, what=f"{name} extrapolate={ex}")
+            assert model._X_cdf.pp.shape == (n + 2,) and (model._X_cdf.pp[0] == -1e20) == (ex in ("min", "both"))
+            np.testing.assert_allclose(model._y_cdf.vals, qo.qm_fit(X.values[:, 0], y.values[:, 0], ex, 10)[1][1], rtol=1e-12)
 
 
 def test_masked_and_nonfinite_cells(ctx):
@@ -84,8 +140,8 @@ def test_estimators_reference_surface():
         QuantileMappingReressor(n_endpoints=1)
     with pytest.raises(NotImplementedError):
         EquidistantCdfMatcher(kind="sum")
-    with pytest.raises(NotImplementedError):
-        QuantileMappingReressor(extrapolate="both").fit(np.arange(30.0).reshape(-1, 1), np.arange(30.0))
+    with pytest.raises(ValueError, match="unknown value for extrapolate"):
+        QuantileMappingReressor(extrapolate="sideways").fit(np.arange(30.0).reshape(-1, 1), np.arange(30.0))
     with pytest.raises(ValueError, match="minimum of 21"):
         QuantileMappingReressor().fit(np.arange(10.0).reshape(-1, 1), np.arange(10.0))
     rng = np.random.default_rng(4)

@@ -216,11 +216,8 @@ def test_quantile_mapping_estimators_argument_checks():
         EquidistantCdfMatcher(n_endpoints=0)
     with pytest.raises(NotImplementedError, match="difference or ratio"):
         EquidistantCdfMatcher(kind="sum")
-    for ex in ("min", "max", "both"):
-        with pytest.raises(NotImplementedError, match="ill-conditioned"):
-            check_extrapolate(ex)
-        with pytest.raises(NotImplementedError):
-            QuantileMappingReressor(extrapolate=ex).fit(np.arange(30.0).reshape(-1, 1), np.arange(30.0))
+    for ex in (None, "1to1", "min", "max", "both"):
+        check_extrapolate(ex)
     with pytest.raises(ValueError, match="unknown value for extrapolate"):
         check_extrapolate("sideways")
     with pytest.raises(ValueError, match="minimum of 21"):
