@@ -56,6 +56,8 @@ extern "C" {
 #define SD_CELL_MASKED 1    /* core.py:35-37: first sample of X is NaN -> cell skipped, output NaN */
 #define SD_CELL_NONFINITE 2 /* base.py:18-20: NaN/inf inside an active cell -> ValueError on host */
 #define SD_CELL_BAD_CLIMO 3 /* bcsd.py:140-141: y climatology <= 0 with return_anoms */
+#define SD_CELL_ONE_CLASS 4 /* gard.py:204-212: a thresholded regression met samples of one class only where the reference's
+                             * LogisticRegression.fit raises -> ValueError on host */
 
 /* PureAnalog kinds (gard.py:258-262) */
 #define SD_ANALOG_BEST 0
@@ -178,10 +180,14 @@ int sd_analog_predict(sd_ctx* ctx, const sd_analog_state* st, const double* Xq, 
 int sd_analog_predict_dev(sd_ctx* ctx, const sd_analog_state* st, const double* Xq_dev, int64_t ld, int64_t Tq, int k,
                           int kind, int has_thresh, double thresh, const int32_t* sample_inds_dev, double* out_dev,
                           int64_t ld_out, int64_t* inds_dev, double* dist_dev, int32_t* cell_status);
-int sd_analogreg_predict(sd_ctx* ctx, const sd_analog_state* st, const double* Xq, int64_t Tq, int k, double* out,
-                         int32_t* cell_status);
+/* AnalogRegression.predict (gard.py:152-224).  has_thresh: exceedance_prob from a logistic regression of (analog value >
+ * thresh) on the analogs' features (the reference reports predict_proba(x)[0, 0], the probability of NOT exceeding;
+ * 1.0 when every analog exceeds), linear model and RMSE on the exceeding analogs; a query without any exceeding analog
+ * sets SD_CELL_ONE_CLASS for its cell (the reference raises there). */
+int sd_analogreg_predict(sd_ctx* ctx, const sd_analog_state* st, const double* Xq, int64_t Tq, int k, int has_thresh, double thresh,
+                         double* out, int32_t* cell_status);
 int sd_analogreg_predict_dev(sd_ctx* ctx, const sd_analog_state* st, const double* Xq_dev, int64_t ld, int64_t Tq,
-                             int k, double* out_dev, int64_t ld_out, int32_t* cell_status);
+                             int k, int has_thresh, double thresh, double* out_dev, int64_t ld_out, int32_t* cell_status);
 int sd_analog_state_info(const sd_analog_state* st, int64_t* T, int* F, int64_t* C);
 int sd_analog_state_destroy(sd_analog_state* st);
 
@@ -214,21 +220,29 @@ int sd_qm_state_info(const sd_qm_state* st, int64_t* T, int64_t* C);
 int sd_qm_state_export(const sd_qm_state* st, double* x_sorted, double* y_sorted, int32_t* cell_status);
 int sd_qm_state_destroy(sd_qm_state* st);
 
-/* ---- PureRegression (thresh=None) ------------------------------------------------------------------
- * Replaces core.py:86-96 / 137-141 looping gard.py:414-470: per cell an ordinary least-squares fit of y [T, C] on
+/* ---- PureRegression ----------------------------------------------------------------------------------
+ * Replaces core.py:86-96 / 137-141 looping gard.py:410-470: per cell an ordinary least-squares fit of y [T, C] on
  * X [T, F, C] (centred lstsq like sklearn's LinearRegression, minimum-norm for collinear features) and its RMSE
- * (fit_error_); predict writes out [Tq, 3, C] = pred / 1.0 / fit_error_ (gard.py:254-255 column order). */
-int sd_linreg_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int F, int64_t C, sd_linreg_state** out);
+ * (fit_error_); predict writes out [Tq, 3, C] = pred / exceedance_prob / fit_error_ (gard.py:254-255 column order).
+ * has_thresh (gard.py:416-437): the linear model uses the samples with y > thresh, exceedance_prob =
+ * predict_proba(X)[:, 1] of a logistic regression of (y > thresh) on the features (L2, C = 1: sklearn's defaults); a cell
+ * whose samples all exceed drops its threshold (probability 1), one without any exceeding sample gets SD_CELL_ONE_CLASS. */
+int sd_linreg_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int F, int64_t C, int has_thresh, double thresh,
+                  sd_linreg_state** out);
 int sd_linreg_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t ld, int64_t T, int F, int64_t C,
-                      sd_linreg_state** out);
+                      int has_thresh, double thresh, sd_linreg_state** out);
 int sd_linreg_predict(sd_ctx* ctx, const sd_linreg_state* st, const double* Xq, int64_t Tq, double* out,
                       int32_t* cell_status);
 int sd_linreg_predict_dev(sd_ctx* ctx, const sd_linreg_state* st, const double* Xq_dev, int64_t ld, int64_t Tq,
                           double* out_dev, int64_t ld_out, int32_t* cell_status);
 int sd_linreg_state_info(const sd_linreg_state* st, int64_t* T, int* F, int64_t* C);
-/* coef [F][C], intercept [C], fit_error [C], status [C]; any pointer may be NULL */
-int sd_linreg_state_export(const sd_linreg_state* st, double* coef, double* intercept, double* fit_error,
-                           int32_t* cell_status);
+/* coef [F][C], intercept [C], fit_error [C], logistic [F+1][C] (coefficients, then the intercept; models with a threshold),
+ * thresh_dropped [C], status [C]; any pointer may be NULL */
+int sd_linreg_state_export(const sd_linreg_state* st, double* coef, double* intercept, double* fit_error, double* logistic,
+                           int32_t* thresh_dropped, int32_t* cell_status);
+/* device state from exported numbers (pickling, checkpoint / resume); logistic = thresh_dropped = NULL without a threshold */
+int sd_linreg_state_import(sd_ctx* ctx, int64_t T, int F, int64_t C, const double* coef, const double* intercept, const double* fit_error,
+                           const double* logistic, const int32_t* thresh_dropped, const int32_t* cell_status, sd_linreg_state** out);
 int sd_linreg_state_destroy(sd_linreg_state* st);
 
 #ifdef __cplusplus

@@ -119,6 +119,97 @@ def analog_regression_predict(X, y, Xq, n_analogs):
     return out, inds
 
 
+def logistic_fit(x, t, C=1.0, tol=1e-12, max_iter=100):
+    """sklearn ``LogisticRegression()`` (penalty='l2', C=1.0, fit_intercept=True; gard.py:177, 204-212, 416-420) restated as
+    the exact minimiser of  sum_i [log(1 + exp(z_i)) - t_i z_i] + ||w||^2 / (2 C),  z = x w + b  (the intercept is not
+    penalised).  sklearn runs L-BFGS to gtol 1e-4 on the mean loss, so its coefficients sit within ~1e-3 of this optimum;
+    here: damped Newton to machine precision.  Returns (w [F], b)."""
+    x = np.asarray(x, dtype=np.float64).reshape(len(t), -1)
+    t = np.asarray(t, dtype=np.float64)
+    n, F = x.shape
+    xa = np.column_stack([x, np.ones(n)])
+    th = np.zeros(F + 1)
+    reg = np.r_[np.full(F, 1.0 / C), 0.0]
+
+    def fval(th):
+        z = xa @ th
+        return np.sum(np.logaddexp(0.0, z) - t * z) + 0.5 * np.sum(reg * th * th)
+
+    f = fval(th)
+    for _ in range(max_iter):
+        z = xa @ th
+        sg = 0.5 * (1.0 + np.tanh(0.5 * z))
+        g = xa.T @ (sg - t) + reg * th
+        if np.max(np.abs(g)) <= tol * max(1.0, n):
+            break
+        H = (xa * (sg * (1.0 - sg))[:, None]).T @ xa + np.diag(reg)
+        H[np.diag_indices(F + 1)] += 1e-12
+        d = np.linalg.solve(H, -g)
+        a = 1.0
+        while True:
+            fn = fval(th + a * d)
+            if fn <= f or a < 1e-10:
+                break
+            a *= 0.5
+        th = th + a * d
+        f = fn
+    return th[:F], th[F]
+
+
+def analog_regression_thresh_predict(X, y, Xq, n_analogs, thresh):
+    """gard.py:152-224 with a threshold: per query, logistic regression of (analog value > thresh) on the k_ analogs'
+    features and ``exceedance_prob = predict_proba(x)[0, 0]`` -- the probability of the *first* class, i.e. of NOT
+    exceeding (gard.py:210, as written there); 1.0 when every analog exceeds; the linear model and its RMSE use the
+    exceeding analogs only (gard.py:215-219).  A query whose analogs all stay at or below the threshold makes the
+    reference raise (LogisticRegression needs two classes): reported as ``ValueError`` here too."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    Xq = np.asarray(Xq, dtype=np.float64)
+    k = min(n_analogs, len(X))
+    _, inds = knn(X, Xq, k)
+    out = np.empty((len(Xq), 3))
+    for i in range(len(Xq)):
+        xa, ya = X[inds[i]], y[inds[i]]
+        exc = ya > thresh
+        if exc.all():
+            prob = 1.0
+        elif not exc.any():
+            raise ValueError("This solver needs samples of at least 2 classes in the data, but the data contains only one class: 0")
+        else:
+            w, b = logistic_fit(xa, exc)
+            prob = 1.0 - 1.0 / (1.0 + np.exp(-(Xq[i] @ w + b)))  # P(class 0)
+        xs, ys = xa[exc], ya[exc]
+        xm, ym = xs.mean(axis=0), ys.mean()
+        coef, *_ = np.linalg.lstsq(xs - xm, ys - ym, rcond=None)
+        icpt = ym - xm @ coef
+        out[i] = [Xq[i] @ coef + icpt, prob, np.sqrt(np.mean((ys - (xs @ coef + icpt)) ** 2))]
+    return out, inds
+
+
+def pure_regression_thresh(X, y, Xq, thresh):
+    """PureRegression(thresh).fit(X, y).predict(Xq) (gard.py:410-470): logistic regression of (y > thresh) on X over the
+    whole series, ``exceedance_prob = predict_proba(Xq)[:, 1]``; linear model and fit_error_ on the exceeding samples.  One
+    class only: the reference drops the threshold (warns, gard.py:426-437) and fits the plain linear model on ``exceed_ind``
+    -- all samples, or none (then LinearRegression raises)."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    Xq = np.asarray(Xq, dtype=np.float64)
+    exc = y > thresh
+    if exc.all() or not exc.any():
+        if not exc.any():
+            raise ValueError("Found array with 0 sample(s) (shape=(0, %d)) while a minimum of 1 is required by LinearRegression." % X.shape[1])
+        prob = np.ones(len(Xq))
+    else:
+        w, b = logistic_fit(X, exc)
+        prob = 1.0 / (1.0 + np.exp(-(Xq @ w + b)))
+    xs, ys = X[exc], y[exc]
+    xm, ym = xs.mean(axis=0), ys.mean()
+    coef = np.linalg.lstsq(xs - xm, ys - ym, rcond=None)[0]
+    icpt = ym - xm @ coef
+    err = np.sqrt(np.mean((ys - (xs @ coef + icpt)) ** 2))
+    return np.column_stack([Xq @ coef + icpt, prob, np.full(len(Xq), err)]), coef, icpt, err
+
+
 def pointwise_analog(X, y, Xq, n_analogs, kind, thresh=None, sample_inds=None, regression=False):
     """Grid driver (core.py:69-143): X [T,F,C], y [T,C], Xq [Tq,F,C] -> out [Tq,3,C]."""
     T, F, C = X.shape
@@ -127,7 +218,9 @@ def pointwise_analog(X, y, Xq, n_analogs, kind, thresh=None, sample_inds=None, r
     for c in range(C):
         if np.isnan(X[0, 0, c]):  # core.py:35-37
             continue
-        if regression:
+        if regression and thresh is not None:
+            o, _ = analog_regression_thresh_predict(X[:, :, c], y[:, c], Xq[:, :, c], n_analogs, thresh)
+        elif regression:
             o, _ = analog_regression_predict(X[:, :, c], y[:, c], Xq[:, :, c], n_analogs)
         else:
             o, _, _ = pure_analog_predict(X[:, :, c], y[:, c], Xq[:, :, c], n_analogs, kind, thresh,

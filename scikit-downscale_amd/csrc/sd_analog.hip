@@ -509,6 +509,7 @@ struct PredictArgs {
     int64_t oc_Tq;          // > 0: out is the cell-major staging buffer of a Tq-long query series
     int64_t* inds;          // [Tq,k,ld_out] or null
     double* dist;           // [Tq,k,ld_out] or null
+    int32_t* one_class;     // per-cell status words (predict side): SDI_ONE_CLASS is set here
 };
 
 __device__ __forceinline__ void put_out(const PredictArgs& pa, int64_t tq, int64_t c, double pred, double prob, double err) {
@@ -578,22 +579,25 @@ __device__ void pure_analog_stats(const PredictArgs& pa, int k, int kind, int sa
     *pred = p;
 }
 
-// AnalogRegression for one query (gard.py:194-224, thresh=None): centred normal equations.
-template <typename XV, typename YV>
-__device__ void analog_regression(int k, int F, XV xv /* (i,f) */, YV yv /* (i) */, const double* q, double* pred,
-                                  double* err) {
+// AnalogRegression for one query (gard.py:194-224): centred normal equations over the analogs selected by `use`
+// (all of them without a threshold; those above it otherwise, gard.py:215: ne of them, ne >= 1).
+template <typename XV, typename YV, typename USE>
+__device__ void analog_regression(int k, int F, XV xv /* (i,f) */, YV yv /* (i) */, USE use /* (i) */, int ne, const double* q,
+                                  double* pred, double* err) {
     double xm[kMaxF], A[kMaxF][kMaxF + 1], coef[kMaxF];
     double ym = 0.0;
     for (int f = 0; f < F; ++f) xm[f] = 0.0;
     for (int i = 0; i < k; ++i) {
+        if (!use(i)) continue;
         ym += yv(i);
         for (int f = 0; f < F; ++f) xm[f] += xv(i, f);
     }
-    ym /= (double)k;
-    for (int f = 0; f < F; ++f) xm[f] /= (double)k;
+    ym /= (double)ne;
+    for (int f = 0; f < F; ++f) xm[f] /= (double)ne;
     for (int f = 0; f < F; ++f)
         for (int g = 0; g <= F; ++g) A[f][g] = 0.0;
     for (int i = 0; i < k; ++i) {
+        if (!use(i)) continue;
         const double dy = yv(i) - ym;
         for (int f = 0; f < F; ++f) {
             const double df = xv(i, f) - xm[f];
@@ -610,13 +614,73 @@ __device__ void analog_regression(int k, int F, XV xv /* (i,f) */, YV yv /* (i) 
     for (int f = 0; f < F; ++f) p += q[f] * coef[f];
     double ss = 0.0;
     for (int i = 0; i < k; ++i) {
+        if (!use(i)) continue;
         double yh = icpt;
         for (int f = 0; f < F; ++f) yh += xv(i, f) * coef[f];
         const double d = yv(i) - yh;
         ss += d * d;
     }
     *pred = p;
-    *err = sqrt(ss / (double)k);  // root_mean_squared_error (gard.py:218-219)
+    *err = sqrt(ss / (double)ne);  // root_mean_squared_error (gard.py:218-219)
+}
+
+// LogisticRegression() of sklearn (L2 penalty, C = 1, intercept not penalised; gard.py:177, 204-212) on the k analogs of a
+// query: labels t_i = (y_i > thresh), both classes present.  Exact minimiser of
+//     sum_i [log(1 + exp(z_i)) - t_i z_i] + |w|^2 / 2,   z_i = w . x_i + b
+// by damped Newton steps (Cholesky of the (F+1) x (F+1) Hessian, step halved until the objective does not increase);
+// sklearn stops its L-BFGS at a gradient of 1e-4 of the mean loss, i.e. within ~1e-3 of this optimum.  Returns z(q).
+template <typename XV, typename TV>
+__device__ double logistic_at_query(int k, int F, XV xv /* (i,f) */, TV tv /* (i) -> 0/1 */, const double* q) {
+    const int n = F + 1;
+    double th[kMaxF + 1], g[kMaxF + 1], d[kMaxF + 1], trial[kMaxF + 1], H[kMaxF + 1][kMaxF + 1];
+    for (int a = 0; a < n; ++a) th[a] = 0.0;
+    auto objective = [&](const double* t) {
+        double f = 0.0;
+        for (int i = 0; i < k; ++i) {
+            double z = t[F];
+            for (int a = 0; a < F; ++a) z += t[a] * xv(i, a);
+            f += sdlsq::softplus(z) - (tv(i) ? z : 0.0);
+        }
+        for (int a = 0; a < F; ++a) f += 0.5 * t[a] * t[a];
+        return f;
+    };
+    double f = objective(th);
+    for (int it = 0; it < 60; ++it) {
+        for (int a = 0; a < n; ++a) {
+            g[a] = a < F ? th[a] : 0.0;
+            for (int b = 0; b < n; ++b) H[a][b] = (a == b && a < F) ? 1.0 : 0.0;
+        }
+        for (int i = 0; i < k; ++i) {
+            double z = th[F];
+            for (int a = 0; a < F; ++a) z += th[a] * xv(i, a);
+            const double sg = sdlsq::sigmoid(z), r = sg - (tv(i) ? 1.0 : 0.0), w = sg * (1.0 - sg);
+            for (int a = 0; a < n; ++a) {
+                const double xa = a < F ? xv(i, a) : 1.0;
+                g[a] += r * xa;
+                for (int b = 0; b <= a; ++b) H[a][b] += w * xa * (b < F ? xv(i, b) : 1.0);
+            }
+        }
+        double gmax = 0.0;
+        for (int a = 0; a < n; ++a) gmax = fmax(gmax, fabs(g[a]));
+        if (gmax <= 1e-12 * (double)k) break;
+        for (int a = 0; a < n; ++a) {
+            H[a][a] += 1e-12;
+            g[a] = -g[a];
+        }
+        if (!sdlsq::chol_solve(n, H, g, d)) break;
+        double step = 1.0, fn = f;
+        for (;;) {
+            for (int a = 0; a < n; ++a) trial[a] = th[a] + step * d[a];
+            fn = objective(trial);
+            if (fn <= f || step < 1e-10) break;
+            step *= 0.5;
+        }
+        for (int a = 0; a < n; ++a) th[a] = trial[a];
+        f = fn;
+    }
+    double z = th[F];
+    for (int a = 0; a < F; ++a) z += th[a] * q[a];
+    return z;
 }
 
 // mode 0 = PureAnalog, 1 = AnalogRegression.  Lists in scratch: sd[i*nthr + tid], si[...].
@@ -636,9 +700,23 @@ __device__ void finish_query(int mode, const PredictArgs& pa, int F, int64_t T, 
             pa, k, pa.kind, s < 0 ? 0 : (s >= k ? k - 1 : s), [&](int i) { return yc_cell[si[(int64_t)i * nthr + tid]]; },
             [&](int i) { return sd[(int64_t)i * nthr + tid]; }, &pred, &prob, &err);
     } else {
-        analog_regression(
-            k, F, [&](int i, int f) { return Xc_cell[(int64_t)f * T + si[(int64_t)i * nthr + tid]]; },
-            [&](int i) { return yc_cell[si[(int64_t)i * nthr + tid]]; }, q, &pred, &err);
+        auto xv = [&](int i, int f) { return Xc_cell[(int64_t)f * T + si[(int64_t)i * nthr + tid]]; };
+        auto yv = [&](int i) { return yc_cell[si[(int64_t)i * nthr + tid]]; };
+        if (pa.has_thresh) {  // gard.py:201-219
+            auto exc = [&](int i) { return yv(i) > pa.thresh; };
+            int ne = 0;
+            for (int i = 0; i < k; ++i) ne += exc(i) ? 1 : 0;
+            if (ne == 0) {
+                // every analog at or below the threshold: the reference's LogisticRegression.fit raises (one class only)
+                if (pa.one_class) atomicOr(&pa.one_class[c], SDI_ONE_CLASS);
+                pred = prob = err = nan;
+            } else {
+                if (ne < k) prob = 1.0 - sdlsq::sigmoid(logistic_at_query(k, F, xv, exc, q));  // predict_proba(X)[0, 0] (gard.py:210)
+                analog_regression(k, F, xv, yv, exc, ne, q, &pred, &err);
+            }
+        } else {
+            analog_regression(k, F, xv, yv, [](int) { return true; }, k, q, &pred, &err);
+        }
     }
     put_out(pa, tq, c, pred, prob, err);
     if (cell_active && pa.inds)
@@ -2033,7 +2111,7 @@ __global__ void __launch_bounds__(256) analog_status_public_kernel(const int32_t
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) {
         const int32_t bits = a[c] | (b ? b[c] : 0);
-        outp[c] = (bits & SDI_MASKED) ? SD_CELL_MASKED : (bits & SDI_NONFINITE) ? SD_CELL_NONFINITE : SD_CELL_OK;
+        outp[c] = (bits & SDI_MASKED) ? SD_CELL_MASKED : (bits & SDI_NONFINITE) ? SD_CELL_NONFINITE : (bits & SDI_ONE_CLASS) ? SD_CELL_ONE_CLASS : SD_CELL_OK;
     }
 }
 
@@ -2063,6 +2141,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
     sd_scratch status_p, sc_d, sc_i, status_pub;
     SD_HIP(status_p.alloc(ctx, sizeof(int32_t) * C));
     SD_HIP(hipMemsetAsync(status_p.p, 0, sizeof(int32_t) * C, ctx->stream));
+    pa.one_class = status_p.as<int32_t>();
     const bool f1 = st->xs != nullptr;
     const int nthr = f1 ? 1024 : kBfThreads;
     int nb = ctx->cu_count * (f1 ? 1 : 4);
@@ -2071,8 +2150,9 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
     if ((int64_t)nb > ((C + 7) / 8) * 8) nb = (int)(((C + 7) / 8) * 8);
     SD_HIP(sc_d.alloc(ctx, sizeof(double) * (size_t)nb * k * nthr));
     SD_HIP(sc_i.alloc(ctx, sizeof(int32_t) * (size_t)nb * k * nthr));
+    // (a thresholded regression needs the analogs themselves: logistic fit and subset OLS, gard.py:201-219)
     const bool window = f1 && (mode == 1 || kind != SD_ANALOG_SAMPLE) && !inds && !dist && st->yx != nullptr &&
-                        sd_dev_env("SD_ANALOG_WALK") == nullptr;
+                        !(mode == 1 && has_thresh) && sd_dev_env("SD_ANALOG_WALK") == nullptr;
     if (window) {
         // fewest value ranges such that xs and yx of a range (+ k entries of margin each side) fit the LDS
         int npass = 1;
@@ -2355,14 +2435,14 @@ int sd_analog_predict(sd_ctx* ctx, const sd_analog_state* st, const double* Xq, 
 }
 
 int sd_analogreg_predict_dev(sd_ctx* ctx, const sd_analog_state* st, const double* Xq_dev, int64_t ld, int64_t Tq,
-                             int k, double* out_dev, int64_t ld_out, int32_t* cell_status) {
-    return predict_common(1, ctx, st, Xq_dev, ld, Tq, k, SD_ANALOG_MEAN, 0, 0.0, nullptr, ld, out_dev, ld_out, nullptr,
+                             int k, int has_thresh, double thresh, double* out_dev, int64_t ld_out, int32_t* cell_status) {
+    return predict_common(1, ctx, st, Xq_dev, ld, Tq, k, SD_ANALOG_MEAN, has_thresh ? 1 : 0, thresh, nullptr, ld, out_dev, ld_out, nullptr,
                           nullptr, cell_status);
 }
 
-int sd_analogreg_predict(sd_ctx* ctx, const sd_analog_state* st, const double* Xq, int64_t Tq, int k, double* out,
-                         int32_t* cell_status) {
-    return predict_host(1, ctx, st, Xq, Tq, k, SD_ANALOG_MEAN, 0, 0.0, nullptr, out, nullptr, nullptr, cell_status);
+int sd_analogreg_predict(sd_ctx* ctx, const sd_analog_state* st, const double* Xq, int64_t Tq, int k, int has_thresh, double thresh,
+                         double* out, int32_t* cell_status) {
+    return predict_host(1, ctx, st, Xq, Tq, k, SD_ANALOG_MEAN, has_thresh ? 1 : 0, thresh, nullptr, out, nullptr, nullptr, cell_status);
 }
 
 }  // extern "C"

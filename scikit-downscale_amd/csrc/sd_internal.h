@@ -27,6 +27,7 @@ static inline const char* sd_dev_env(const char*) { return nullptr; }
 #define SDI_MASKED 1
 #define SDI_NONFINITE 2
 #define SDI_BAD_CLIMO 4
+#define SDI_ONE_CLASS 8
 
 struct sd_prof_entry {
     double ms = 0.0;
@@ -167,10 +168,11 @@ struct sd_group_table {
 int sd_build_group_table(const int32_t* gid, int64_t T, int G, sd_group_table* out);
 
 // public status from internal bitmask
-static inline int32_t sd_public_status(int32_t bits) {
+__host__ __device__ static inline int32_t sd_public_status(int32_t bits) {
     if (bits & SDI_MASKED) return SD_CELL_MASKED;
     if (bits & SDI_NONFINITE) return SD_CELL_NONFINITE;
     if (bits & SDI_BAD_CLIMO) return SD_CELL_BAD_CLIMO;
+    if (bits & SDI_ONE_CLASS) return SD_CELL_ONE_CLASS;
     return SD_CELL_OK;
 }
 static inline int32_t sd_internal_status(int32_t code) {
@@ -178,6 +180,7 @@ static inline int32_t sd_internal_status(int32_t code) {
         case SD_CELL_MASKED: return SDI_MASKED;
         case SD_CELL_NONFINITE: return SDI_NONFINITE;
         case SD_CELL_BAD_CLIMO: return SDI_BAD_CLIMO;
+        case SD_CELL_ONE_CLASS: return SDI_ONE_CLASS;
         default: return 0;
     }
 }

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SD_DOWNSCALE_LIB", os.path.join(os.path.dirname(_HERE
 
 SD_OK = 0
 BCSD_TAS, BCSD_PR = 0, 1
-CELL_OK, CELL_MASKED, CELL_NONFINITE, CELL_BAD_CLIMO = 0, 1, 2, 3
+CELL_OK, CELL_MASKED, CELL_NONFINITE, CELL_BAD_CLIMO, CELL_ONE_CLASS = 0, 1, 2, 3, 4
 ANALOG_BEST, ANALOG_SAMPLE, ANALOG_WEIGHT, ANALOG_MEAN = 0, 1, 2, 3
 QM_REGRESSOR, QM_EDCDF_DIFFERENCE, QM_EDCDF_RATIO = 0, 1, 2
 CUNNANE_FORWARD, CUNNANE_INVERSE = 0, 1
@@ -69,16 +69,17 @@ SIGNATURES = {
     "sd_analog_fit_dev": [_p, _p, _p, _i64, _i64, _int, _i64, C.POINTER(_p)],
     "sd_analog_predict": [_p, _p, _p, _i64, _int, _int, _int, _dbl, _p, _p, _p, _p, _p],
     "sd_analog_predict_dev": [_p, _p, _p, _i64, _i64, _int, _int, _int, _dbl, _p, _p, _i64, _p, _p, _p],
-    "sd_analogreg_predict": [_p, _p, _p, _i64, _int, _p, _p],
-    "sd_analogreg_predict_dev": [_p, _p, _p, _i64, _i64, _int, _p, _i64, _p],
+    "sd_analogreg_predict": [_p, _p, _p, _i64, _int, _int, _dbl, _p, _p],
+    "sd_analogreg_predict_dev": [_p, _p, _p, _i64, _i64, _int, _int, _dbl, _p, _i64, _p],
     "sd_analog_state_info": [_p, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_i64)],
     "sd_analog_state_destroy": [_p],
-    "sd_linreg_fit": [_p, _p, _p, _i64, _int, _i64, C.POINTER(_p)],
-    "sd_linreg_fit_dev": [_p, _p, _p, _i64, _i64, _int, _i64, C.POINTER(_p)],
+    "sd_linreg_fit": [_p, _p, _p, _i64, _int, _i64, _int, _dbl, C.POINTER(_p)],
+    "sd_linreg_fit_dev": [_p, _p, _p, _i64, _i64, _int, _i64, _int, _dbl, C.POINTER(_p)],
     "sd_linreg_predict": [_p, _p, _p, _i64, _p, _p],
     "sd_linreg_predict_dev": [_p, _p, _p, _i64, _i64, _p, _i64, _p],
     "sd_linreg_state_info": [_p, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_i64)],
-    "sd_linreg_state_export": [_p, _p, _p, _p, _p],
+    "sd_linreg_state_export": [_p, _p, _p, _p, _p, _p, _p],
+    "sd_linreg_state_import": [_p, _i64, _int, _i64, _p, _p, _p, _p, _p, _p, C.POINTER(_p)],
     "sd_linreg_state_destroy": [_p],
     "sd_qm_fit": [_p, _p, _p, _i64, _i64, C.POINTER(_p)],
     "sd_qm_fit_dev": [_p, _p, _p, _i64, _i64, _i64, C.POINTER(_p)],

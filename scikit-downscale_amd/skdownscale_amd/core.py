@@ -166,8 +166,12 @@ class PointWiseDownscaler:
             check_supported(self._bcsd_proto)
             return "bcsd"
         if isinstance(m, (PureAnalog, AnalogRegression)):
-            if isinstance(m, AnalogRegression) and (m.thresh is not None or m.lr_kwargs):
-                raise NotImplementedError("AnalogRegression(thresh=... / lr_kwargs) is not supported on the HIP engine")
+            if isinstance(m, AnalogRegression):
+                m._check()
+            else:
+                from .gard import check_tree_kwargs
+
+                check_tree_kwargs(m)
             return "analog"
         if isinstance(m, PureRegression):
             m._check()
@@ -244,8 +248,19 @@ class PointWiseDownscaler:
             gm.status_ = gm.state.export()["status"]
             self._raise_for_status(gm.status_, Xv[:, 0, :], yv)
         else:
-            gm = RegressionGridModel().fit(Xv, yv) if kind == "linreg" else AnalogGridModel(m.n_analogs).fit(Xv, yv)
+            gm = RegressionGridModel(thresh=m.thresh).fit(Xv, yv) if kind == "linreg" else AnalogGridModel(m.n_analogs).fit(Xv, yv)
             gm.status_ = np.where(mask, 0, _lib.CELL_MASKED).astype(np.int32)
+            if kind == "linreg" and m.thresh is not None:
+                e = gm.export()
+                live_one_class = mask & (e["status"] == _lib.CELL_ONE_CLASS)
+                if (mask & (e["thresh_dropped"] | (e["status"] == _lib.CELL_ONE_CLASS))).any():  # gard.py:426-437, per cell
+                    import warnings
+
+                    warnings.warn("Found only one class while attempting logistic regression. Mutating attribute thresh")
+                if live_one_class.any():  # the linear model of such a cell gets an empty sample (gard.py:439)
+                    from .gard import NO_SAMPLES_MESSAGE
+
+                    raise ValueError(NO_SAMPLES_MESSAGE.format(F=F))
             bad = mask & ~(np.isfinite(Xv).all(axis=(0, 1)) & np.isfinite(yv).all(axis=0))
             if bad.any():
                 c = int(np.flatnonzero(bad)[0])
@@ -332,11 +347,15 @@ class PointWiseDownscaler:
             if mdl.kind == "linreg":
                 out, status = mdl.grid_model.predict(Xv)
             elif isinstance(m, AnalogRegression):
-                out, status = mdl.grid_model.predict_regression(Xv)
+                out, status = mdl.grid_model.predict_regression(Xv, m.thresh)
             else:
                 out, status = mdl.grid_model.predict_pure(Xv, m.kind, m.thresh)
             if (status == _lib.CELL_NONFINITE).any():
                 raise ValueError("Input X contains NaN.")
+            if (status == _lib.CELL_ONE_CLASS).any():  # a query without any analog above the threshold (gard.py:204-207)
+                from .gard import ONE_CLASS_MESSAGE
+
+                raise ValueError(ONE_CLASS_MESSAGE)
             vals = out.reshape((T, 3) + tuple(spatial_shape)).astype(Xg.dtype, copy=False)
             coords[feature_dim] = np.array(output_names)
             res = GridArray(vals, (self._dim, feature_dim) + spatial_dims, coords)

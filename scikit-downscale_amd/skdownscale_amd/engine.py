@@ -130,11 +130,18 @@ class LinregState(_State):
         return dict(T=T.value, F=F.value, C=Cc.value)
 
     def export(self):
+        """coef [F, C], intercept [C], fit_error [C], status [C]; with a threshold also logistic_coef [F, C],
+        logistic_intercept [C] and thresh_dropped [C] (cells whose samples all exceed: probability 1, gard.py:426-437)"""
         i = self.info()
         coef, icpt, err = np.empty((i["F"], i["C"])), np.empty(i["C"]), np.empty(i["C"])
+        logit = np.full((i["F"] + 1, i["C"]), np.nan)
+        dropped = np.full(i["C"], -1, dtype=np.int32)
         status = np.empty(i["C"], dtype=np.int32)
-        check(self.ctx.lib.sd_linreg_state_export(self.vptr, ptr(coef), ptr(icpt), ptr(err), ptr(status)))
-        return dict(coef=coef, intercept=icpt, fit_error=err, status=status)
+        check(self.ctx.lib.sd_linreg_state_export(self.vptr, ptr(coef), ptr(icpt), ptr(err), ptr(logit), ptr(dropped), ptr(status)))
+        out = dict(coef=coef, intercept=icpt, fit_error=err, status=status, T=i["T"])
+        if (dropped >= 0).all():  # a model with a threshold
+            out.update(logistic_coef=logit[:-1], logistic_intercept=logit[-1], thresh_dropped=dropped.astype(bool))
+        return out
 
 
 class QmState(_State):
@@ -453,37 +460,66 @@ class Context:
                                              ptr(inds), ptr(dist), ptr(status)))
         return (out, status, inds, dist) if want_neighbors else (out, status)
 
-    def analogreg_predict(self, state, Xq, k, out=None):
-        Cc = state.info()["C"]
-        status = np.empty(Cc, dtype=np.int32)
-        if isinstance(Xq, DeviceArray):
-            Tq = Xq.shape[0]
-            out = self.empty((Tq, 3, Cc)) if out is None else out
-            check(self.lib.sd_analogreg_predict_dev(self.handle, state.vptr, Xq.vptr, Xq.ld, Tq, k, out.vptr, out.ld, ptr(status)))
-        else:
+    def analogreg_predict(self, state, Xq, k, thresh=None, out=None):
+        """AnalogRegression.predict for every cell; ``thresh``: exceedance probability by logistic regression on the analogs
+        (gard.py:201-212), linear model on the exceeding analogs."""
+        info = state.info()
+        Cc = info["C"]
+        if not isinstance(Xq, DeviceArray):
             Xq = _lib.as_f64(Xq)
-            Tq = Xq.shape[0]
+        if len(Xq.shape) != 3 or Xq.shape[1] != info["F"] or Xq.shape[2] != Cc:
+            raise ValueError(f"Xq: expected a [Tq, {info['F']}, {Cc}] field, got shape {tuple(Xq.shape)}")
+        status = np.empty(Cc, dtype=np.int32)
+        has, thr = (0, 0.0) if thresh is None else (1, float(thresh))
+        Tq = Xq.shape[0]
+        if isinstance(Xq, DeviceArray):
+            out = self.empty((Tq, 3, Cc)) if out is None else out
+            check(self.lib.sd_analogreg_predict_dev(self.handle, state.vptr, Xq.vptr, Xq.ld, Tq, int(k), has, thr, out.vptr, out.ld,
+                                                    ptr(status)))
+        else:
             out = np.empty((Tq, 3, Cc))
-            check(self.lib.sd_analogreg_predict(self.handle, state.vptr, ptr(Xq), Tq, k, ptr(out), ptr(status)))
+            check(self.lib.sd_analogreg_predict(self.handle, state.vptr, ptr(Xq), Tq, int(k), has, thr, ptr(out), ptr(status)))
         return out, status
 
-
     # ---- PureRegression (thresh=None) ----
-    def linreg_fit(self, X, y):
-        """X [T,F,C], y [T,C] numpy or DeviceArray -> LinregState (coefficients, intercept, fit error per cell)."""
-        h = C.c_void_p()
-        if isinstance(X, DeviceArray):
-            T, F, Cc = X.shape
-            assert X.ld == y.ld
-            check(self.lib.sd_linreg_fit_dev(self.handle, X.vptr, y.vptr, y.ld, T, F, Cc, C.byref(h)))
-        else:
+    def linreg_fit(self, X, y, thresh=None):
+        """X [T,F,C], y [T,C] numpy or DeviceArray -> LinregState (coefficients, intercept, fit error per cell; with ``thresh``
+        also the logistic model of the exceedance probability, gard.py:416-437)."""
+        if not isinstance(X, DeviceArray):
             X, y = _lib.as_f64(X), _lib.as_f64(y)
-            T, F, Cc = X.shape
-            check(self.lib.sd_linreg_fit(self.handle, ptr(X), ptr(y), T, F, Cc, C.byref(h)))
+        if len(X.shape) != 3 or tuple(y.shape) != (X.shape[0], X.shape[2]) or isinstance(X, DeviceArray) != isinstance(y, DeviceArray):
+            raise ValueError(f"expected X [T, F, C] and y [T, C] of the same kind, got {tuple(X.shape)} and {tuple(y.shape)}")
+        has, thr = (0, 0.0) if thresh is None else (1, float(thresh))
+        h = C.c_void_p()
+        T, F, Cc = X.shape
+        if isinstance(X, DeviceArray):
+            assert X.ld == y.ld
+            check(self.lib.sd_linreg_fit_dev(self.handle, X.vptr, y.vptr, y.ld, T, F, Cc, has, thr, C.byref(h)))
+        else:
+            check(self.lib.sd_linreg_fit(self.handle, ptr(X), ptr(y), T, F, Cc, has, thr, C.byref(h)))
+        return LinregState(self, h.value, self.lib.sd_linreg_state_destroy)
+
+    def linreg_import(self, exported):
+        """device state from ``LinregState.export()`` (pickling, checkpoint / resume)"""
+        coef = _lib.as_f64(exported["coef"])
+        F, Cc = coef.shape
+        logit = dropped = None
+        if "logistic_coef" in exported:
+            logit = _lib.as_f64(np.vstack([exported["logistic_coef"], np.asarray(exported["logistic_intercept"]).reshape(1, Cc)]))
+            dropped = _lib.as_i32(exported["thresh_dropped"])
+        h = C.c_void_p()
+        check(self.lib.sd_linreg_state_import(self.handle, int(exported["T"]), F, Cc, ptr(coef), ptr(_lib.as_f64(exported["intercept"])),
+                                              ptr(_lib.as_f64(exported["fit_error"])), ptr(logit), ptr(dropped),
+                                              ptr(_lib.as_i32(exported["status"])), C.byref(h)))
         return LinregState(self, h.value, self.lib.sd_linreg_state_destroy)
 
     def linreg_predict(self, state, Xq, out=None):
-        Cc = state.info()["C"]
+        info = state.info()
+        Cc = info["C"]
+        if not isinstance(Xq, DeviceArray):
+            Xq = _lib.as_f64(Xq)
+        if len(Xq.shape) != 3 or Xq.shape[1] != info["F"] or Xq.shape[2] != Cc:
+            raise ValueError(f"Xq: expected a [Tq, {info['F']}, {Cc}] field, got shape {tuple(Xq.shape)}")
         status = np.empty(Cc, dtype=np.int32)
         if isinstance(Xq, DeviceArray):
             Tq = Xq.shape[0]

@@ -1,7 +1,7 @@
 """GARD analog estimators with the reference's surface, computed by the HIP engine.
 
 Mirrors ``skdownscale/pointwise_models/gard.py``: ``AnalogBase`` (55-98), ``AnalogRegression``
-(101-224, ``thresh=None`` only), ``PureAnalog`` (227-364) and ``PureRegression`` (367-504, ``thresh=None`` only).  The KD-tree of the reference is
+(101-224), ``PureAnalog`` (227-364) and ``PureRegression`` (367-504), with and without ``thresh``.  The KD-tree of the reference is
 replaced by batched exact nearest-neighbour search in ``csrc/sd_analog.hip`` (neighbours ordered by
 (squared distance, training index); identical to ``KDTree.query`` on tie-free data).
 """
@@ -54,8 +54,29 @@ class AnalogGridModel:
             sample_inds = np.stack([np.random.randint(low=0, high=k, size=Tq) for _ in range(C)], axis=1)
         return self.ctx.analog_predict(self.state, Xq, k, KIND_CODES[kind], thresh, sample_inds, want_neighbors, out=out)
 
-    def predict_regression(self, Xq, out=None):
-        return self.ctx.analogreg_predict(self.state, Xq, self.k_, out=out)
+    def predict_regression(self, Xq, thresh=None, out=None):
+        return self.ctx.analogreg_predict(self.state, Xq, self.k_, thresh, out=out)
+
+
+ONE_CLASS_MESSAGE = ("This solver needs samples of at least 2 classes in the data, but the data contains only one class: "
+                     "np.int8(0)")  # sklearn's LogisticRegression.fit on the labels of gard.py:204-207
+
+
+def check_tree_kwargs(model):
+    """kdtree_kwargs / query_kwargs (gard.py:82, 194, 299) that would change the neighbours are refused: the engine searches
+    exactly, Euclidean; performance-only options of the KD-tree are ignored."""
+    harmless = {"leaf_size", "dualtree", "breadth_first", "sort_results"}
+    for name in ("kdtree_kwargs", "query_kwargs"):
+        kw = getattr(model, name, None) or {}
+        for k, v in kw.items():
+            if k == "metric" and v in ("euclidean", "minkowski", "l2"):
+                continue
+            if k == "p" and v == 2:
+                continue
+            if k == "sort_results" and not v:
+                raise NotImplementedError(f"{name}={{'sort_results': False}}: the engine returns neighbours in distance order")
+            if k not in harmless:
+                raise NotImplementedError(f"{name}={{{k!r}: {v!r}}} is not supported on the HIP engine (exact Euclidean search)")
 
 
 def _as_2d(X, name="X"):
@@ -85,6 +106,7 @@ class AnalogBase(RegressorMixin, BaseEstimator):
         if len(X2) != len(y1):
             raise ValueError(f"Found input variables with inconsistent numbers of samples: [{len(X2)}, {len(y1)}]")
         self.n_features_in_ = X2.shape[1]
+        check_tree_kwargs(self)
         grid = AnalogGridModel(self.n_analogs)
         grid.fit(X2[:, :, None], y1[:, None])
         self._grid = grid
@@ -121,8 +143,10 @@ class AnalogBase(RegressorMixin, BaseEstimator):
 
 
 class AnalogRegression(AnalogBase):
-    """AnalogRegression (gard.py:101-224).  ``thresh`` (per-step logistic regression) is outside the
-    engine's hot path and raises NotImplementedError."""
+    """AnalogRegression (gard.py:101-224): per query, a linear regression on its ``n_analogs`` nearest training samples.
+    With ``thresh`` the exceedance probability comes from a logistic regression on the same analogs (the exact minimiser of
+    sklearn's default L2-penalised objective; sklearn's own L-BFGS stops within ~1e-3 of it) and the linear model uses the
+    analogs above the threshold."""
 
     def __init__(self, n_analogs=200, thresh=None, kdtree_kwargs=None, query_kwargs=None, logistic_kwargs=None,
                  lr_kwargs=None):
@@ -133,14 +157,19 @@ class AnalogRegression(AnalogBase):
         self.logistic_kwargs = logistic_kwargs
         self.lr_kwargs = lr_kwargs
 
-    def predict(self, X):
-        X2 = self._query(X)
-        if self.thresh is not None:
-            raise NotImplementedError("AnalogRegression(thresh=...) (per-step LogisticRegression, gard.py:206-212) is "
-                                      "not supported on the HIP engine")
+    def _check(self):
         if self.lr_kwargs:
             raise NotImplementedError("lr_kwargs are not supported on the HIP engine (plain OLS with intercept)")
-        out, _ = self._grid.predict_regression(X2[:, :, None])
+        if self.logistic_kwargs:
+            raise NotImplementedError("logistic_kwargs are not supported on the HIP engine (LogisticRegression defaults: L2, C=1)")
+        check_tree_kwargs(self)
+
+    def predict(self, X):
+        X2 = self._query(X)
+        self._check()
+        out, status = self._grid.predict_regression(X2[:, :, None], self.thresh)
+        if status[0] == _lib.CELL_ONE_CLASS:
+            raise ValueError(ONE_CLASS_MESSAGE)
         out = out[:, :, 0]
         return pd.DataFrame(out, columns=self.output_names) if isinstance(X, pd.DataFrame) else out
 
@@ -172,14 +201,15 @@ class PureAnalog(AnalogBase):
 
 
 class RegressionGridModel:
-    """Batched PureRegression(thresh=None) over the cell axis: X [T,F,C], y [T,C], Xq [Tq,F,C] (numpy or DeviceArray)."""
+    """Batched PureRegression over the cell axis: X [T,F,C], y [T,C], Xq [Tq,F,C] (numpy or DeviceArray)."""
 
-    def __init__(self, ctx=None):
+    def __init__(self, ctx=None, thresh=None):
         self.ctx = ctx or default_context()
+        self.thresh = thresh
         self.state = None
 
     def fit(self, X, y):
-        self.state = self.ctx.linreg_fit(X, y)
+        self.state = self.ctx.linreg_fit(X, y, self.thresh)
         return self
 
     def predict(self, Xq, out=None):
@@ -192,20 +222,31 @@ class RegressionGridModel:
 
 
 class _FittedLinearModel:
-    """``linear_model_`` stand-in: the attributes of the fitted sklearn LinearRegression (gard.py:439)."""
+    """``linear_model_`` stand-in: the numbers of the fitted sklearn LinearRegression (gard.py:439)."""
 
     def __init__(self, coef, intercept):
         self.coef_ = coef
         self.intercept_ = intercept
 
-    def predict(self, X):
-        return _as_2d(X, "X") @ self.coef_ + self.intercept_
+
+class _FittedLogisticModel:
+    """``logistic_model_`` stand-in: the numbers of the fitted sklearn LogisticRegression (gard.py:420)."""
+
+    def __init__(self, coef, intercept):
+        self.coef_ = np.asarray(coef, dtype=np.float64).reshape(1, -1)
+        self.intercept_ = np.asarray([intercept], dtype=np.float64)
+        self.classes_ = np.array([0, 1], dtype=np.int8)
+
+
+NO_SAMPLES_MESSAGE = "Found array with 0 sample(s) (shape=(0, {F})) while a minimum of 1 is required by LinearRegression."
 
 
 class PureRegression(RegressorMixin, BaseEstimator):
-    """PureRegression (gard.py:367-504) with ``thresh=None``: ordinary least squares of y on the features, the RMSE of the
-    fit as prediction error, exceedance probability 1.  ``thresh`` (a LogisticRegression for the exceedance probability,
-    lbfgs) and non-default ``linear_kwargs`` are outside the engine's path and raise NotImplementedError."""
+    """PureRegression (gard.py:367-504): ordinary least squares of y on the features, the RMSE of the fit as prediction
+    error.  With ``thresh``: the exceedance probability from a logistic regression of ``y > thresh`` on the features (the
+    exact minimiser of sklearn's default L2-penalised objective; sklearn's own L-BFGS stops within ~1e-3 of it), the
+    linear model on the exceeding samples; one class only: the threshold is dropped with the reference's warning.
+    ``logistic_kwargs`` / ``linear_kwargs`` other than the defaults raise NotImplementedError."""
 
     _fit_attributes = ["logistic_model_", "linear_model_", "fit_error_"]
     n_outputs = 3
@@ -217,11 +258,17 @@ class PureRegression(RegressorMixin, BaseEstimator):
         self.linear_kwargs = linear_kwargs
 
     def _check(self):
-        if self.thresh is not None:
-            raise NotImplementedError("PureRegression(thresh=...) (LogisticRegression, gard.py:416-420) is not supported on "
-                                      "the HIP engine")
         if self.linear_kwargs:
             raise NotImplementedError("linear_kwargs are not supported on the HIP engine (plain OLS with intercept)")
+        if self.logistic_kwargs:
+            raise NotImplementedError("logistic_kwargs are not supported on the HIP engine (LogisticRegression defaults: L2, C=1)")
+
+    def _adopt(self, e, c):
+        """fitted attributes of cell ``c`` of an exported state (gard.py:420-443)"""
+        self.linear_model_ = _FittedLinearModel(e["coef"][:, c].copy(), float(e["intercept"][c]))
+        self.fit_error_ = float(e["fit_error"][c])
+        if "logistic_coef" in e and not e["thresh_dropped"][c]:
+            self.logistic_model_ = _FittedLogisticModel(e["logistic_coef"][:, c], float(e["logistic_intercept"][c]))
 
     def fit(self, X, y):
         self._check()
@@ -234,10 +281,18 @@ class PureRegression(RegressorMixin, BaseEstimator):
         if len(X2) != len(y1):
             raise ValueError(f"Found input variables with inconsistent numbers of samples: [{len(X2)}, {len(y1)}]")
         self.n_features_in_ = X2.shape[1]
-        self._grid = RegressionGridModel().fit(X2[:, :, None], y1[:, None])
+        self._grid = RegressionGridModel(thresh=self.thresh).fit(X2[:, :, None], y1[:, None])
         e = self._grid.export()
-        self.linear_model_ = _FittedLinearModel(e["coef"][:, 0].copy(), float(e["intercept"][0]))
-        self.fit_error_ = float(e["fit_error"][0])
+        self._n_fit = len(X2)
+        if self.thresh is not None:
+            if e["status"][0] == _lib.CELL_ONE_CLASS:  # no sample above the threshold: the linear model gets an empty set
+                warnings.warn("Found only one class while attempting logistic regression. Mutating attribute thresh")
+                self.thresh = None
+                raise ValueError(NO_SAMPLES_MESSAGE.format(F=X2.shape[1]))
+            if e["thresh_dropped"][0]:  # every sample above it (gard.py:426-437)
+                warnings.warn("Found only one class while attempting logistic regression. Mutating attribute thresh")
+                self.thresh = None
+        self._adopt(e, 0)
         return self
 
     def predict(self, X):
@@ -249,12 +304,16 @@ class PureRegression(RegressorMixin, BaseEstimator):
         if X2.shape[1] != self.n_features_in_:
             raise ValueError(f"X has {X2.shape[1]} features, but {type(self).__name__} is expecting "
                              f"{self.n_features_in_} features as input.")
-        if getattr(self, "_grid", None) is None:  # unpickled: the fitted numbers are enough
-            pred = self.linear_model_.predict(X2)
-            out = np.column_stack([pred, np.ones(len(X2)), np.full(len(X2), self.fit_error_)])
-        else:
-            out, _ = self._grid.predict(X2[:, :, None])
-            out = out[:, :, 0]
+        if getattr(self, "_grid", None) is None:  # unpickled: the device state is rebuilt from the fitted numbers
+            e = dict(coef=self.linear_model_.coef_.reshape(-1, 1), intercept=np.array([self.linear_model_.intercept_]),
+                     fit_error=np.array([self.fit_error_]), status=np.zeros(1, np.int32), T=getattr(self, "_n_fit", 1))
+            if self.thresh is not None:
+                e.update(logistic_coef=self.logistic_model_.coef_.reshape(-1, 1), logistic_intercept=self.logistic_model_.intercept_,
+                         thresh_dropped=np.zeros(1, np.int32))
+            self._grid = RegressionGridModel(thresh=self.thresh)
+            self._grid.state = self._grid.ctx.linreg_import(e)
+        out, _ = self._grid.predict(X2[:, :, None])
+        out = out[:, :, 0]
         return pd.DataFrame(out, columns=self.output_names) if isinstance(X, pd.DataFrame) else out  # gard.py:467-489
 
     def __getstate__(self):

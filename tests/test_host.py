@@ -172,8 +172,8 @@ def test_pure_regression_argument_checks():
     assert clone(m).get_params() == dict(thresh=None, logistic_kwargs=None, linear_kwargs=None)
     assert m.n_outputs == 3 and m.output_names == ["pred", "exceedance_prob", "prediction_error"]
     X, y = np.arange(10.0).reshape(-1, 1), np.arange(10.0)
-    with pytest.raises(NotImplementedError, match="thresh"):
-        PureRegression(thresh=1.0).fit(X, y)
+    with pytest.raises(NotImplementedError, match="logistic_kwargs"):
+        PureRegression(thresh=1.0, logistic_kwargs={"C": 10.0}).fit(X, y)
     with pytest.raises(NotImplementedError, match="linear_kwargs"):
         PureRegression(linear_kwargs={"fit_intercept": False}).fit(X, y)
     with pytest.raises(NotFittedError):

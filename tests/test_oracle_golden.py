@@ -225,3 +225,33 @@ def test_bcsd_daily_nasanex_and_separate_trend_grouper():
             np.testing.assert_allclose(stp["y_climo"], g[f"pr_y_climo{case}"][:, c], rtol=1e-12)
             out, _ = bo.bcsd_predict_cell(stp, Pp[:, c], gq, return_anoms=False)
             assert_close(out, g[f"pr_out{case}"][:, c], what=f"daily pr case {case} cell {c}")
+
+
+PROB_TIGHT = 1e-6    # exceedance probability vs the reference's objective solved tightly (logistic_kwargs tol=1e-12)
+PROB_DEFAULT = 1e-3  # ... vs the reference's default LogisticRegression: its L-BFGS stops at tol=1e-4, within ~2e-4 of the optimum
+
+
+def test_thresholded_regressions():
+    """g14_thresholded_regressions.npz (from the reference): AnalogRegression(thresh) (gard.py:201-219), PureRegression(thresh)
+    (gard.py:416-470) incl. the cell that drops its threshold, and PureRegression on features of very different scales."""
+    g = load("g14_thresholded_regressions")
+    for case in (0, 1):
+        X, y, Xq = g[f"ar_X{case}"], g[f"ar_y{case}"], g[f"ar_Xq{case}"]
+        out = ao.pointwise_analog(X, y, Xq, int(g[f"ar_k{case}"]), None, thresh=float(g[f"ar_thresh{case}"]), regression=True)
+        for name, tol in (("tight", PROB_TIGHT), ("default", PROB_DEFAULT)):
+            exp = g[f"ar_out{case}_{name}"]
+            assert_close(out[:, 0], exp[:, 0], what=f"analog regression pred case {case}")
+            assert_close(out[:, 2], exp[:, 2], what=f"analog regression error case {case}")
+            assert np.abs(out[:, 1] - exp[:, 1]).max() <= tol, (case, name)
+    for case in (0, 1):
+        X, y, Xq, thresh = g[f"pr_X{case}"], g[f"pr_y{case}"], g[f"pr_Xq{case}"], float(g[f"pr_thresh{case}"])
+        for c in range(X.shape[2]):
+            out = ao.pure_regression_thresh(X[:, :, c], y[:, c], Xq[:, :, c], thresh)[0]
+            for name, tol in (("tight", PROB_TIGHT), ("default", PROB_DEFAULT)):
+                exp = g[f"pr_out{case}_{name}"][:, :, c]
+                assert_close(out[:, [0, 2]], exp[:, [0, 2]], what=f"pure regression case {case} cell {c}")
+                assert np.abs(out[:, 1] - exp[:, 1]).max() <= tol, (case, c, name)
+            assert bool(g[f"pr_dropped{case}"][c]) == bool((y[:, c] > thresh).all())
+    out, coef, icpt, _ = ao.pure_regression(g["ms_X"], g["ms_y"], g["ms_Xq"])
+    assert_close(out, g["ms_out"], what="mixed-scale features")
+    np.testing.assert_allclose(coef, g["ms_coef"], rtol=1e-9)
