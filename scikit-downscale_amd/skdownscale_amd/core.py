@@ -48,6 +48,36 @@ class GridArray:
     def sizes(self):
         return dict(zip(self.dims, self.values.shape))
 
+    # chunk structure like a dask-backed xarray object: PointWiseDownscaler walks the spatial blocks (core.py:256-262,
+    # 300-336: xr.map_blocks); the values themselves stay plain NumPy
+    chunksizes = None
+
+    @property
+    def chunks(self):
+        return None if self.chunksizes is None else tuple(self.chunksizes[d] for d in self.dims)
+
+    def chunk(self, chunks):
+        """``chunks``: dim -> block length (or -1 for one block), like ``xarray.DataArray.chunk``"""
+        g = GridArray(self.values, self.dims, self.coords, self.name)
+        cs = {}
+        for d, n in self.sizes.items():
+            b = chunks.get(d, -1) if chunks else -1
+            b = n if b in (-1, None) or b >= n else int(b)
+            cs[d] = tuple([b] * (n // b) + ([n % b] if n % b else [])) if n else (0,)
+        g.chunksizes = cs
+        return g
+
+    def isel(self, **indexers):
+        """positional selection by slices along named dims (coords follow)"""
+        key = tuple(indexers.get(d, slice(None)) for d in self.dims)
+        coords = {}
+        for k, v in self.coords.items():
+            if k in indexers and np.ndim(v) == 1 and len(v) == self.sizes.get(k, -1):
+                coords[k] = v[indexers[k]]
+            else:
+                coords[k] = v
+        return GridArray(self.values[key], self.dims, coords, self.name)
+
     def transpose(self, *dims):
         if Ellipsis in dims:
             i = dims.index(Ellipsis)
@@ -62,6 +92,18 @@ class GridArray:
 
 class GridDataset(dict):
     """Ordered mapping name -> GridArray (stand-in for xarray.Dataset)."""
+
+    @property
+    def chunksizes(self):
+        first = next(iter(self.values()), None)
+        return None if first is None else first.chunksizes
+
+    @property
+    def chunks(self):
+        return self.chunksizes
+
+    def chunk(self, chunks):
+        return GridDataset({k: v.chunk(chunks) for k, v in self.items()})
 
 
 def _is_xarray(obj):
@@ -100,6 +142,17 @@ def _from_grid(g, as_xarray):
     return xr.DataArray(g.values, dims=g.dims, coords=coords)
 
 
+def _unchunked(obj):
+    """a block handed to a child model: plain (loaded) data without chunk structure"""
+    if isinstance(obj, GridDataset):
+        return GridDataset({k: _unchunked(v) for k, v in obj.items()})
+    if isinstance(obj, GridArray):
+        return GridArray(obj.values, obj.dims, obj.coords, obj.name)
+    if _is_xarray(obj):
+        return obj.compute() if getattr(obj, "chunks", None) else obj
+    return obj
+
+
 def _time_index(g, dim):
     """core.py:52-64: pandas index of the time coordinate (RangeIndex when absent)."""
     if dim in g.coords:
@@ -122,6 +175,41 @@ class _BatchedModels:
         self.spatial_dims = spatial_dims
         self.spatial_shape = spatial_shape
         self.coords = coords
+
+
+class _BlockedModels:
+    """Fitted state of a chunked grid: one fitted PointWiseDownscaler per spatial block (the reference maps
+    ``_fit_wrapper`` over the blocks of a dask-backed input, core.py:256-262; the engine then batches the cells of a block)."""
+
+    kind = "blocks"
+
+    def __init__(self, spatial_dims, spatial_shape, chunksizes, blocks):
+        self.spatial_dims = tuple(spatial_dims)
+        self.spatial_shape = tuple(spatial_shape)
+        self.chunksizes = chunksizes  # dim -> tuple of block lengths
+        self.blocks = blocks          # list of ({dim: slice}, fitted child)
+
+    @property
+    def sizes(self):
+        return dict(zip(self.spatial_dims, self.spatial_shape))
+
+
+def _block_slices(dims, chunksizes):
+    """all blocks of a chunked grid as {dim: slice} dicts, last dim fastest"""
+    import itertools
+
+    per_dim = []
+    for d in dims:
+        edges = np.concatenate([[0], np.cumsum(chunksizes[d])]).astype(int)
+        per_dim.append([slice(int(a), int(b)) for a, b in zip(edges[:-1], edges[1:])])
+    return [dict(zip(dims, combo)) for combo in itertools.product(*per_dim)]
+
+
+def _isel(obj, sel):
+    """positional block selection on GridArray / GridDataset / xarray objects, ignoring dims the object does not have"""
+    if isinstance(obj, GridDataset):
+        return GridDataset({k: _isel(v, sel) for k, v in obj.items()})
+    return obj.isel(**{d: s for d, s in sel.items() if d in obj.dims})
 
 
 class PointWiseDownscaler:
@@ -155,6 +243,55 @@ class PointWiseDownscaler:
             coords[feature_dim] = np.array([f"{feature_dim}_0"])
             g = GridArray(vals, dims, coords, g.name)
         return g.transpose(self._dim, feature_dim, ...), was_x
+
+    def _spatial_chunks(self, X, feature_dim):
+        """(spatial dims, sizes, dim -> block lengths) of a chunked input, else None.  Time and feature dims are always taken
+        whole (the reference needs them in one chunk: core.py:435-437 and the ``time: -1`` of its examples)."""
+        if not getattr(X, "chunks", None):
+            return None
+        cs = X.chunksizes
+        probe = X[list(X)[0]] if isinstance(X, GridDataset) else X
+        if _is_xarray(X) and not hasattr(X, "dims"):
+            return None
+        dims = [d for d in probe.dims if d not in (self._dim, feature_dim)]
+        sizes = dict(probe.sizes)
+        chunksizes = {d: tuple(int(b) for b in cs[d]) if d in cs else (int(sizes[d]),) for d in dims}
+        if all(len(chunksizes[d]) == 1 for d in dims):
+            return None
+        return dims, sizes, chunksizes
+
+    def _apply_blocks(self, method, X, kwargs):
+        """predict / transform / inverse_transform of a block-fitted grid: every block through its own fitted child, results
+        assembled along the spatial dims (core.py:300-336 maps ``_predict_wrapper`` over the blocks)."""
+        mdl = self._models
+        was_x = _is_xarray(X)
+        out = None
+        for sel, child in mdl.blocks:
+            res = getattr(child, method)(_unchunked(_isel(X, sel)), **kwargs)
+            rg, _ = _to_grid(res, kwargs.get("feature_dim", DEFAULT_FEATURE_DIM))
+            if out is None:
+                sizes = dict(rg.sizes)
+                sizes.update(mdl.sizes)
+                full = np.full([sizes[d] for d in rg.dims], np.nan, dtype=rg.dtype)
+                coords = {k: v for k, v in rg.coords.items() if k not in mdl.spatial_dims}
+                probe = X[list(X)[0]] if isinstance(X, GridDataset) else X
+                out = (full, rg.dims, coords, {} if was_x else dict(getattr(probe, "coords", {})))
+            out[0][tuple(sel.get(d, slice(None)) for d in out[1])] = rg.values
+        full, out_dims, coords, xg_coords = out
+        if was_x:
+            import xarray as xr
+
+            xc = {k: v for k, v in X.coords.items() if set(v.dims) <= set(out_dims)}
+            xc.update({k: ((k,), v) for k, v in coords.items() if k in out_dims and k not in xc})
+            res = xr.DataArray(full, dims=out_dims, coords=xc)
+            try:  # like the reference's map_blocks result: same spatial chunk structure (needs dask)
+                return res.chunk({d: mdl.chunksizes[d] for d in mdl.spatial_dims})
+            except Exception:  # noqa: BLE001
+                return res
+        for k in mdl.spatial_dims:
+            if k in xg_coords:
+                coords[k] = xg_coords[k]
+        return GridArray(full, out_dims, coords).chunk({d: mdl.chunksizes[d][0] for d in mdl.spatial_dims})
 
     def _batched(self):
         m = self._model
@@ -195,6 +332,16 @@ class PointWiseDownscaler:
         if len(args) > 1:
             raise ValueError(f"Expected at most 1 positional argument, got {len(args)}")
         feature_dim = kws["feature_dim"]
+        blocks = self._spatial_chunks(X, feature_dim)
+        if blocks is not None:  # chunked input (dask-backed xarray, GridArray.chunk): block by block (core.py:256-262)
+            dims, sizes, chunksizes = blocks
+            fitted = []
+            for sel in _block_slices(dims, chunksizes):
+                child = PointWiseDownscaler(copy.deepcopy(self._model), self._dim)
+                child.fit(_unchunked(_isel(X, sel)), *[_unchunked(_isel(a, sel)) for a in args], **kwargs)
+                fitted.append((sel, child))
+            self._models = _BlockedModels(dims, [sizes[d] for d in dims], chunksizes, fitted)
+            return
         Xg, _ = self._to_feature_x(X, feature_dim)
         yg = None
         spatial_dims, spatial_shape = Xg.dims[2:], Xg.shape[2:]
@@ -319,6 +466,8 @@ class PointWiseDownscaler:
         """Predict for every fitted cell (core.py:266-338); masked cells stay NaN."""
         if self._models is None:
             raise ValueError("PointWiseDownscaler is not fitted: call fit() first")
+        if isinstance(self._models, _BlockedModels):
+            return self._apply_blocks("predict", X, kwargs)
         kws = {"along_dim": self._dim, "feature_dim": DEFAULT_FEATURE_DIM} | kwargs
         feature_dim = kws["feature_dim"]
         Xg, was_x = self._to_feature_x(X, feature_dim)
@@ -394,6 +543,8 @@ class PointWiseDownscaler:
         """core.py:146-171 (``_transform_wrapper``): same dims / shape as the feature-normalised X, masked cells NaN."""
         if self._models is None:
             raise ValueError("PointWiseDownscaler is not fitted: call fit() first")
+        if isinstance(self._models, _BlockedModels):
+            return self._apply_blocks(direction, X, kwargs)
         kind = self._models.kind
         if kind not in ("loop", "cunnane", "qmapper") or (kind == "qmapper" and direction != "transform"):
             raise AttributeError(f"{type(self._model).__name__} has no {direction}()")
@@ -428,26 +579,123 @@ class PointWiseDownscaler:
         return _from_grid(GridArray(out.reshape(Xg.shape), Xg.dims, dict(Xg.coords)), was_x)
 
     # ------------------------------------------------------------------------------------------
+    def _cell_model(self, c, cache):
+        """The fitted estimator of cell ``c`` of an engine-batched grid, rebuilt from the exported state: what the
+        reference keeps per cell in its object array (core.py:81-96)."""
+        mdl = self._models
+        if mdl.kind == "loop":
+            return mdl.grid_model[c]
+        if not mdl.mask[c]:
+            return None
+        m = self._model
+        if mdl.kind == "bcsd":
+            e = cache.setdefault("e", mdl.grid_model.export())
+            est = copy.deepcopy(self._bcsd_proto)
+            est._adopt(e, c)
+            est.n_features_in_ = 1
+            return est
+        if mdl.kind == "linreg":
+            e = cache.setdefault("e", mdl.grid_model.export())
+            est = copy.deepcopy(m)
+            est.n_features_in_ = e["coef"].shape[0]
+            if est.thresh is not None and e["thresh_dropped"][c]:
+                est.thresh = None  # gard.py:437
+            est._adopt(e, c)
+            return est
+        if mdl.kind == "analog":
+            est = copy.deepcopy(m)
+            est.k_ = mdl.grid_model.k_
+            est.n_features_in_ = mdl.grid_model.state.info()["F"]
+            return est
+        if mdl.kind == "qm":
+            e = cache.setdefault("e", mdl.grid_model.state.export())
+            est = copy.deepcopy(m)
+            est._X_cdf = est._extended(e["x_sorted"][c])
+            est._y_cdf = est._extended(e["y_sorted"][c])
+            est.n_features_in_ = 1
+            return est
+        if mdl.kind == "cunnane":
+            from .quantile import Cdf, plotting_positions
+
+            e = cache.setdefault("e", mdl.grid_model.state.export(with_y=False))
+            est = copy.deepcopy(m)
+            est.cdf_ = Cdf(plotting_positions(e["x_sorted"].shape[1]), e["x_sorted"][c])
+            est.n_features_in_ = 1
+            return est
+        if mdl.kind == "qmapper":
+            from .quantile import Cdf, FittedCunnane, plotting_positions
+
+            e = cache.setdefault("e", mdl.grid_model.state.export())
+            est = copy.deepcopy(m)
+            vals = e["y_sorted"][c]
+            est.x_cdf_fit_ = FittedCunnane(Cdf(plotting_positions(len(vals)), vals))
+            est.n_features_in_ = 1
+            return est
+        raise NotImplementedError(f"get_attr is not available for {mdl.kind} grids")
+
     def get_attr(self, key, dtype=np.float64, template_output=None):
-        """Fitted attribute of every cell (core.py:405-425).  Batched BCSD grids serve ``y_climo_`` /
-        ``_x_climo`` as [group, *spatial] fields straight from the engine state."""
+        """Get attribute values specified in ``key`` from each of the pointwise models (core.py:405-425, 174-197): an array
+        shaped like the model grid, or like ``template_output`` (whose non-spatial dims receive array-valued attributes).
+        Engine-batched grids rebuild the per-cell fitted attributes from the exported state.  Extension: without a template,
+        the BCSD climatologies ``y_climo_`` / ``_x_climo`` come back as [group, *spatial] fields."""
         mdl = self._models
         if mdl is None:
             raise ValueError("PointWiseDownscaler is not fitted: call fit() first")
-        if mdl.kind == "bcsd" and key in ("y_climo_", "_x_climo"):
+        if isinstance(mdl, _BlockedModels):
+            return self._get_attr_blocks(key, dtype, template_output)
+        if mdl.kind == "bcsd" and key in ("y_climo_", "_x_climo") and template_output is None:
             e = mdl.grid_model.export()
             a = e["y_climo" if key == "y_climo_" else "x_climo"].T.astype(dtype)  # [G, C]
             a = np.where(mdl.mask[None, :], a, np.nan)
             coords = dict(mdl.coords)
             coords["group"] = e["keys"]
             return GridArray(a.reshape((a.shape[0],) + tuple(mdl.spatial_shape)), ("group",) + tuple(mdl.spatial_dims), coords)
-        if mdl.kind == "loop":
-            vals = np.full(len(mdl.grid_model), np.nan, dtype=dtype)
-            for c, m in enumerate(mdl.grid_model):
-                if m is not None:
-                    vals[c] = getattr(m, key)
-            return GridArray(vals.reshape(tuple(mdl.spatial_shape)), tuple(mdl.spatial_dims), dict(mdl.coords))
-        raise NotImplementedError(f"get_attr({key!r}) is not available for engine-batched {mdl.kind} grids")
+        sp_dims, sp_shape = tuple(mdl.spatial_dims), tuple(mdl.spatial_shape)
+        was_x = False
+        if template_output is None:
+            dims, shape, coords = sp_dims, sp_shape, dict(mdl.coords)
+        else:
+            if _is_xarray(template_output):
+                import xarray as xr
+
+                was_x = True
+                if isinstance(template_output, xr.Dataset):  # core.py:184-186
+                    template_output = template_output[list(template_output.data_vars)[0]]
+            elif isinstance(template_output, GridDataset):
+                template_output = template_output[list(template_output)[0]]
+            tg, _ = _to_grid(template_output, DEFAULT_FEATURE_DIM)
+            dims, shape, coords = tg.dims, tg.shape, dict(tg.coords)
+            if not set(sp_dims) <= set(dims):
+                raise ValueError(f"template_output dims {dims} do not contain the model grid's dims {sp_dims}")
+        other = tuple(d for d in dims if d not in sp_dims)
+        C = int(np.prod(sp_shape, dtype=np.int64)) if sp_shape else 1
+        sizes = dict(zip(dims, shape))
+        with np.errstate(invalid="ignore"):
+            flat = np.full(tuple(sizes[d] for d in other) + (C,), np.nan, dtype=dtype)  # core.py:191
+        cache = {}
+        for c in range(C):
+            est = self._cell_model(c, cache)
+            if est is None:
+                continue
+            flat[..., c] = np.asarray(getattr(est, key)).reshape(flat.shape[:-1])  # core.py:194-196
+        full = flat.reshape(tuple(sizes[d] for d in other) + sp_shape)
+        g = GridArray(full, other + sp_dims, coords).transpose(*dims)
+        return _from_grid(g, was_x)
+
+    def _get_attr_blocks(self, key, dtype, template_output):
+        mdl = self._models
+        out = None
+        for sel, child in mdl.blocks:
+            tmpl = None if template_output is None else _unchunked(_isel(template_output, sel))
+            res, _ = _to_grid(child.get_attr(key, dtype, tmpl), DEFAULT_FEATURE_DIM)
+            if out is None:
+                sizes = dict(res.sizes)
+                sizes.update(mdl.sizes)
+                with np.errstate(invalid="ignore"):
+                    full = np.full([sizes[d] for d in res.dims], np.nan, dtype=dtype)
+                out = (full, res.dims, {k: v for k, v in res.coords.items() if k not in mdl.spatial_dims})
+            out[0][tuple(sel.get(d, slice(None)) for d in out[1])] = res.values
+        return _from_grid(GridArray(*out), template_output is not None and _is_xarray(template_output))
 
     def __repr__(self):
         summary = [f"<skdownscale.{self.__class__.__name__}>", f"  Fit Status: {self._models is not None}",

@@ -255,3 +255,88 @@ def test_pointwise_transform_and_inverse_transform_loop():
     assert np.allclose(back.values[:, 0][:, ok], X[:, ok])
     with pytest.raises(ValueError, match="not fitted"):
         PointWiseDownscaler(StandardScaler()).transform(GridArray(X, ("time", "y", "x")))
+
+
+def _runner_inputs(shape, n_vars, rng):
+    """test/__init__.py:35-53 (random_point_data / random_grid_data) as GridArray / GridDataset"""
+    from skdownscale_amd.core import GridArray, GridDataset
+
+    dims = ("time", "point") if len(shape) == 1 else ("time", "y", "x")
+    times = pd.date_range("2000-01-01", periods=100)
+    ds = GridDataset()
+    for i in range(n_vars):
+        ds[chr(ord("a") + i)] = GridArray(rng.random((100,) + shape), dims, {"time": times})
+    return ds
+
+
+@pytest.mark.parametrize("shape,chunks", [((3,), None), ((2, 3), None), ((3,), {"point": 1}), ((2, 3), {"y": 1, "x": 1}), ((4, 5), {"y": 3, "x": 2})])
+def test_pointwise_runner_restated(shape, chunks):
+    """The reference's grid-driver tests (test_pointwise_runner.py:13-145) on GridArray / GridDataset with a scikit-learn
+    pipeline (the per-cell loop of core.py:69-143), unchunked and chunked: chunked inputs are fitted and predicted block by
+    block (core.py:256-262, 300-336) and give the same numbers and the same chunk structure."""
+    from sklearn.linear_model import LinearRegression
+    from sklearn.pipeline import Pipeline
+    from sklearn.preprocessing import StandardScaler
+
+    from skdownscale_amd import PointWiseDownscaler
+    from skdownscale_amd.core import GridArray, GridDataset, _BlockedModels
+
+    rng = np.random.default_rng(len(shape))
+    X, y = _runner_inputs(shape, 3, rng), _runner_inputs(shape, 1, rng)["a"]
+    pipe = lambda: Pipeline([("scaler", StandardScaler()), ("lr", LinearRegression())])  # noqa: E731
+    ref_model = PointWiseDownscaler(pipe())
+    ref_model.fit(X, y)
+    expected = ref_model.predict(X)
+    if chunks:
+        X, y = X.chunk(chunks), y.chunk(chunks)
+    model = PointWiseDownscaler(pipe())
+    model.fit(X, y)
+    assert isinstance(model._models, _BlockedModels) == bool(chunks)
+    y_pred = model.predict(X)
+    assert isinstance(y_pred, GridArray) and y_pred.sizes == y.sizes  # test_pointwise_runner.py:48-52
+    np.testing.assert_allclose(y_pred.values, expected.values, rtol=1e-12)
+    if chunks:
+        assert y_pred.chunks == y.chunks  # test_pointwise_runner.py:54-63
+    # transform (test_pointwise_runner.py:66-90) and attributes (93-145)
+    scaler = PointWiseDownscaler(StandardScaler())
+    scaler.fit(X)
+    xt = scaler.transform(X)
+    assert xt.sizes["variable"] == 3 and {d: xt.sizes[d] for d in y.dims} == y.sizes
+    np.testing.assert_allclose(scaler.inverse_transform(xt).values[:, 0], X["a"].values, rtol=1e-9)
+    attrs = scaler.get_attr("n_features_in_", "int64")
+    assert attrs.sizes == {d: y.sizes[d] for d in y.dims[1:]} and attrs.dtype == np.dtype("int64") and (attrs.values == 3).all()
+    template = GridArray(np.zeros((3,) + shape), ("var",) + y.dims[1:], {"var": np.arange(3)})
+    scale = scaler.get_attr("scale_", dtype="float64", template_output=template)
+    assert scale.sizes == template.sizes and scale.dtype == np.dtype("float64")
+    np.testing.assert_allclose(scale.values[0], X["a"].values.std(axis=0), rtol=1e-9)
+
+
+def test_pointwise_runner_xarray():
+    """The same through xarray objects, numpy- and dask-backed (test_pointwise_runner.py:13-63) -- runs where xarray is
+    installed."""
+    xr = pytest.importorskip("xarray")
+    from sklearn.linear_model import LinearRegression
+    from sklearn.pipeline import Pipeline
+    from sklearn.preprocessing import StandardScaler
+
+    from skdownscale_amd import PointWiseDownscaler
+
+    rng = np.random.default_rng(0)
+    times = pd.date_range("2000-01-01", periods=100)
+    ds = xr.Dataset({k: (("time", "y", "x"), rng.random((100, 2, 3))) for k in "abc"}, coords={"time": times})
+    y = xr.DataArray(rng.random((100, 2, 3)), dims=("time", "y", "x"), coords={"time": times})
+    model = PointWiseDownscaler(Pipeline([("scaler", StandardScaler()), ("lr", LinearRegression())]))
+    model.fit(ds, y)
+    pred = model.predict(ds)
+    assert isinstance(pred, xr.DataArray) and dict(pred.sizes) == dict(y.sizes)
+    try:
+        import dask  # noqa: F401
+    except ImportError:
+        return
+    dsc, yc = ds.chunk({"y": 1, "x": 1}), y.chunk({"y": 1, "x": 1})
+    model = PointWiseDownscaler(Pipeline([("scaler", StandardScaler()), ("lr", LinearRegression())]))
+    model.fit(dsc, yc)
+    predc = model.predict(dsc)
+    assert isinstance(predc, xr.DataArray) and dict(predc.sizes) == dict(y.sizes)
+    assert predc.chunks == yc.chunks
+    np.testing.assert_allclose(predc.values, pred.values, rtol=1e-12)
