@@ -88,6 +88,8 @@ typedef struct sd_bcsd_state sd_bcsd_state;
 typedef struct sd_analog_state sd_analog_state;
 typedef struct sd_qm_state sd_qm_state;
 typedef struct sd_linreg_state sd_linreg_state;
+typedef struct sd_comm sd_comm;
+#define SD_COMM_ID_BYTES 128 /* RCCL's ncclUniqueId */
 
 /* ---- library / context ---------------------------------------------------------------------- */
 int sd_version(void);
@@ -244,6 +246,26 @@ int sd_linreg_state_export(const sd_linreg_state* st, double* coef, double* inte
 int sd_linreg_state_import(sd_ctx* ctx, int64_t T, int F, int64_t C, const double* coef, const double* intercept, const double* fit_error,
                            const double* logistic, const int32_t* thresh_dropped, const int32_t* cell_status, sd_linreg_state** out);
 int sd_linreg_state_destroy(sd_linreg_state* st);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI (no PyTorch) -----------------------------------
+ * The reference's only parallelism is dask's map_blocks over spatial chunks (core.py:256-262, 300-336) and a client-side
+ * collection of the result; here cells are block-partitioned over the ranks of one node, fit / predict need no exchange
+ * (cells are independent, core.py:87), and the predicted shards are gathered to a root GPU.
+ * Bootstrap: rank 0 calls sd_comm_unique_id and hands the 128 bytes to the other ranks by any channel (the Python side
+ * uses a TCP socket next to MASTER_PORT); every rank then calls sd_comm_create on its own context.
+ * sd_comm_gather_field: every rank contributes one contiguous [T, cells[rank]] float64 field; the root receives block r at
+ * offset sum_{q<r} T * cells[q] of root_dev (layout [rank][T][C_r]: no padding, no concatenation copy).  The transfer is
+ * ordered behind the work already queued on the context and runs on the communicator's own stream: with wait = 0 the next
+ * chunk of cells can be computed meanwhile, sd_comm_wait joins. */
+int sd_comm_unique_id(char* id /* [SD_COMM_ID_BYTES] */);
+int sd_comm_create(sd_ctx* ctx, const char* id /* [SD_COMM_ID_BYTES] */, int rank, int world, sd_comm** out);
+int sd_comm_destroy(sd_comm* comm);
+int sd_comm_info(const sd_comm* comm, int* rank, int* world);
+int sd_comm_barrier(sd_comm* comm);
+int sd_comm_allreduce_max(sd_comm* comm, double value, double* result);
+int sd_comm_gather_field(sd_comm* comm, const double* local_dev, int64_t T, const int64_t* cells /* [world] */,
+                         double* root_dev /* root only */, int root, int wait);
+int sd_comm_wait(sd_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -27,9 +27,29 @@
 #define BETA 0.4  /* quantile.py:424 */
 #define N_ENDPOINTS 10 /* quantile.py:426 */
 
-static int cmp_double(const void* a, const void* b) {
-    const double x = *(const double*)a, y = *(const double*)b;
-    return (x > y) - (x < y);
+/* np.sort (quantile.py:462) for finite data: insertion-sorted runs of 16, then bottom-up merges through tmp[n] */
+static void sort_doubles(double* a, int n, double* tmp) {
+    for (int s = 0; s < n; s += 16) {
+        const int e = s + 16 < n ? s + 16 : n;
+        for (int i = s + 1; i < e; ++i) {
+            const double v = a[i];
+            int j = i - 1;
+            while (j >= s && a[j] > v) { a[j + 1] = a[j]; --j; }
+            a[j + 1] = v;
+        }
+    }
+    double *src = a, *dst = tmp;
+    for (int w = 16; w < n; w <<= 1) {
+        for (int lo = 0; lo < n; lo += 2 * w) {
+            const int mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            int i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) dst[k++] = src[j] < src[i] ? src[j++] : src[i++];
+            while (i < mid) dst[k++] = src[i++];
+            while (j < hi) dst[k++] = src[j++];
+        }
+        double* t = src; src = dst; dst = t;
+    }
+    if (src != a) memcpy(a, src, sizeof(double) * n);
 }
 
 /* quantile.py:23-43 plotting_positions, same operation order */
@@ -61,27 +81,31 @@ static void ols_line(const double* ys, int first, int e, double denom, double* s
 }
 
 /* CunnaneTransformer.inverse_transform (quantile.py:523-545): np.interp(p, pp, ys, -inf, inf) + OLS tails */
-static double inverse_cdf(double p, const double* ys, int n, double denom, const double* tails) {
-    if (p < pp_at(0, denom)) return p * tails[0] + tails[1];
-    if (p > pp_at(n - 1, denom)) return p * tails[2] + tails[3];
+static double inverse_cdf(double p, const double* ys, const double* pp /* plotting positions of the fit, [n] */, int n,
+                          const double* tails) {
+    if (p < pp[0]) return p * tails[0] + tails[1];
+    if (p > pp[n - 1]) return p * tails[2] + tails[3];
     /* binary search for the last i with pp[i] <= p (numpy compiled_base.c arr_interp) */
     int lo = 0, hi = n;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (pp_at(mid, denom) <= p) lo = mid + 1; else hi = mid;
+        if (pp[mid] <= p) lo = mid + 1; else hi = mid;
     }
     const int i = lo - 1;
-    const double pi = pp_at(i, denom);
+    const double pi = pp[i];
     if (i == n - 1 || pi == p) return ys[i];
-    const double slope = (ys[i + 1] - ys[i]) / (pp_at(i + 1, denom) - pi);
+    const double slope = (ys[i + 1] - ys[i]) / (pp[i + 1] - pi);
     return slope * (p - pi) + ys[i];
 }
 
-/* QuantileMapper.transform for one segment (quantile.py:109-147): u[m] -> q[m]; work: m doubles */
-static void qm_segment(const double* u, int m, const double* ys, int n, double* q, double* work) {
+/* QuantileMapper.transform for one segment (quantile.py:109-147): u[m] -> q[m]; work: 3 * max(m, n) doubles */
+static void qm_segment(const double* u, int m, const double* ys, int n, double* q, double* work, int nmax) {
+    double* tmp = work + nmax;
+    double* ppn = work + 2 * nmax; /* plotting positions of the fitted CDF (quantile.py:457-463) */
     memcpy(work, u, sizeof(double) * m);
-    qsort(work, m, sizeof(double), cmp_double); /* quantile.py:462 via fit_transform 505-521 */
+    sort_doubles(work, m, tmp); /* quantile.py:462 via fit_transform 505-521 */
     const double dm = pp_denom(m), dn = pp_denom(n);
+    for (int i = 0; i < n; ++i) ppn[i] = pp_at(i, dn);
     double tails[4] = {0, 0, 0, 0};
     const int e = n < N_ENDPOINTS ? n : N_ENDPOINTS;
     if (m > n) {
@@ -90,7 +114,7 @@ static void qm_segment(const double* u, int m, const double* ys, int n, double* 
     }
     for (int j = 0; j < m; ++j) {
         const int r = upper_bound(work, m, u[j]) - 1; /* quantile.py:488 np.interp on own sorted data */
-        q[j] = inverse_cdf(pp_at(r, dm), ys, n, dn, tails);
+        q[j] = inverse_cdf(pp_at(r, dm), ys, ppn, n, tails);
     }
 }
 
@@ -98,13 +122,13 @@ static void qm_segment(const double* u, int m, const double* ys, int n, double* 
  * x, y: [T] strided by ld; xp: [Tp] strided by ldp; out: [Tp] strided by ldo. */
 static int bcsd_cell(int kind, const double* x, const double* y, int64_t ld, const double* xp, int64_t ldp,
                      const int32_t* ord, const int64_t* off, const int32_t* ordp, const int64_t* offp, int G,
-                     int return_anoms, double* out, int64_t ldo, double* buf /* 6*nmax */, int nmax) {
+                     int return_anoms, double* out, int64_t ldo, double* buf /* 8*nmax */, int nmax) {
     double* ys = buf;            /* sorted y segment */
     double* xg = buf + nmax;     /* predict segment  */
     double* u = buf + 2 * nmax;
     double* q = buf + 3 * nmax;
-    double* work = buf + 4 * nmax;
-    double* shiftv = buf + 5 * nmax;
+    double* shiftv = buf + 4 * nmax;
+    double* work = buf + 5 * nmax; /* 3 * nmax */
     const double first = x ? x[0] : y[0];
     if (first != first) return ST_MASKED; /* core.py:35-37 */
     int status = ST_OK;
@@ -135,7 +159,7 @@ static int bcsd_cell(int kind, const double* x, const double* y, int64_t ld, con
         }
         xc /= n; /* bcsd.py:222 */
         yc /= n; /* bcsd.py:223 / 138 */
-        qsort(ys, n, sizeof(double), cmp_double); /* quantile.py:462 np.sort */
+        sort_doubles(ys, n, work); /* quantile.py:462 np.sort */
         for (int j = 0; j < m; ++j) xg[j] = xp[(int64_t)ordp[offp[g] + j] * ldp];
         if (kind == KIND_TAS) {
             for (int j = 0; j < m; ++j) { /* bcsd.py:247-256 */
@@ -146,14 +170,14 @@ static int bcsd_cell(int kind, const double* x, const double* y, int64_t ld, con
                 u[j] = xg[j] - shift;
                 shiftv[j] = shift;
             }
-            qm_segment(u, m, ys, n, q, work); /* bcsd.py:260 */
+            qm_segment(u, m, ys, n, q, work, nmax); /* bcsd.py:260 */
             for (int j = 0; j < m; ++j) {
                 double r = shiftv[j] + q[j];      /* bcsd.py:263 */
                 if (return_anoms) r = r - yc;     /* bcsd.py:266-267 */
                 out[(int64_t)ordp[offp[g] + j] * ldo] = r;
             }
         } else {
-            qm_segment(xg, m, ys, n, q, work); /* bcsd.py:167 */
+            qm_segment(xg, m, ys, n, q, work, nmax); /* bcsd.py:167 */
             for (int j = 0; j < m; ++j) out[(int64_t)ordp[offp[g] + j] * ldo] = return_anoms ? q[j] / yc : q[j]; /* bcsd.py:170-185 */
         }
     }
@@ -195,7 +219,7 @@ int sdo_bcsd_fit_predict(int kind, const double* X, const double* y, const doubl
     const int64_t nblk = (C + 7) / 8;
 #pragma omp parallel
     {
-        double* buf = (double*)malloc(sizeof(double) * 6 * (size_t)nmax);
+        double* buf = (double*)malloc(sizeof(double) * 8 * (size_t)nmax);
         double* cx = (double*)malloc(sizeof(double) * 8 * (size_t)(2 * T + 2 * Tp));
         double* cy = cx + 8 * T;
         double* cp = cy + 8 * T;

@@ -2285,16 +2285,16 @@ int predict_host(int mode, sd_ctx* ctx, const sd_analog_state* st, const double*
     const size_t qb = sizeof(double) * (size_t)Tq * st->F * C, ob = sizeof(double) * (size_t)Tq * 3 * C;
     SD_HIP(dq.alloc(ctx, qb));
     SD_HIP(dout.alloc(ctx, ob));
-    SD_HIP(hipMemcpyAsync(dq.p, Xq, qb, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_copy_h2d(ctx, dq.p, Xq, qb));
     if (inds) SD_HIP(dinds.alloc(ctx, sizeof(int64_t) * (size_t)Tq * k * C));
     if (dist) SD_HIP(ddist.alloc(ctx, sizeof(double) * (size_t)Tq * k * C));
     if (sample) {
         SD_HIP(dsamp.alloc(ctx, sizeof(int32_t) * (size_t)Tq * C));
-        SD_HIP(hipMemcpyAsync(dsamp.p, sample, sizeof(int32_t) * (size_t)Tq * C, hipMemcpyHostToDevice, ctx->stream));
+        SD_TRY(sd_copy_h2d(ctx, dsamp.p, sample, sizeof(int32_t) * (size_t)Tq * C));
     }
     SD_TRY(predict_common(mode, ctx, st, dq.as<double>(), C, Tq, k, kind, has_thresh, thresh, dsamp.as<int32_t>(), C,
                           dout.as<double>(), C, dinds.as<int64_t>(), ddist.as<double>(), cell_status));
-    SD_HIP(hipMemcpyAsync(out, dout.p, ob, hipMemcpyDeviceToHost, ctx->stream));
+    SD_TRY(sd_copy_d2h(ctx, out, dout.p, ob));
     if (inds) SD_HIP(hipMemcpyAsync(inds, dinds.p, sizeof(int64_t) * (size_t)Tq * k * C, hipMemcpyDeviceToHost, ctx->stream));
     if (dist) SD_HIP(hipMemcpyAsync(dist, ddist.p, sizeof(double) * (size_t)Tq * k * C, hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(hipStreamSynchronize(ctx->stream));
@@ -2416,8 +2416,8 @@ int sd_analog_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int 
     sd_scratch dX, dy;
     SD_HIP(dX.alloc(ctx, sizeof(double) * (size_t)T * F * C));
     SD_HIP(dy.alloc(ctx, sizeof(double) * (size_t)T * C));
-    SD_HIP(hipMemcpyAsync(dX.p, X, sizeof(double) * (size_t)T * F * C, hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(hipMemcpyAsync(dy.p, y, sizeof(double) * (size_t)T * C, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_copy_h2d(ctx, dX.p, X, sizeof(double) * (size_t)T * F * C));
+    SD_TRY(sd_copy_h2d(ctx, dy.p, y, sizeof(double) * (size_t)T * C));
     return sd_analog_fit_dev(ctx, dX.as<double>(), dy.as<double>(), C, T, F, C, out);
 }
 

@@ -1124,10 +1124,10 @@ int sd_bcsd_fit(sd_ctx* ctx, int kind, const double* X, const double* y, const i
     const size_t bytes = sizeof(double) * (size_t)T * (size_t)C;
     if (X) {
         SD_HIP(dX.alloc(ctx, bytes));
-        SD_HIP(hipMemcpyAsync(dX.p, X, bytes, hipMemcpyHostToDevice, ctx->stream));
+        SD_TRY(sd_copy_h2d(ctx, dX.p, X, bytes));
     }
     SD_HIP(dy.alloc(ctx, bytes));
-    SD_HIP(hipMemcpyAsync(dy.p, y, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_copy_h2d(ctx, dy.p, y, bytes));
     return sd_bcsd_fit_dev(ctx, kind, dX.as<double>(), dy.as<double>(), C, group_id, G, T, C, return_anoms, out);
 }
 
@@ -1140,9 +1140,9 @@ int sd_bcsd_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, cons
     const size_t bytes = sizeof(double) * (size_t)Tp * (size_t)st->C;
     SD_HIP(dX.alloc(ctx, bytes));
     SD_HIP(dout.alloc(ctx, bytes));
-    SD_HIP(hipMemcpyAsync(dX.p, Xp, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_copy_h2d(ctx, dX.p, Xp, bytes));
     SD_TRY(sd_bcsd_predict_dev(ctx, st, dX.as<double>(), st->C, group_id_p, Tp, dout.as<double>(), st->C, cell_status));
-    SD_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SD_TRY(sd_copy_d2h(ctx, out, dout.p, bytes));
     SD_HIP(hipStreamSynchronize(ctx->stream));
     return SD_OK;
 }
@@ -1170,10 +1170,10 @@ int sd_bcsd_fit_groups(sd_ctx* ctx, int kind, const double* X, const double* y, 
     const size_t bytes = sizeof(double) * (size_t)T * (size_t)C;
     if (X) {
         SD_HIP(dX.alloc(ctx, bytes));
-        SD_HIP(hipMemcpyAsync(dX.p, X, bytes, hipMemcpyHostToDevice, ctx->stream));
+        SD_TRY(sd_copy_h2d(ctx, dX.p, X, bytes));
     }
     SD_HIP(dy.alloc(ctx, bytes));
-    SD_HIP(hipMemcpyAsync(dy.p, y, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_copy_h2d(ctx, dy.p, y, bytes));
     return sd_bcsd_fit_groups_dev(ctx, kind, dX.as<double>(), dy.as<double>(), C, group_order, group_offsets, G, T, C, return_anoms, out);
 }
 
@@ -1186,10 +1186,10 @@ int sd_bcsd_predict_trend(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp
     const size_t bytes = sizeof(double) * (size_t)Tp * (size_t)st->C;
     SD_HIP(dX.alloc(ctx, bytes));
     SD_HIP(dout.alloc(ctx, bytes));
-    SD_HIP(hipMemcpyAsync(dX.p, Xp, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_copy_h2d(ctx, dX.p, Xp, bytes));
     SD_TRY(sd_bcsd_predict_trend_dev(ctx, st, dX.as<double>(), st->C, group_id_p, trend_group_id, G_trend, Tp, dout.as<double>(), st->C,
                                      cell_status));
-    SD_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SD_TRY(sd_copy_d2h(ctx, out, dout.p, bytes));
     SD_HIP(hipStreamSynchronize(ctx->stream));
     return SD_OK;
 }

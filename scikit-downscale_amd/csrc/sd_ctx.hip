@@ -1,6 +1,10 @@
 // Context, device memory, timers, per-kernel profile and the on-device synthetic field generator.
 #include <cstring>
 
+#include <algorithm>
+#include <cstring>
+#include <thread>
+
 #include "sd_internal.h"
 
 static thread_local std::string g_last_error;
@@ -21,6 +25,94 @@ void sd_gt_cache_clear(sd_ctx* ctx) {
         if (e.off) (void)hipFree(e.off);
     }
     ctx->gt_cache.clear();
+}
+
+// ---- pinned, chunked, double-buffered host <-> device copies ------------------------------------------------------
+namespace {
+
+constexpr size_t kDirectCopyBytes = (size_t)8 << 20;  // smaller copies take the runtime's own path
+
+int stage_init(sd_ctx* ctx) {
+    if (ctx->copy_stream) return SD_OK;
+    SD_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    SD_HIP(hipEventCreateWithFlags(&ctx->stage_join, hipEventDisableTiming));
+    for (int b = 0; b < sd_ctx::kStageBufs; ++b) {
+        SD_HIP(hipHostMalloc(&ctx->stage[b], sd_ctx::kStageBytes, hipHostMallocDefault));
+        SD_HIP(hipEventCreateWithFlags(&ctx->stage_ev[b], hipEventDisableTiming));
+    }
+    return SD_OK;
+}
+
+void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+    unsigned nt = std::thread::hardware_concurrency() / 8;
+    nt = nt < 2 ? 2 : (nt > 16 ? 16 : nt);
+    const size_t part = ((bytes / nt) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) {
+        const size_t off = t * part;
+        if (off >= bytes) break;
+        const size_t n = std::min(part, bytes - off);
+        th.emplace_back([=]() { memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, n); });
+    }
+    memcpy(dst, src, std::min(part, bytes));
+    for (auto& t : th) t.join();
+}
+
+}  // namespace
+
+int sd_copy_h2d(sd_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes < kDirectCopyBytes) {
+        SD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SD_OK;
+    }
+    SD_TRY(stage_init(ctx));
+    // the destination may still be read by work queued earlier (recycled blocks): the transfer starts behind it
+    SD_HIP(hipEventRecord(ctx->stage_join, ctx->stream));
+    SD_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->stage_join, 0));
+    size_t off = 0;
+    for (int i = 0; off < bytes; ++i) {
+        const int b = i % sd_ctx::kStageBufs;
+        const size_t n = std::min(sd_ctx::kStageBytes, bytes - off);
+        if (i >= sd_ctx::kStageBufs) SD_HIP(hipEventSynchronize(ctx->stage_ev[b]));  // the DMA out of this buffer is done
+        parallel_memcpy(ctx->stage[b], static_cast<const char*>(src) + off, n);
+        SD_HIP(hipMemcpyAsync(static_cast<char*>(dst) + off, ctx->stage[b], n, hipMemcpyHostToDevice, ctx->copy_stream));
+        SD_HIP(hipEventRecord(ctx->stage_ev[b], ctx->copy_stream));
+        off += n;
+    }
+    SD_HIP(hipEventRecord(ctx->stage_join, ctx->copy_stream));
+    SD_HIP(hipStreamWaitEvent(ctx->stream, ctx->stage_join, 0));
+    // the staging buffers are reused by the next call: wait for the last DMAs here (the kernels need the data anyway)
+    SD_HIP(hipStreamSynchronize(ctx->copy_stream));
+    return SD_OK;
+}
+
+int sd_copy_d2h(sd_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes < kDirectCopyBytes) {
+        SD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        return SD_OK;
+    }
+    SD_TRY(stage_init(ctx));
+    SD_HIP(hipEventRecord(ctx->stage_join, ctx->stream));
+    SD_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->stage_join, 0));
+    const int nchunks = (int)((bytes + sd_ctx::kStageBytes - 1) / sd_ctx::kStageBytes);
+    auto issue = [&](int i) -> int {
+        const size_t off = (size_t)i * sd_ctx::kStageBytes, n = std::min(sd_ctx::kStageBytes, bytes - off);
+        const int b = i % sd_ctx::kStageBufs;
+        SD_HIP(hipMemcpyAsync(ctx->stage[b], static_cast<const char*>(src) + off, n, hipMemcpyDeviceToHost, ctx->copy_stream));
+        SD_HIP(hipEventRecord(ctx->stage_ev[b], ctx->copy_stream));
+        return SD_OK;
+    };
+    for (int i = 0; i < nchunks && i < sd_ctx::kStageBufs - 1; ++i) SD_TRY(issue(i));
+    for (int i = 0; i < nchunks; ++i) {
+        const int next = i + sd_ctx::kStageBufs - 1;
+        if (next < nchunks) SD_TRY(issue(next));  // its buffer was drained in iteration i - 1
+        const size_t off = (size_t)i * sd_ctx::kStageBytes, n = std::min(sd_ctx::kStageBytes, bytes - off);
+        const int b = i % sd_ctx::kStageBufs;
+        SD_HIP(hipEventSynchronize(ctx->stage_ev[b]));
+        parallel_memcpy(static_cast<char*>(dst) + off, ctx->stage[b], n);
+    }
+    return SD_OK;
 }
 
 extern "C" {
@@ -74,6 +166,12 @@ int sd_ctx_destroy(sd_ctx* ctx) {
     (void)hipEventDestroy(ctx->p0);
     (void)hipEventDestroy(ctx->p1);
     if (ctx->ws_ptr) (void)hipFree(ctx->ws_ptr);
+    for (int b = 0; b < sd_ctx::kStageBufs; ++b) {
+        if (ctx->stage[b]) (void)hipHostFree(ctx->stage[b]);
+        if (ctx->stage_ev[b]) (void)hipEventDestroy(ctx->stage_ev[b]);
+    }
+    if (ctx->stage_join) (void)hipEventDestroy(ctx->stage_join);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     sd_gt_cache_clear(ctx);
     sd_pool_trim(ctx);
     (void)hipStreamDestroy(ctx->stream);
@@ -134,7 +232,7 @@ int sd_dev_free(sd_ctx* ctx, void* dptr) {
 int sd_memcpy_h2d(sd_ctx* ctx, void* dst, const void* src, size_t bytes) {
     SD_CHECK_ARG(ctx && dst && src, "sd_memcpy_h2d: NULL argument");
     SD_HIP(hipSetDevice(ctx->device));
-    SD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_copy_h2d(ctx, dst, src, bytes));
     SD_HIP(hipStreamSynchronize(ctx->stream));
     return SD_OK;
 }
@@ -142,8 +240,7 @@ int sd_memcpy_h2d(sd_ctx* ctx, void* dst, const void* src, size_t bytes) {
 int sd_memcpy_d2h(sd_ctx* ctx, void* dst, const void* src, size_t bytes) {
     SD_CHECK_ARG(ctx && dst && src, "sd_memcpy_d2h: NULL argument");
     SD_HIP(hipSetDevice(ctx->device));
-    SD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    SD_HIP(hipStreamSynchronize(ctx->stream));
+    SD_TRY(sd_copy_d2h(ctx, dst, src, bytes));
     return SD_OK;
 }
 

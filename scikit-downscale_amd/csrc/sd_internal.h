@@ -66,8 +66,22 @@ struct sd_ctx {
     size_t pool_cached = 0, pool_cap = 0;
     std::vector<sd_gt_cache_entry> gt_cache;  // at most kGtCacheEntries, least recently used entry replaced
     uint64_t gt_clock = 0;
+    // pinned staging ring of the host-buffer entry points (sd_copy_h2d / sd_copy_d2h), created on first use
+    static constexpr int kStageBufs = 3;
+    static constexpr size_t kStageBytes = (size_t)64 << 20;
+    void* stage[kStageBufs] = {nullptr, nullptr, nullptr};
+    hipEvent_t stage_ev[kStageBufs] = {nullptr, nullptr, nullptr};
+    hipEvent_t stage_join = nullptr;
+    hipStream_t copy_stream = nullptr;
 };
 void sd_gt_cache_clear(sd_ctx* ctx);
+// Large host <-> device copies of the host-buffer entry points.  Pageable host memory goes through a ring of pinned
+// staging buffers: several host threads copy a chunk into (out of) a pinned buffer while the DMA engine moves the
+// previous chunk, so the transfer runs at the PCIe rate instead of the runtime's single-threaded pageable path.
+// sd_copy_h2d: returns once every chunk is queued; later work on ctx->stream is ordered behind the transfer.
+// sd_copy_d2h: ordered behind the work already queued on ctx->stream; returns when the host buffer is complete.
+int sd_copy_h2d(sd_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int sd_copy_d2h(sd_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 
 // Device memory through the context's block cache (exact-size reuse).  Blocks go back with sd_pool_release;
 // the cache is bounded by pool_cap (a quarter of the device memory) and emptied by sd_ctx_release_cached /

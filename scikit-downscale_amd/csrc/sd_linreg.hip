@@ -514,8 +514,8 @@ int sd_linreg_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int 
     sd_scratch dX, dy;
     SD_HIP(dX.alloc(ctx, sizeof(double) * (size_t)T * F * C));
     SD_HIP(dy.alloc(ctx, sizeof(double) * (size_t)T * C));
-    SD_HIP(hipMemcpyAsync(dX.p, X, sizeof(double) * (size_t)T * F * C, hipMemcpyHostToDevice, ctx->stream));
-    SD_HIP(hipMemcpyAsync(dy.p, y, sizeof(double) * (size_t)T * C, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_copy_h2d(ctx, dX.p, X, sizeof(double) * (size_t)T * F * C));
+    SD_TRY(sd_copy_h2d(ctx, dy.p, y, sizeof(double) * (size_t)T * C));
     return sd_linreg_fit_dev(ctx, dX.as<double>(), dy.as<double>(), C, T, F, C, has_thresh, thresh, out);
 }
 
@@ -547,9 +547,9 @@ int sd_linreg_predict(sd_ctx* ctx, const sd_linreg_state* st, const double* Xq, 
     const size_t in_bytes = sizeof(double) * (size_t)Tq * st->F * st->C, out_bytes = sizeof(double) * (size_t)Tq * 3 * st->C;
     SD_HIP(dX.alloc(ctx, in_bytes));
     SD_HIP(dout.alloc(ctx, out_bytes));
-    SD_HIP(hipMemcpyAsync(dX.p, Xq, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_copy_h2d(ctx, dX.p, Xq, in_bytes));
     SD_TRY(sd_linreg_predict_dev(ctx, st, dX.as<double>(), st->C, Tq, dout.as<double>(), st->C, cell_status));
-    SD_HIP(hipMemcpyAsync(out, dout.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SD_TRY(sd_copy_d2h(ctx, out, dout.p, out_bytes));
     SD_HIP(hipStreamSynchronize(ctx->stream));
     return SD_OK;
 }

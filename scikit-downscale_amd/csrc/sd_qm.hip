@@ -520,10 +520,10 @@ int sd_qm_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int64_t 
     sd_scratch dX, dy;
     const size_t bytes = sizeof(double) * (size_t)T * C;
     SD_HIP(dX.alloc(ctx, bytes));
-    SD_HIP(hipMemcpyAsync(dX.p, X, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_copy_h2d(ctx, dX.p, X, bytes));
     if (y) {
         SD_HIP(dy.alloc(ctx, bytes));
-        SD_HIP(hipMemcpyAsync(dy.p, y, bytes, hipMemcpyHostToDevice, ctx->stream));
+        SD_TRY(sd_copy_h2d(ctx, dy.p, y, bytes));
     }
     return sd_qm_fit_dev(ctx, dX.as<double>(), y ? dy.as<double>() : nullptr, C, T, C, out);
 }
@@ -581,9 +581,9 @@ int sd_qm_predict(sd_ctx* ctx, const sd_qm_state* st, int model, int extrapolate
     const size_t bytes = sizeof(double) * (size_t)Tp * st->C;
     SD_HIP(dX.alloc(ctx, bytes));
     SD_HIP(dout.alloc(ctx, bytes));
-    SD_HIP(hipMemcpyAsync(dX.p, Xp, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_copy_h2d(ctx, dX.p, Xp, bytes));
     SD_TRY(sd_qm_predict_dev(ctx, st, model, extrapolate, n_endpoints, dX.as<double>(), st->C, Tp, dout.as<double>(), st->C, cell_status));
-    SD_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SD_TRY(sd_copy_d2h(ctx, out, dout.p, bytes));
     SD_HIP(hipStreamSynchronize(ctx->stream));
     return SD_OK;
 }
@@ -632,10 +632,10 @@ int sd_qm_cunnane(sd_ctx* ctx, const sd_qm_state* st, int direction, int extrapo
     const size_t bytes = sizeof(double) * (size_t)Tp * st->C;
     SD_HIP(dX.alloc(ctx, bytes));
     SD_HIP(dout.alloc(ctx, bytes));
-    SD_HIP(hipMemcpyAsync(dX.p, X, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SD_TRY(sd_copy_h2d(ctx, dX.p, X, bytes));
     SD_TRY(sd_qm_cunnane_dev(ctx, st, direction, extrapolate, n_endpoints, dX.as<double>(), st->C, Tp, dout.as<double>(), st->C,
                              cell_status));
-    SD_HIP(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SD_TRY(sd_copy_d2h(ctx, out, dout.p, bytes));
     SD_HIP(hipStreamSynchronize(ctx->stream));
     return SD_OK;
 }

@@ -90,6 +90,14 @@ SIGNATURES = {
     "sd_qm_state_info": [_p, C.POINTER(_i64), C.POINTER(_i64)],
     "sd_qm_state_export": [_p, _p, _p, _p],
     "sd_qm_state_destroy": [_p],
+    "sd_comm_unique_id": [_p],
+    "sd_comm_create": [_p, _p, _int, _int, C.POINTER(_p)],
+    "sd_comm_destroy": [_p],
+    "sd_comm_info": [_p, C.POINTER(_int), C.POINTER(_int)],
+    "sd_comm_barrier": [_p],
+    "sd_comm_allreduce_max": [_p, _dbl, C.POINTER(_dbl)],
+    "sd_comm_gather_field": [_p, _p, _i64, _p, _p, _int, _int],
+    "sd_comm_wait": [_p],
 }
 
 _libs = {}

@@ -2,13 +2,146 @@
 
 Cells are independent (each gets its own estimator in the reference, core.py:87), so the grid is
 block-partitioned over ranks with no exchange during fit/predict; the only communication is the
-gather of the predicted field ``out[Tp, C_local]`` to the root.  ``torch.distributed`` is launcher
-plumbing here (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in CPU tests); the engine
-itself never imports torch.
+gather of the predicted field ``out[Tp, C_local]`` to the root.
+
+``Communicator`` is the product path: one process per GPU, RCCL over xGMI through the engine's own C ABI
+(``sd_comm_*``, csrc/sd_comm.hip) -- no PyTorch.  The ranks find each other through the launcher's environment
+(``RANK``, ``WORLD_SIZE``, ``MASTER_ADDR``, ``MASTER_PORT``: what ``python -m torch.distributed.run`` or any other
+launcher exports); rank 0 hands RCCL's 128-byte unique id to the others over a TCP socket.
+``gather_field`` (torch.distributed) remains for hosts whose fields already live in torch tensors and for the CPU
+test of the partition logic (gloo).
 """
 from __future__ import annotations
 
+import ctypes
+import os
+import socket
+import time
+
 import numpy as np
+
+ID_BYTES = 128
+PORT_OFFSET = 17  # the id is served on MASTER_PORT + PORT_OFFSET (MASTER_PORT itself may belong to the launcher's store)
+
+
+def exchange_unique_id(rank, world, make_id, addr=None, port=None, timeout=300.0):
+    """Rank 0 calls ``make_id()`` (-> 128 bytes) and serves the result to the other ranks; every rank returns it."""
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + PORT_OFFSET)
+    if world == 1:
+        return make_id()
+    if rank == 0:
+        uid = make_id()
+        assert len(uid) == ID_BYTES
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        try:
+            for _ in range(world - 1):
+                conn, _peer = srv.accept()
+                with conn:
+                    conn.sendall(uid)
+        finally:
+            srv.close()
+        return uid
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as conn:
+                buf = b""
+                while len(buf) < ID_BYTES:
+                    chunk = conn.recv(ID_BYTES - len(buf))
+                    if not chunk:
+                        break
+                    buf += chunk
+            if len(buf) == ID_BYTES:
+                return buf
+        except OSError:
+            pass
+        if time.time() > deadline:
+            raise TimeoutError(f"rank {rank}: no unique id from {addr}:{port} within {timeout} s")
+        time.sleep(0.05)
+
+
+class Communicator:
+    """RCCL communicator of the engine (one rank per process / GPU)."""
+
+    def __init__(self, ctx, rank, world, unique_id):
+        from ._lib import check
+
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        h = ctypes.c_void_p()
+        check(ctx.lib.sd_comm_create(ctx.handle, ctypes.c_char_p(unique_id), self.rank, self.world, ctypes.byref(h)))
+        self.handle = h
+
+    @classmethod
+    def from_env(cls, ctx, timeout=300.0):
+        """rank / world / rendezvous address from the launcher's environment"""
+        from ._lib import check
+
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+        def make_id():
+            buf = ctypes.create_string_buffer(ID_BYTES)
+            check(ctx.lib.sd_comm_unique_id(buf))
+            return buf.raw
+
+        return cls(ctx, rank, world, exchange_unique_id(rank, world, make_id, timeout=timeout))
+
+    def close(self):
+        if self.handle is not None:
+            self.ctx.lib.sd_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def barrier(self):
+        from ._lib import check
+
+        check(self.ctx.lib.sd_comm_barrier(self.handle))
+
+    def allreduce_max(self, value):
+        from ._lib import check
+
+        out = ctypes.c_double()
+        check(self.ctx.lib.sd_comm_allreduce_max(self.handle, float(value), ctypes.byref(out)))
+        return out.value
+
+    def gather_field(self, local, cells, root=0, root_buffer=None, wait=True):
+        """Gather the contiguous [T, C_local] DeviceArray ``local`` of every rank to ``root``.  ``cells`` = C_local of every
+        rank.  On the root returns the list of per-rank views [T, cells[r]] into ``root_buffer`` (allocated when None:
+        sum(cells) * T doubles, shards back to back -- no concatenation copy); elsewhere None."""
+        from ._lib import check
+
+        cells = np.ascontiguousarray(cells, dtype=np.int64)
+        T = local.shape[0]
+        if local.ld != local.shape[1] or local.shape[1] != cells[self.rank]:
+            raise ValueError("gather_field needs a contiguous [T, cells[rank]] field")
+        views = None
+        if self.rank == root:
+            if root_buffer is None:
+                root_buffer = self.ctx.empty((int(cells.sum()) * T,))
+            views, off = [], 0
+            for r in range(self.world):
+                n = T * int(cells[r])
+                views.append(self.ctx.wrap(root_buffer.ptr + off * 8, (T, int(cells[r]))))
+                off += n
+            self._root_buffer = root_buffer  # keeps the allocation alive with the views
+        check(self.ctx.lib.sd_comm_gather_field(self.handle, local.vptr, T, cells.ctypes.data_as(ctypes.c_void_p),
+                                                None if root_buffer is None else root_buffer.vptr, int(root), 1 if wait else 0))
+        return views
+
+    def wait(self):
+        from ._lib import check
+
+        check(self.ctx.lib.sd_comm_wait(self.handle))
+
 
 
 def cell_partition(n_cells: int, world: int):

@@ -94,3 +94,34 @@ def test_state_use_after_destroy_and_release_cached(ctx):
     st = ctx.bcsd_fit(0, X, y, (np.arange(60) % 12).astype(np.int32), 12, True)
     out, status = ctx.bcsd_predict(st, X, (np.arange(60) % 12).astype(np.int32))
     assert np.isfinite(out).all()
+
+
+def test_single_rank_communicator_self_gather(ctx):
+    """sd_comm_* through the C ABI with one rank: RCCL is loaded with dlopen, the communicator is created from a unique
+    id, barrier / max-reduction work, and the gather of a [T, C] field to the root (= this rank) is an in-place copy into
+    the [rank][T][C_r] layout.  (world_size 2 is covered on CPU for the partition logic, tests/test_host.py.)"""
+    from skdownscale_amd.shard import Communicator
+
+    comm = Communicator.from_env(ctx)  # RANK / WORLD_SIZE unset: one rank
+    assert (comm.rank, comm.world) == (0, 1)
+    comm.barrier()
+    assert comm.allreduce_max(3.5) == 3.5
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((50, 7))
+    views = comm.gather_field(ctx.to_device(a), [7])
+    assert len(views) == 1 and np.array_equal(views[0].to_host(), a)
+    views = comm.gather_field(ctx.to_device(a), [7], wait=False)
+    comm.wait()
+    assert np.array_equal(views[0].to_host(), a)
+    with pytest.raises(ValueError, match="contiguous"):
+        comm.gather_field(ctx.to_device(a).cells(1, 4), [3])
+    comm.close()
+
+
+def test_large_host_copies_take_the_staged_path(ctx):
+    """host <-> device copies above 8 MB go through the pinned staging ring (several chunks, ragged tail)"""
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((3, 9_000_001))  # 216 MB: four 64 MB chunks, the last one partial
+    d = ctx.to_device(a)
+    assert np.array_equal(d.to_host(), a)
+    d.free()
