@@ -126,7 +126,14 @@ int sd_synth_fill(sd_ctx* ctx, double* out_dev, int64_t T, int64_t C, int64_t ld
 
 /* ---- BCSD quantile mapping --------------------------------------------------------------------
  * X: [T,C] model-historical field (TAS: used for x_climo; PR: only validated, may be NULL ->
- * mask/validation then use y).  y: [T,C] observations.  group_id: host int32[T]. */
+ * mask/validation then use y).  y: [T,C] observations.  group_id: host int32[T].
+ * The `return_anoms` argument of the fit entry points and of sd_bcsd_state_import / sd_bcsd_state_info is a bit set:
+ * SD_BCSD_RETURN_ANOMS (bcsd.py:27,266-267 / 170-185) | SD_BCSD_QM_DETREND (qm_kwargs={'detrend': True}: quantile.py:95-98,
+ * 128-145 -- every group's series loses its least-squares line over the sample index, trend.py:51-83, before the CDFs are
+ * built; the predict line is added back re-based on the fitted intercept).  Plain 0 / 1 keep their old meaning.  Detrended
+ * mapping serves group segments of up to 2112 samples (SD_ERR_UNSUPPORTED beyond). */
+#define SD_BCSD_RETURN_ANOMS 1
+#define SD_BCSD_QM_DETREND 2
 int sd_bcsd_fit(sd_ctx* ctx, int kind, const double* X, const double* y, const int32_t* group_id, int G, int64_t T,
                 int64_t C, int return_anoms, sd_bcsd_state** out);
 int sd_bcsd_fit_dev(sd_ctx* ctx, int kind, const double* X_dev, const double* y_dev, int64_t ld,
@@ -166,6 +173,11 @@ int sd_bcsd_state_export(const sd_bcsd_state* st, double* y_sorted, double* x_cl
 int sd_bcsd_state_import(sd_ctx* ctx, int kind, int G, int64_t T, int64_t C, int return_anoms, const double* y_sorted,
                          const double* x_climo, const double* y_climo, const int32_t* cell_status,
                          const int64_t* group_offsets, sd_bcsd_state** out);
+/* SD_BCSD_QM_DETREND states: slope and intercept of the fitted segments' lines, [C][G][2] (x_trend_fit_.lr_model_.coef_ /
+ * .intercept_ of every group's QuantileMapper, quantile.py:97,145).  set_trend completes a state made by
+ * sd_bcsd_state_import (only the intercepts enter predictions). */
+int sd_bcsd_state_get_trend(const sd_bcsd_state* st, double* y_trend);
+int sd_bcsd_state_set_trend(sd_bcsd_state* st, const double* y_trend);
 int sd_bcsd_state_destroy(sd_bcsd_state* st);
 
 /* ---- GARD analogs ----------------------------------------------------------------------------

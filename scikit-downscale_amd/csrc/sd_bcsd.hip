@@ -463,9 +463,10 @@ bool fz_shift_slab() {
     const char* e = sd_dev_env("SD_FZ_SLAB");
     return e ? e[0] == '1' : false;
 }
-bool use_fz_path(int kind, int nmax) {
+bool use_fz_path(int kind, int nmax, bool detrend) {
     const char* e = sd_dev_env("SD_BCSD_FUSED");  // "0": RANK + APPLY for every segment (A/B measurements)
     if (e && e[0] == '0') return false;
+    if (detrend) return false;  // QuantileMapper(detrend=True): RANK + APPLY carry the trend lines
     return kind == SD_BCSD_TAS && sd_bcsd_fz_supported(nmax);
 }
 
@@ -474,15 +475,18 @@ struct RsWorkspace {
     uint32_t* ranks = nullptr;
     double* shift = nullptr;
     double* x_climo = nullptr;  // [C][G], only for calls without a state
+    double* trend_u = nullptr;  // [C*G][2], only for detrended quantile mapping
     int64_t* worklist = nullptr;
     int* work_count = nullptr;
     int work_cap = 0;
 };
-int carve_workspace(sd_ctx* ctx, int nmax, int64_t C, int G, bool fused, bool want_shift, bool want_x_climo, RsWorkspace* w) {
+int carve_workspace(sd_ctx* ctx, int nmax, int64_t C, int G, bool fused, bool want_shift, bool want_x_climo, bool want_trend,
+                    RsWorkspace* w) {
     size_t rank_bytes = 0, shift_bytes = 0;
     sd_bcsd_rs_handoff_bytes(nmax, C, G, &rank_bytes, &shift_bytes);
     if (!want_shift) shift_bytes = 0;
-    const size_t xc_bytes = want_x_climo ? ((sizeof(double) * (size_t)G * (size_t)C + 255) / 256) * 256 : 0;
+    const size_t cg_bytes = ((sizeof(double) * (size_t)G * (size_t)C + 255) / 256) * 256;
+    const size_t xc_bytes = (want_x_climo ? cg_bytes : 0) + (want_trend ? 2 * cg_bytes : 0);
     const int64_t items = ((C + 7) / 8) * (int64_t)G;
     SD_CHECK_ARG(items < ((int64_t)1 << 31), "too many (tile, group) items");
     const size_t list_bytes = fused ? ((sizeof(int64_t) * (size_t)items + 255) / 256) * 256 : 0;
@@ -491,7 +495,8 @@ int carve_workspace(sd_ctx* ctx, int nmax, int64_t C, int G, bool fused, bool wa
     char* base = static_cast<char*>(ws);
     w->ranks = reinterpret_cast<uint32_t*>(base);
     w->shift = shift_bytes ? reinterpret_cast<double*>(base + rank_bytes) : nullptr;
-    w->x_climo = xc_bytes ? reinterpret_cast<double*>(base + rank_bytes + shift_bytes) : nullptr;
+    w->x_climo = want_x_climo ? reinterpret_cast<double*>(base + rank_bytes + shift_bytes) : nullptr;
+    w->trend_u = want_trend ? reinterpret_cast<double*>(base + rank_bytes + shift_bytes + (want_x_climo ? cg_bytes : 0)) : nullptr;
     if (fused) {
         w->worklist = reinterpret_cast<int64_t*>(base + rank_bytes + shift_bytes + xc_bytes);
         w->work_count = reinterpret_cast<int*>(base + rank_bytes + shift_bytes + xc_bytes + list_bytes);
@@ -823,8 +828,13 @@ bool use_long_path(int nmax, size_t lds_max) {
     return nmax > 64 * 33 && long_width(nmax, lds_max) != 0;
 }
 
-int alloc_state(sd_ctx* ctx, int kind, int G, int64_t T, int64_t C, int return_anoms, sd_bcsd_state** out) {
+// options = SD_BCSD_RETURN_ANOMS | SD_BCSD_QM_DETREND bits (the public `return_anoms` argument of the fit entry points)
+int alloc_state(sd_ctx* ctx, int kind, int G, int64_t T, int64_t C, int options, sd_bcsd_state** out) {
+    *out = nullptr;
+    SD_CHECK_ARG(options >= 0 && options <= 3, "options %d: expected a combination of SD_BCSD_RETURN_ANOMS and SD_BCSD_QM_DETREND", options);
+    const int return_anoms = options & SD_BCSD_RETURN_ANOMS;
     sd_bcsd_state* st = new sd_bcsd_state();
+    st->detrend = (options & SD_BCSD_QM_DETREND) ? 1 : 0;
     st->ctx = ctx;
     st->kind = kind;
     st->G = G;
@@ -835,6 +845,8 @@ int alloc_state(sd_ctx* ctx, int kind, int G, int64_t T, int64_t C, int return_a
     SD_HIP(sd_pool_malloc(ctx, (void**)&st->ys, sizeof(double) * T * C));
     SD_HIP(sd_pool_malloc(ctx, (void**)&st->x_climo, sizeof(double) * G * C));
     SD_HIP(sd_pool_malloc(ctx, (void**)&st->y_climo, sizeof(double) * G * C));
+    SD_HIP(sd_pool_malloc(ctx, (void**)&st->y_trend, sizeof(double) * 2 * G * C));
+    SD_HIP(hipMemsetAsync(st->y_trend, 0, sizeof(double) * 2 * G * C, ctx->stream));
     SD_HIP(sd_pool_malloc(ctx, (void**)&st->status, sizeof(int32_t) * C));
     SD_HIP(sd_pool_malloc(ctx, (void**)&st->goff_dev, sizeof(int32_t) * (G + 1)));
     SD_HIP(hipMemsetAsync(st->x_climo, 0, sizeof(double) * G * C, ctx->stream));
@@ -862,6 +874,7 @@ int sd_bcsd_state_destroy(sd_bcsd_state* st) {
     sd_pool_release(st->ctx, st->ys);
     sd_pool_release(st->ctx, st->x_climo);
     sd_pool_release(st->ctx, st->y_climo);
+    sd_pool_release(st->ctx, st->y_trend);
     sd_pool_release(st->ctx, st->status);
     sd_pool_release(st->ctx, st->goff_dev);
     delete st;
@@ -892,6 +905,9 @@ static int predict_with_table(sd_ctx* ctx, const sd_bcsd_state* st, const double
     const int nmax_all = gt.nmax > st->nmax ? gt.nmax : st->nmax;
     const bool rs = use_rs_path(nmax_all, ld > ld_out ? ld : ld_out);
     const bool lng = !rs && use_long_path(nmax_all, ctx->lds_max) && long_width(gt.nmax, ctx->lds_max) != 0;
+    if (st->detrend && !rs)
+        return sd_set_error(SD_ERR_UNSUPPORTED, "detrended quantile mapping serves group segments of up to %d samples (longest here: %d)",
+                            64 * 33, nmax_all);
     if (!rs && !lng) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 2, &W, &stride));
     QTables qt;
     if (rs) {
@@ -908,10 +924,11 @@ static int predict_with_table(sd_ctx* ctx, const sd_bcsd_state* st, const double
         p.status_fit = st->status; p.status_p = status_p;
         p.identity = identity ? 1 : 0;
         p.from_state = 1;
-        const bool fused = use_fz_path(st->kind, nmax_all);
+        p.detrend = st->detrend; p.y_trend = st->y_trend;
+        const bool fused = use_fz_path(st->kind, nmax_all, st->detrend != 0);
         RsWorkspace w;
-        SD_TRY(carve_workspace(ctx, nmax_all, C, st->G, fused, fused && fz_shift_slab(), false, &w));
-        p.ranks = w.ranks; p.shift = w.shift;
+        SD_TRY(carve_workspace(ctx, nmax_all, C, st->G, fused, fused && fz_shift_slab(), false, st->detrend != 0, &w));
+        p.ranks = w.ranks; p.shift = w.shift; p.trend_u = w.trend_u;
         p.worklist = w.worklist; p.work_count = w.work_count; p.work_cap = w.work_cap;
         const std::vector<int> glen = group_lengths(st->goff, &gt.host_off, st->G);
         SD_TRY(run_predict_kernels(ctx, p, fused, nmax_all, glen));
@@ -947,15 +964,19 @@ static int finish_predict(sd_ctx* ctx, const sd_bcsd_state* st, const int32_t* s
 
 // fit on an uploaded group table; the state's series length is the table's entry count (= T unless groups overlap)
 static int fit_with_table(sd_ctx* ctx, int kind, const double* X_dev, const double* y_dev, int64_t ld, const DevGroupTable& gt, int G,
-                          int64_t T_rows, int64_t C, int return_anoms, sd_bcsd_state** out) {
+                          int64_t T_rows, int64_t C, int options, sd_bcsd_state** out) {
     const int64_t T = gt.host_off[G];
     (void)T_rows;
+    const int return_anoms = options & SD_BCSD_RETURN_ANOMS;
     int W = 0, stride = 0;
     const bool rs = use_rs_path(gt.nmax, ld);
     const bool lng = !rs && use_long_path(gt.nmax, ctx->lds_max);
     if (!rs && !lng) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 1, &W, &stride));
     sd_bcsd_state* st = nullptr;
-    int rc = alloc_state(ctx, kind, G, T, C, return_anoms, &st);
+    int rc = alloc_state(ctx, kind, G, T, C, options, &st);
+    if (rc == SD_OK && st->detrend && !rs)
+        rc = sd_set_error(SD_ERR_UNSUPPORTED, "detrended quantile mapping serves group segments of up to %d samples (longest here: %d)",
+                          64 * 33, gt.nmax);
     if (rc != SD_OK) {
         sd_bcsd_state_destroy(st);
         return rc;
@@ -974,6 +995,7 @@ static int fit_with_table(sd_ctx* ctx, int kind, const double* X_dev, const doub
             p.X = X_dev; p.y = y_dev; p.ld = ld;
             p.ord_f = (const int32_t*)gt.order.p; p.off_f = (const int32_t*)gt.off.p;
             p.ys = st->ys; p.x_climo = st->x_climo; p.y_climo = st->y_climo; p.status_fit = st->status;
+            p.detrend = st->detrend; p.y_trend = st->y_trend;
             SD_TRY(sd_bcsd_rs_launch(ctx, sdrs::MODE_FIT, p, gt.nmax, group_lengths(gt.host_off, nullptr, G).data()));
         } else if (lng) {
             SD_LONG_DISPATCH(long_width(gt.nmax, ctx->lds_max), launch_long_fit, ctx, kind, X_dev, y_dev, ld, gt, G, T, C, return_anoms, st);
@@ -1062,6 +1084,8 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
     SD_TRY(upload_group_table(ctx, group_id, T, G, &gf));
     SD_TRY(upload_group_table(ctx, group_id_p, Tp, G, &gp));
     const int nmax_all = gf.nmax > gp.nmax ? gf.nmax : gp.nmax;
+    SD_CHECK_ARG(return_anoms >= 0 && return_anoms <= 3, "sd_bcsd_fit_predict: options %d", return_anoms);
+    const bool detrend = (return_anoms & SD_BCSD_QM_DETREND) != 0;
     if (!use_rs_path(nmax_all, std::max(ld, std::max(ld_p, ld_out)))) {
         // generic path: fit then predict through a transient state
         sd_bcsd_state* st = nullptr;
@@ -1082,9 +1106,10 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
     SD_LAUNCH(ctx, "bcsd_mask_kernel", bcsd_mask_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, first, C,
               status_f.as<int32_t>());
     sdrs::Params p = {};
-    p.kind = kind; p.G = G; p.return_anoms = return_anoms; p.RS = sd_bcsd_rs_row_stride(nmax_all);
+    p.kind = kind; p.G = G; p.return_anoms = return_anoms & SD_BCSD_RETURN_ANOMS; p.RS = sd_bcsd_rs_row_stride(nmax_all);
     p.C = C; p.Tf = T; p.ntiles = (C + 7) / 8;
     p.X = X_dev; p.y = y_dev; p.ld = ld;
+    p.detrend = detrend ? 1 : 0;
     p.Xp = Xp_dev; p.ld_p = ld_p; p.out = out_dev; p.ld_out = ld_out;
     p.ord_f = (const int32_t*)gf.order.p; p.off_f = (const int32_t*)gf.off.p;
     p.ord_p = (const int32_t*)gp.order.p; p.off_p = (const int32_t*)gp.off.p;
@@ -1095,10 +1120,10 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
         // No persisted sorted state.  BcsdTemperature: one fused kernel per segment (no hand-off at all); the segments
         // it hands back, and BcsdPrecipitation: RANK writes 2 bytes/sample (rank of every x_fut sample in its shifted
         // segment) + x_climo, APPLY sorts y_obs on chip, maps the ranks and restores the shift.
-        const bool fused = use_fz_path(kind, nmax_all);
+        const bool fused = use_fz_path(kind, nmax_all, detrend);
         RsWorkspace w;
-        SD_TRY(carve_workspace(ctx, nmax_all, C, G, fused, fused && fz_shift_slab(), true, &w));
-        p.ranks = w.ranks; p.shift = w.shift; p.x_climo = w.x_climo;
+        SD_TRY(carve_workspace(ctx, nmax_all, C, G, fused, fused && fz_shift_slab(), true, detrend, &w));
+        p.ranks = w.ranks; p.shift = w.shift; p.x_climo = w.x_climo; p.trend_u = w.trend_u;
         p.worklist = w.worklist; p.work_count = w.work_count; p.work_cap = w.work_cap;
         const std::vector<int> glen = group_lengths(gf.host_off, &gp.host_off, G);
         SD_TRY(run_predict_kernels(ctx, p, fused, nmax_all, glen));
@@ -1200,7 +1225,7 @@ int sd_bcsd_state_info(const sd_bcsd_state* st, int* kind, int* G, int64_t* T, i
     if (G) *G = st->G;
     if (T) *T = st->T;
     if (C) *C = st->C;
-    if (return_anoms) *return_anoms = st->return_anoms;
+    if (return_anoms) *return_anoms = (st->return_anoms ? SD_BCSD_RETURN_ANOMS : 0) | (st->detrend ? SD_BCSD_QM_DETREND : 0);
     return SD_OK;
 }
 
@@ -1225,6 +1250,25 @@ int sd_bcsd_state_export(const sd_bcsd_state* st, double* y_sorted, double* x_cl
     if (cell_status) SD_TRY(sd_bcsd_state_status(st, cell_status));
     if (group_offsets)
         for (int g = 0; g <= st->G; ++g) group_offsets[g] = st->goff[g];
+    return SD_OK;
+}
+
+int sd_bcsd_state_get_trend(const sd_bcsd_state* st, double* y_trend) {
+    SD_CHECK_ARG(st && y_trend, "sd_bcsd_state_get_trend: NULL argument");
+    sd_ctx* ctx = st->ctx;
+    SD_HIP(hipSetDevice(ctx->device));
+    SD_HIP(hipMemcpyAsync(y_trend, st->y_trend, sizeof(double) * 2 * st->G * st->C, hipMemcpyDeviceToHost, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_bcsd_state_set_trend(sd_bcsd_state* st, const double* y_trend) {
+    SD_CHECK_ARG(st && y_trend, "sd_bcsd_state_set_trend: NULL argument");
+    SD_CHECK_ARG(st->detrend, "sd_bcsd_state_set_trend: the state was not created with SD_BCSD_QM_DETREND");
+    sd_ctx* ctx = st->ctx;
+    SD_HIP(hipSetDevice(ctx->device));
+    SD_HIP(hipMemcpyAsync(st->y_trend, y_trend, sizeof(double) * 2 * st->G * st->C, hipMemcpyHostToDevice, ctx->stream));
+    SD_HIP(hipStreamSynchronize(ctx->stream));
     return SD_OK;
 }
 

@@ -38,6 +38,12 @@ struct Params {
     int* work_count;  // device counter (items appended, may exceed work_cap: the excess is lost and reported)
     int work_cap;
     int use_worklist;
+    // QuantileMapper(detrend=True) (quantile.py:95-98, 128-145): both series lose their least-squares line over the sample
+    // index before the CDFs; the predict line comes back afterwards, re-based on the fitted intercept.  RANK / APPLY / FIT
+    // only (the fused kernel is bypassed).
+    int detrend;
+    double* trend_u;       // RANK -> APPLY: [C*G][2] slope, intercept of the predict segment's line
+    double* y_trend;       // state [C][G][2]: slope, intercept of the fitted segment's line
     int dev_flags;  // development library only (SD_FZ_ABLATE): phases skipped to time the rest; results are then wrong
 };
 

@@ -110,6 +110,19 @@ __device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (p->detrend) {  // quantile.py:128-132: the series to rank is X minus its own least-squares line
+            double a, b;
+            trend_line<K>(u, m, lane, &a, &b);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = K * lane + i;
+                u[i] = j < m ? u[i] - ((double)j * a + b) : u[i];  // trend.py:65,83
+            }
+            if (lane == 0 && cell_ok) {
+                p->trend_u[2 * seg] = a;
+                p->trend_u[2 * seg + 1] = b;
+            }
+        }
         wave_fence();
         {
             double s[K];
@@ -179,6 +192,7 @@ __device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g
 
     // ---- y: climatology + sorted segment in the wave's row ------------------------------------------
     double yc = 0.0;
+    double icpt_fit = 0.0;  // detrend: intercept of the fitted segment's line
     if (!(MODE == MODE_APPLY && p->from_state)) {
         if (n > 0) {
             load_tile<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, tile, RS, p->status_fit);
@@ -193,6 +207,16 @@ __device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g
                 if (MODE == MODE_FIT) p->y_climo[seg] = yc;
                 if (!kTas && p->return_anoms && yc <= 0.0) atomicOr(&p->status_fit[c], SDI_BAD_CLIMO);  // bcsd.py:140-141
             }
+            if (p->detrend) {  // quantile.py:95-98: the CDF is fitted on y minus its least-squares line
+                double a;
+                trend_line<K>(v, n, lane, &a, &icpt_fit);
+#pragma unroll
+                for (int i = 0; i < K; ++i) v[i] = v[i] - ((double)(K * lane + i) * a + icpt_fit);  // trend.py:65,83
+                if (MODE == MODE_FIT && lane == 0 && cell_ok) {
+                    p->y_trend[2 * seg] = a;
+                    p->y_trend[2 * seg + 1] = icpt_fit;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < K; ++i) v[i] = K * lane + i < n ? v[i] : __builtin_inf();
             wave_fence();
@@ -205,6 +229,7 @@ __device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g
     } else {
         if (cell_ok) {
             yc = p->y_climo[seg];
+            if (p->detrend) icpt_fit = p->y_trend[2 * seg + 1];
             const double* src = p->ys + c * p->Tf + begf;
             for (int i = lane; i < n; i += kWave) row[i] = src[i];
         }
@@ -256,6 +281,13 @@ __device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g
             q[i] = t;
             if ((i + 1) % CH == 0) __builtin_amdgcn_sched_barrier(0);  // keep later samples' loads from piling up
         }
+    }
+
+    if (p->detrend && cell_ok) {  // quantile.py:140-145: the predict line comes back, re-based on the fitted intercept
+        const double a = p->trend_u[2 * seg], b = p->trend_u[2 * seg + 1];
+        const double rebase = b - icpt_fit;
+#pragma unroll
+        for (int i = 0; i < K; ++i) q[i] = (q[i] + ((double)(K * lane + i) * a + b)) - rebase;
     }
 
     // ---- restore the climate-trend shift (bcsd.py:263-267) / ratio anomalies (bcsd.py:170-185) ------

@@ -93,12 +93,14 @@ void sd_pool_trim(sd_ctx* ctx);
 struct sd_bcsd_state {
     sd_ctx* ctx = nullptr;
     int kind = 0, G = 0, return_anoms = 1;
+    int detrend = 0;  // QuantileMapper(detrend=True): ys holds the sorted detrended observations
     int64_t T = 0, C = 0;
     std::vector<int64_t> goff;  // host copy, [G+1]
     int nmax = 0;
     double* ys = nullptr;        // device [C][T] cell-major, group segments back to back
     double* x_climo = nullptr;   // device [C][G]
     double* y_climo = nullptr;   // device [C][G]
+    double* y_trend = nullptr;   // device [C][G][2]: slope, intercept of the fitted segments' least-squares lines (detrend)
     int32_t* status = nullptr;   // device [C] internal bitmask
     int32_t* goff_dev = nullptr; // device [G+1]
 };

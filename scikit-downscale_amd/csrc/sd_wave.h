@@ -34,6 +34,29 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
     return v;
 }
+
+// Least-squares line of a blocked series (lane holds samples j = K * lane + i, valid while j < n) on j = 0 .. n-1:
+// trend.py:51 (LinearRegression on np.arange(len(X))); centred sums like sklearn's _preprocess_data + lstsq.
+template <int K>
+__device__ __forceinline__ void trend_line(const double (&v)[K], int n, int lane, double* slope, double* icpt) {
+    const double tbar = 0.5 * (double)(n - 1);
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) s += K * lane + i < n ? v[i] : 0.0;
+    const double vbar = wave_sum(s) / (double)n;
+    double sxy = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const int j = K * lane + i;
+        sxy += j < n ? ((double)j - tbar) * (v[i] - vbar) : 0.0;
+    }
+    sxy = wave_sum(sxy);
+    const double dn = (double)n;
+    const double sxx = dn * (dn * dn - 1.0) / 12.0;
+    const double a = n > 1 ? sxy / sxx : 0.0;
+    *slope = a;
+    *icpt = vbar - a * tbar;
+}
 // Lanes of one wave exchange data through LDS inside the sort.  The hardware serves a wave's LDS
 // requests in order; for the compiler the exchange needs a wavefront-scope fence plus the wave barrier.
 __device__ __forceinline__ void wave_fence() {

@@ -9,6 +9,7 @@ from .gard import AnalogGridModel, AnalogRegression, PureAnalog, PureRegression,
 from .groupers import DAY_GROUPER, MONTH_GROUPER, PaddedDOYGrouper
 from .quantile import (CunnaneGridModel, CunnaneTransformer, EquidistantCdfMatcher, QmGridModel, QuantileMapper,
                        QuantileMapperGridModel, QuantileMappingReressor)
+from .trend import LinearTrendTransformer
 
 __all__ = [
     "AnalogRegression",
@@ -31,6 +32,7 @@ __all__ = [
     "CunnaneGridModel",
     "QuantileMapperGridModel",
     "PureRegression",
+    "LinearTrendTransformer",
     "RegressionGridModel",
 ]
 __version__ = "0.1.0"

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("SD_DOWNSCALE_LIB", os.path.join(os.path.dirname(_HERE
 
 SD_OK = 0
 BCSD_TAS, BCSD_PR = 0, 1
+BCSD_RETURN_ANOMS, BCSD_QM_DETREND = 1, 2  # bits of the `return_anoms` argument of the fit entry points
 CELL_OK, CELL_MASKED, CELL_NONFINITE, CELL_BAD_CLIMO, CELL_ONE_CLASS = 0, 1, 2, 3, 4
 ANALOG_BEST, ANALOG_SAMPLE, ANALOG_WEIGHT, ANALOG_MEAN = 0, 1, 2, 3
 QM_REGRESSOR, QM_EDCDF_DIFFERENCE, QM_EDCDF_RATIO = 0, 1, 2
@@ -64,6 +65,8 @@ SIGNATURES = {
     "sd_bcsd_state_status": [_p, _p],
     "sd_bcsd_state_export": [_p, _p, _p, _p, _p, _p],
     "sd_bcsd_state_import": [_p, _int, _int, _i64, _i64, _int, _p, _p, _p, _p, _p, C.POINTER(_p)],
+    "sd_bcsd_state_get_trend": [_p, _p],
+    "sd_bcsd_state_set_trend": [_p, _p],
     "sd_bcsd_state_destroy": [_p],
     "sd_analog_fit": [_p, _p, _p, _i64, _int, _i64, C.POINTER(_p)],
     "sd_analog_fit_dev": [_p, _p, _p, _i64, _i64, _int, _i64, C.POINTER(_p)],

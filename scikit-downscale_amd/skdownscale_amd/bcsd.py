@@ -21,6 +21,7 @@ from . import _lib
 from .base import TimeSynchronousDownscaler
 from .engine import DeviceArray, default_context
 from .groupers import DAY_GROUPER, MONTH_GROUPER, PaddedDOYGrouper, group_keys, padded_doy_table
+from .trend import FittedLine, FittedTrend
 
 Cdf = collections.namedtuple("Cdf", ["pp", "vals"])  # quantile.py:20
 FittedCunnane = collections.namedtuple("FittedCunnane", ["cdf_"])
@@ -37,8 +38,11 @@ class _FittedQuantileMapper:
     """Read-only stand-in for the reference's per-group ``QuantileMapper`` (quantile.py:46-157):
     exposes ``x_cdf_fit_.cdf_`` = (plotting positions, sorted values)."""
 
-    def __init__(self, vals):
+    def __init__(self, vals, trend=None):
         self.x_cdf_fit_ = FittedCunnane(Cdf(plotting_positions(len(vals)), vals))
+        self.detrend = trend is not None
+        if trend is not None:  # quantile.py:97: the fitted line of the (group's) series over its sample index
+            self.x_trend_fit_ = FittedTrend(FittedLine(np.array([[trend[0]]]), np.array([trend[1]])))
 
 
 def check_supported(model):
@@ -53,8 +57,8 @@ def check_supported(model):
     extra = set(qm) - {"detrend", "lt_kwargs", "qt_kwargs"}
     if extra:
         raise TypeError(f"QuantileMapper.__init__() got an unexpected keyword argument {sorted(extra)[0]!r}")
-    if qm.get("detrend", False):
-        raise NotImplementedError("QuantileMapper(detrend=True) is not supported on the HIP engine")
+    if qm.get("detrend", False) and (qm.get("lt_kwargs") or {}).get("lr_kwargs"):
+        raise NotImplementedError("LinearTrendTransformer(lr_kwargs=...): only the LinearRegression defaults run on the HIP engine")
     qt = qm.get("qt_kwargs") or {}
     for k, v in qt.items():
         if k not in _QT_DEFAULTS:
@@ -72,9 +76,11 @@ class BcsdGridModel:
     (bcsd.py:247-250).  ``day_grouper`` (``climate_trend_grouper``): what the daily time step groups by in predict
     (bcsd.py:51-53) -- its keys select fitted day-of-year groups, which is the reference's behaviour."""
 
-    def __init__(self, kind, return_anoms=True, grouper=MONTH_GROUPER, ctx=None, trend_grouper=None, day_grouper=DAY_GROUPER):
+    def __init__(self, kind, return_anoms=True, grouper=MONTH_GROUPER, ctx=None, trend_grouper=None, day_grouper=DAY_GROUPER,
+                 detrend=False):
         self.kind = kind
         self.return_anoms = bool(return_anoms)
+        self.detrend = bool(detrend)  # qm_kwargs={'detrend': True}: quantile.py:95-98, 128-145 per group
         self.grouper = grouper
         self.trend_grouper = grouper if trend_grouper is None else trend_grouper
         self.day_grouper = day_grouper
@@ -103,10 +109,10 @@ class BcsdGridModel:
             if (np.diff(offsets) == 0).any():  # QuantileMapper.fit on an empty group (bcsd.py:66-67 -> sklearn check_array)
                 raise ValueError("Found array with 0 sample(s) (shape=(0, 1)) while a minimum of 1 is required by QuantileMapper.")
             self.keys = np.arange(1, 367)
-            self.state = self.ctx.bcsd_fit_groups(self.kind, X, y, order, offsets, self.return_anoms)
+            self.state = self.ctx.bcsd_fit_groups(self.kind, X, y, order, offsets, self.return_anoms, detrend=self.detrend)
         else:
             gid = self.group_ids_fit(index)
-            self.state = self.ctx.bcsd_fit(self.kind, X, y, gid, len(self.keys), self.return_anoms)
+            self.state = self.ctx.bcsd_fit(self.kind, X, y, gid, len(self.keys), self.return_anoms, detrend=self.detrend)
         self.status_ = self.state.status()
         return self
 
@@ -162,7 +168,7 @@ class BcsdBase(TimeSynchronousDownscaler):
 
     def _new_grid(self):
         return BcsdGridModel(self._kind, self.return_anoms, self.time_grouper, trend_grouper=self.climate_trend,
-                             day_grouper=self.climate_trend_grouper)
+                             day_grouper=self.climate_trend_grouper, detrend=bool((self.qm_kwargs or {}).get("detrend", False)))
 
     def _fit_engine(self, X2, y2, index):
         self._pre_fit()
@@ -181,7 +187,9 @@ class BcsdBase(TimeSynchronousDownscaler):
         if self._kind == _lib.BCSD_TAS:
             self._x_climo = pd.DataFrame(exported["x_climo"][c].reshape(-1, 1), index=keys)  # bcsd.py:222
         ys = exported["y_sorted"][c]
-        self.quantile_mappers_ = {k: _FittedQuantileMapper(ys[off[g]:off[g + 1]]) for g, k in enumerate(keys)}
+        trend = exported.get("y_trend")
+        self.quantile_mappers_ = {k: _FittedQuantileMapper(ys[off[g]:off[g + 1]], None if trend is None else trend[c, g])
+                                  for g, k in enumerate(keys)}
 
     def _require_fitted(self):
         if not hasattr(self, "y_climo_"):
@@ -202,10 +210,14 @@ class BcsdBase(TimeSynchronousDownscaler):
         vals = [self.quantile_mappers_[k].x_cdf_fit_.cdf_.vals for k in keys]
         off = np.concatenate([[0], np.cumsum([len(v) for v in vals])]).astype(np.int64)
         T = int(off[-1])
-        info = dict(kind=self._kind, G=len(keys), T=T, C=1, return_anoms=bool(self.return_anoms))
+        detrend = bool((self.qm_kwargs or {}).get("detrend", False))
+        info = dict(kind=self._kind, G=len(keys), T=T, C=1, return_anoms=bool(self.return_anoms), detrend=detrend)
         xc = self._x_climo.values.reshape(1, -1) if self._kind == _lib.BCSD_TAS else np.zeros((1, len(keys)))
         exported = dict(info=info, y_sorted=np.concatenate(vals).reshape(1, T), x_climo=xc,
                         y_climo=self.y_climo_.values.reshape(1, -1), status=np.zeros(1, np.int32), group_offsets=off)
+        if detrend:
+            lines = [self.quantile_mappers_[k].x_trend_fit_.lr_model_ for k in keys]
+            exported["y_trend"] = np.array([[float(np.ravel(l.coef_)[0]), float(np.ravel(l.intercept_)[0])] for l in lines]).reshape(1, -1, 2)
         grid = self._new_grid()
         grid.keys = keys
         grid.state = grid.ctx.bcsd_import(exported)

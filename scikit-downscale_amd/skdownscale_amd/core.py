@@ -370,7 +370,7 @@ class PointWiseDownscaler:
                 if kind == "cunnane":
                     raise ValueError("CunnaneTransformer.fit() only supports a single feature")
                 raise ValueError(f"Found array with {F} features (shape=({T}, {F})) while a maximum of 1 is required")
-            gm = (CunnaneGridModel(m.extrapolate, m.n_endpoints) if kind == "cunnane" else QuantileMapperGridModel()).fit(Xv[:, 0, :])
+            gm = (CunnaneGridModel(m.extrapolate, m.n_endpoints) if kind == "cunnane" else QuantileMapperGridModel(detrend=m.detrend)).fit(Xv[:, 0, :])
             gm.status_ = gm.state.export(with_y=False)["status"] if kind == "cunnane" else gm.status_
             self._raise_for_status(gm.status_, Xv[:, 0, :], Xv[:, 0, :])
             self._models = _BatchedModels(kind, gm, mask, spatial_dims, spatial_shape, coords)
@@ -629,6 +629,10 @@ class PointWiseDownscaler:
             est = copy.deepcopy(m)
             vals = e["y_sorted"][c]
             est.x_cdf_fit_ = FittedCunnane(Cdf(plotting_positions(len(vals)), vals))
+            if est.detrend:
+                from .trend import FittedLine, FittedTrend
+
+                est.x_trend_fit_ = FittedTrend(FittedLine(np.array([[e["y_trend"][c, 0, 0]]]), np.array([e["y_trend"][c, 0, 1]])))
             est.n_features_in_ = 1
             return est
         raise NotImplementedError(f"get_attr is not available for {mdl.kind} grids")

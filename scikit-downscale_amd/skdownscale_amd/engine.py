@@ -98,7 +98,8 @@ class BcsdState(_State):
         kind, G, ra = C.c_int(), C.c_int(), C.c_int()
         T, Cc = C.c_int64(), C.c_int64()
         check(self.ctx.lib.sd_bcsd_state_info(self.vptr, C.byref(kind), C.byref(G), C.byref(T), C.byref(Cc), C.byref(ra)))
-        return dict(kind=kind.value, G=G.value, T=T.value, C=Cc.value, return_anoms=bool(ra.value))
+        return dict(kind=kind.value, G=G.value, T=T.value, C=Cc.value, return_anoms=bool(ra.value & _lib.BCSD_RETURN_ANOMS),
+                    detrend=bool(ra.value & _lib.BCSD_QM_DETREND))
 
     def status(self):
         st = np.empty(self.info()["C"], dtype=np.int32)
@@ -113,7 +114,11 @@ class BcsdState(_State):
         st = np.empty(i["C"], dtype=np.int32)
         off = np.empty(i["G"] + 1, dtype=np.int64)
         check(self.ctx.lib.sd_bcsd_state_export(self.vptr, ptr(ys), ptr(xc), ptr(yc), ptr(st), ptr(off)))
-        return dict(info=i, y_sorted=ys, x_climo=xc, y_climo=yc, status=st, group_offsets=off)
+        e = dict(info=i, y_sorted=ys, x_climo=xc, y_climo=yc, status=st, group_offsets=off)
+        if i["detrend"]:  # slope, intercept of every fitted segment's line (quantile.py:97)
+            e["y_trend"] = np.empty((i["C"], i["G"], 2))
+            check(self.ctx.lib.sd_bcsd_state_get_trend(self.vptr, ptr(e["y_trend"])))
+        return e
 
 
 class AnalogState(_State):
@@ -260,8 +265,14 @@ class Context:
             raise ValueError(f"{name}: group ids must lie in [0, {G})")
         return gid
 
-    def bcsd_fit(self, kind, X, y, gid, G, return_anoms=True):
-        """X, y: numpy [T,C] (host path) or DeviceArray [T,C] (resident path); X may be None for PR."""
+    @staticmethod
+    def _bcsd_options(return_anoms, detrend):
+        return (_lib.BCSD_RETURN_ANOMS if return_anoms else 0) | (_lib.BCSD_QM_DETREND if detrend else 0)
+
+    def bcsd_fit(self, kind, X, y, gid, G, return_anoms=True, detrend=False):
+        """X, y: numpy [T,C] (host path) or DeviceArray [T,C] (resident path); X may be None for PR.  ``detrend``:
+        qm_kwargs={'detrend': True} (quantile.py:95-98,128-145)."""
+        return_anoms = self._bcsd_options(return_anoms, detrend)
         y = self._field2("y", y)
         X = self._field2("X", X, *y.shape)
         if X is not None and isinstance(X, DeviceArray) != isinstance(y, DeviceArray):
@@ -280,9 +291,10 @@ class Context:
             check(self.lib.sd_bcsd_fit(self.handle, kind, ptr(X), ptr(y), ptr(gid), G, T, Cc, int(return_anoms), C.byref(h)))
         return BcsdState(self, h.value, self.lib.sd_bcsd_state_destroy)
 
-    def bcsd_fit_groups(self, kind, X, y, order, offsets, return_anoms=True):
+    def bcsd_fit_groups(self, kind, X, y, order, offsets, return_anoms=True, detrend=False):
         """Fit on explicitly listed (possibly overlapping) groups: ``order`` = time indices group by group,
         ``offsets[G+1]`` (time_grouper='daily_nasa-nex': bcsd.py:36-38,50-55)."""
+        return_anoms = self._bcsd_options(return_anoms, detrend)
         y = self._field2("y", y)
         X = self._field2("X", X, *y.shape)
         T, Cc = y.shape
@@ -339,8 +351,9 @@ class Context:
             check(self.lib.sd_bcsd_predict(self.handle, state.vptr, ptr(Xp), ptr(gid_p), Tp, ptr(out), ptr(status)))
         return out, status
 
-    def bcsd_fit_predict(self, kind, X, y, gid, G, Xp, gid_p, return_anoms=True, out=None):
+    def bcsd_fit_predict(self, kind, X, y, gid, G, Xp, gid_p, return_anoms=True, out=None, detrend=False):
         """Fused resident path (DeviceArrays only)."""
+        return_anoms = self._bcsd_options(return_anoms, detrend)
         y = self._field2("y", y)
         X = self._field2("X", X, *y.shape)
         Xp = self._field2("Xp", Xp, None, y.shape[1])
@@ -361,10 +374,17 @@ class Context:
         i = exported["info"]
         h = C.c_void_p()
         check(self.lib.sd_bcsd_state_import(
-            self.handle, i["kind"], i["G"], i["T"], i["C"], int(i["return_anoms"]), ptr(_lib.as_f64(exported["y_sorted"])),
+            self.handle, i["kind"], i["G"], i["T"], i["C"], self._bcsd_options(i["return_anoms"], i.get("detrend", False)),
+            ptr(_lib.as_f64(exported["y_sorted"])),
             ptr(_lib.as_f64(exported["x_climo"])), ptr(_lib.as_f64(exported["y_climo"])), ptr(_lib.as_i32(exported["status"])),
             ptr(np.ascontiguousarray(exported["group_offsets"], dtype=np.int64)), C.byref(h)))
-        return BcsdState(self, h.value, self.lib.sd_bcsd_state_destroy)
+        st = BcsdState(self, h.value, self.lib.sd_bcsd_state_destroy)
+        if i.get("detrend", False):
+            trend = _lib.as_f64(exported["y_trend"])
+            if trend.shape != (i["C"], i["G"], 2):
+                raise ValueError(f"y_trend: expected shape {(i['C'], i['G'], 2)}, got {trend.shape}")
+            check(self.lib.sd_bcsd_state_set_trend(st.vptr, ptr(trend)))
+        return st
 
     # ---- quantile-mapping regressors ----
     def qm_fit(self, X, y=None):

@@ -18,6 +18,7 @@ from sklearn.utils import check_array
 
 from . import _lib
 from .engine import default_context
+from .trend import FittedLine, FittedTrend
 
 Cdf = collections.namedtuple("Cdf", ["pp", "vals"])  # quantile.py:20
 
@@ -45,9 +46,11 @@ FittedCunnane = collections.namedtuple("FittedCunnane", ["cdf_"])
 
 
 class QuantileMapper(TransformerMixin, BaseEstimator):
-    """Transform features using quantile mapping (quantile.py:46-157), ``detrend=False`` and default ``qt_kwargs``:
+    """Transform features using quantile mapping (quantile.py:46-157), default ``qt_kwargs`` / ``lt_kwargs``:
     ``transform(X)`` ranks X within itself (Cunnane plotting positions of its own sorted values, np.interp exact-hit
     rule) and maps the positions through the CDF of the data seen in ``fit`` (10-point OLS tails when X is longer).
+    ``detrend=True`` (quantile.py:95-98, 128-145): both series lose their least-squares line over the sample index first;
+    the line of the transformed series comes back afterwards, re-based on the fitted intercept (``x_trend_fit_``).
     This is the mapping BCSD applies per month (bcsd.py:59-79); here the whole series is one group."""
 
     _fit_attributes = ["x_cdf_fit_"]
@@ -58,8 +61,8 @@ class QuantileMapper(TransformerMixin, BaseEstimator):
         self.qt_kwargs = qt_kwargs
 
     def _check(self):
-        if self.detrend:
-            raise NotImplementedError("QuantileMapper(detrend=True) is not supported on the HIP engine")
+        if self.detrend and self.lt_kwargs:
+            raise NotImplementedError("QuantileMapper(lt_kwargs=...): only the LinearTrendTransformer defaults run on the HIP engine")
         if self.qt_kwargs:
             raise NotImplementedError("QuantileMapper(qt_kwargs=...): only the CunnaneTransformer defaults run on the HIP engine")
 
@@ -69,11 +72,27 @@ class QuantileMapper(TransformerMixin, BaseEstimator):
         X = check_max_features(X, n=1)
         Xv = np.asarray(X, dtype=np.float64).reshape(-1, 1)
         ctx = default_context()
-        self._state = ctx.bcsd_fit(_lib.BCSD_PR, None, Xv, np.zeros(len(Xv), dtype=np.int32), 1, False)
-        vals = self._state.export()["y_sorted"][0]
+        self._state = ctx.bcsd_fit(_lib.BCSD_PR, None, Xv, np.zeros(len(Xv), dtype=np.int32), 1, False, detrend=bool(self.detrend))
+        e = self._state.export()
+        vals = e["y_sorted"][0]
         self.x_cdf_fit_ = FittedCunnane(Cdf(plotting_positions(len(vals)), vals))
+        if self.detrend:
+            slope, icpt = e["y_trend"][0, 0]
+            self.x_trend_fit_ = FittedTrend(FittedLine(np.array([[slope]]), np.array([icpt])))
         self.n_features_in_ = 1
         return self
+
+    def _rebuild_state(self, ctx):
+        """device state from the fitted attributes (after unpickling)"""
+        vals = np.asarray(self.x_cdf_fit_.cdf_.vals, dtype=np.float64)
+        n = len(vals)
+        exported = dict(info=dict(kind=_lib.BCSD_PR, G=1, T=n, C=1, return_anoms=False, detrend=bool(self.detrend)),
+                        y_sorted=vals.reshape(1, n), x_climo=np.zeros((1, 1)), y_climo=np.array([[vals.mean()]]),
+                        status=np.zeros(1, np.int32), group_offsets=np.array([0, n], dtype=np.int64))
+        if self.detrend:
+            line = self.x_trend_fit_.lr_model_
+            exported["y_trend"] = np.array([float(np.ravel(line.coef_)[0]), float(np.ravel(line.intercept_)[0])]).reshape(1, 1, 2)
+        return ctx.bcsd_import(exported)
 
     def transform(self, X):
         if not hasattr(self, "x_cdf_fit_"):
@@ -83,8 +102,7 @@ class QuantileMapper(TransformerMixin, BaseEstimator):
         Xv = np.asarray(X, dtype=np.float64)[:, :1]
         ctx = default_context()
         if getattr(self, "_state", None) is None:  # unpickled: rebuild the device state from the fitted CDF
-            n = len(self.x_cdf_fit_.cdf_.vals)
-            self._state = ctx.bcsd_fit(_lib.BCSD_PR, None, self.x_cdf_fit_.cdf_.vals.reshape(n, 1), np.zeros(n, dtype=np.int32), 1, False)
+            self._state = self._rebuild_state(ctx)
         out, _ = ctx.bcsd_predict(self._state, np.ascontiguousarray(Xv), np.zeros(len(Xv), dtype=np.int32))
         return out
 
@@ -207,16 +225,17 @@ class CunnaneGridModel:
 
 
 class QuantileMapperGridModel:
-    """Batched QuantileMapper (``detrend=False``) over the cell axis: the BCSD kernels with the whole series of a cell as
-    one group (quantile.py:81-147 per cell).  X [T, C] numpy or DeviceArray."""
+    """Batched QuantileMapper over the cell axis: the BCSD kernels with the whole series of a cell as one group
+    (quantile.py:81-147 per cell).  X [T, C] numpy or DeviceArray."""
 
-    def __init__(self, ctx=None):
+    def __init__(self, ctx=None, detrend=False):
         self.ctx = ctx or default_context()
+        self.detrend = bool(detrend)
         self.state = None
 
     def fit(self, X):
         T = X.shape[0]
-        self.state = self.ctx.bcsd_fit(_lib.BCSD_PR, None, X, np.zeros(T, dtype=np.int32), 1, False)
+        self.state = self.ctx.bcsd_fit(_lib.BCSD_PR, None, X, np.zeros(T, dtype=np.int32), 1, False, detrend=self.detrend)
         self.status_ = self.state.status()
         return self
 

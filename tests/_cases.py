@@ -52,6 +52,21 @@ def nasanex_inputs(g, case):
     return index, index_p, tas, pr
 
 
+def detrend_inputs(g):
+    """inputs of tests/golden/g15_detrend.npz (make_golden.py:g15_detrend): drifting tas fields and their positive twins"""
+    import pandas as pd
+
+    index = pd.date_range(str(g["start"]), str(g["end"]))
+    index_p = pd.date_range(str(g["pstart"]), str(g["pend"]))
+    cells = np.arange(int(g["C"]))
+    T, Tp = len(index), len(index_p)
+    drift, drift_p = 2e-4 * np.arange(T)[:, None] * (1 + cells), 5e-4 * np.arange(Tp)[:, None] * (1 + cells)
+    X = synth.tas_field("X_hist", 22, index, cells, 1000) + drift
+    y = synth.tas_field("y_obs", 22, index, cells, 1000) + 0.5 * drift
+    Xp = synth.tas_field("X_fut", 22, index_p, cells, 1000) + drift_p
+    return index, index_p, (X, y, Xp), (np.abs(X) + 0.1, np.abs(y) + 0.1, np.abs(Xp) + 0.1)
+
+
 def analog_inputs(g):
     T, Tq, C, F, seed, c_full = (int(g[k]) for k in ("T", "Tq", "C", "F", "seed", "c_full"))
     return synth.analog_fields(seed, T, np.arange(C), c_full, n_query=Tq, n_features=F)

@@ -77,7 +77,8 @@ def test_unsupported_configurations_raise():
     from skdownscale_amd.groupers import DAY_GROUPER
 
     check_supported(BcsdTemperature(climate_trend=DAY_GROUPER))
-    for bad in (BcsdTemperature(time_grouper="M"), BcsdTemperature(qm_kwargs={"detrend": True}),
+    check_supported(BcsdTemperature(qm_kwargs={"detrend": True}))
+    for bad in (BcsdTemperature(time_grouper="M"), BcsdTemperature(qm_kwargs={"detrend": True, "lt_kwargs": {"lr_kwargs": {"fit_intercept": False}}}),
                 BcsdTemperature(qm_kwargs={"qt_kwargs": {"extrapolate": None}})):
         with pytest.raises(NotImplementedError):
             check_supported(bad)

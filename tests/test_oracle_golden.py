@@ -227,6 +227,35 @@ def test_bcsd_daily_nasanex_and_separate_trend_grouper():
             assert_close(out, g[f"pr_out{case}"][:, c], what=f"daily pr case {case} cell {c}")
 
 
+def test_detrended_quantile_mapping():
+    """g15_detrend.npz (from the reference): QuantileMapper(detrend=True) on whole series (quantile.py:95-98,128-145), and
+    BCSD with qm_kwargs={'detrend': True} per month / per padded day-of-year group (bcsd.py:65-67)."""
+    from _cases import detrend_inputs
+
+    g = load("g15_detrend")
+    index, index_p, (X, y, Xp), (P, yP, Pp) = detrend_inputs(g)
+    C = X.shape[1]
+    for name, A, B in (("short", X, Xp), ("long", y, Xp)):
+        A, B = A[:int(g[f"qmap_{name}_nfit"])], B[:int(g[f"qmap_{name}_n"])]
+        for c in range(C):
+            st, _ = bo.bcsd_fit_cell(bo.PR, None, A[:, c], np.zeros(len(A), dtype=int), G=1, return_anoms=False, detrend=True)
+            np.testing.assert_allclose(st["ys"], g[f"qmap_{name}_cdf"][:, c], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(st["y_trend_icpt"][0], g[f"qmap_{name}_line"][c, 1], rtol=1e-10)
+            out, _ = bo.bcsd_predict_cell(st, B[:, c], np.zeros(len(B), dtype=int), return_anoms=False)
+            assert_close(out, g[f"qmap_{name}_out"][:, c], what=f"QuantileMapper(detrend) {name} cell {c}")
+    gid, gid_p = bo.month_group_id(index), bo.month_group_id(index_p)
+    for ra in (True, False):
+        out, _ = bo.pointwise_fit_predict(bo.TAS, X, y, Xp, gid, gid_p, return_anoms=ra, detrend=True)
+        assert_close(out, g[f"tas_out_anoms{int(ra)}"], what=f"tas detrend anoms={ra}")
+        out, _ = bo.pointwise_fit_predict(bo.PR, P, yP, Pp, gid, gid_p, return_anoms=ra, detrend=True)
+        assert_close(out, g[f"pr_out_anoms{int(ra)}"], what=f"pr detrend anoms={ra}")
+    table = bo.padded_doy_table(index)
+    for c in range(C):
+        st, _ = bo.bcsd_fit_cell(bo.TAS, X[:, c], y[:, c], None, table=table, return_anoms=False, detrend=True)
+        out, _ = bo.bcsd_predict_trend_cell(st, Xp[:, c], np.asarray(index_p.day) - 1, np.asarray(index_p.month) - 1, return_anoms=False)
+        assert_close(out, g["tas_nasanex_out"][:, c], what=f"daily_nasa-nex detrend cell {c}")
+
+
 PROB_TIGHT = 1e-6    # exceedance probability vs the reference's objective solved tightly (logistic_kwargs tol=1e-12)
 PROB_DEFAULT = 1e-3  # ... vs the reference's default LogisticRegression: its L-BFGS stops at tol=1e-4, within ~2e-4 of the optimum
 
