@@ -85,11 +85,14 @@ __global__ void __launch_bounds__(256) analog_transpose_kernel(const double* __r
 }
 
 // cell-major staging [C][3][Tq] -> output field [Tq, 3, ld] through a 32x33 LDS tile (grid: cells/32, Tq/32, 3)
+// prob_from_pred: the probability plane of the staging buffer was not written; the column is 1 where the prediction is
+// not NaN (no threshold: gard.py:346), NaN where it is
 __global__ void __launch_bounds__(256) analog_untranspose_kernel(const double* __restrict__ oc, int64_t Tq, int64_t C,
-                                                                 double* __restrict__ out, int64_t ld) {
+                                                                 double* __restrict__ out, int64_t ld, int prob_from_pred) {
     __shared__ double tile[32][33];
     const int64_t c0 = (int64_t)blockIdx.x * 32, t0 = (int64_t)blockIdx.y * 32;
-    const int j = blockIdx.z, tx = threadIdx.x % 32, ty = threadIdx.x / 32;
+    const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;
+    const int j = prob_from_pred ? 2 * (int)blockIdx.z : (int)blockIdx.z;  // grid z: 2 planes (pred [+ prob], err) or all 3
     for (int r = ty; r < 32; r += 8) {
         const int64_t c = c0 + r, t = t0 + tx;
         tile[r][tx] = (c < C && t < Tq) ? oc[(c * 3 + j) * Tq + t] : 0.0;
@@ -97,7 +100,11 @@ __global__ void __launch_bounds__(256) analog_untranspose_kernel(const double* _
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int64_t t = t0 + r, c = c0 + tx;
-        if (t < Tq && c < C) out[(t * 3 + j) * ld + c] = tile[tx][r];
+        if (t < Tq && c < C) {
+            const double v = tile[tx][r];
+            out[(t * 3 + j) * ld + c] = v;
+            if (prob_from_pred && j == 0) out[(t * 3 + 1) * ld + c] = v != v ? v : 1.0;
+        }
     }
 }
 
@@ -182,9 +189,19 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         const double* x = Xc + c * x_stride;
         __syncthreads();
-        for (int i = tid; i <= np; i += nthr) {  // coalesced load, blocked read below
-            const double xv = i < n ? x[i] : inf;
-            buf[i] = (i < n && !sd_finite(xv)) ? 0.0 : xv;
+        {
+            // coalesced load (all K + 1 requests of a thread in flight together), blocked read below
+            double xv[K + 1];
+#pragma unroll
+            for (int t = 0; t <= K; ++t) {
+                const int i = tid + t * nthr;
+                xv[t] = i < n ? x[i] : inf;
+            }
+#pragma unroll
+            for (int t = 0; t <= K; ++t) {
+                const int i = tid + t * nthr;
+                if (i <= np) buf[i] = (i < n && !sd_finite(xv[t])) ? 0.0 : xv[t];
+            }
         }
         __syncthreads();
         double v[K], orig[K];
@@ -289,6 +306,7 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
         for (int w = 0; w < 16; ++w) tot += red[w];
         const double ybar = tot / (double)n;
         if (tid == 0) ybar_all[c] = ybar;
+        if (pq_all == nullptr) continue;  // the prefix sums are built when a kernel first needs them (ensure_prefix_sums)
         double a = 0.0, b = 0.0;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
@@ -380,7 +398,8 @@ int sort2_width(int64_t T, size_t lds_max) {
 // then cost two 16-byte loads (centring keeps the running sums small: no cancellation for the differences).
 // One 1024-thread workgroup per cell: serial partial sums per thread, wave shuffles + LDS for the offsets.
 __global__ void __launch_bounds__(1024) analog_prefix_kernel(const double* __restrict__ yx_all, int64_t T, int64_t C,
-                                                             double* __restrict__ pq_all, double* __restrict__ ybar_all) {
+                                                             double* __restrict__ pq_all, double* __restrict__ ybar_all,
+                                                             int keep_ybar /* 1: centre on the ybar_all given */) {
     __shared__ double wsum[2][16];
     const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int per = (n + nthr - 1) / nthr;  // consecutive elements per thread
@@ -398,8 +417,8 @@ __global__ void __launch_bounds__(1024) analog_prefix_kernel(const double* __res
         __syncthreads();
         double tot = 0.0;
         for (int w = 0; w < 16; ++w) tot += wsum[0][w];
-        const double ybar = tot / (double)n;
-        if (tid == 0) ybar_all[c] = ybar;
+        const double ybar = keep_ybar ? ybar_all[c] : tot / (double)n;
+        if (tid == 0 && !keep_ybar) ybar_all[c] = ybar;
         // per-thread totals of d and d^2, exclusive scan across the workgroup
         double a = 0.0, b = 0.0;
         for (int i = beg; i < end; ++i) {
@@ -1306,62 +1325,165 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
     }
 }
 
-// F == 1, PureAnalog 'mean_analogs' without a threshold (the BASELINE configuration) or a single analog: the same answer as
-// analog_f1_mean_kernel with the prefix sums staged through LDS as well.  The two 16-byte prefix loads of a query land
-// on random sectors, and reading them from memory made that kernel move 4x its compulsory bytes (PMC: 32.7 GB fetched
-// per 16 384 cells).  Here a thread keeps the window starts of its (up to kPhQ) queries in registers and the LDS array
-// is filled three times per cell -- sorted values (search), then the first, then the second prefix component --
-// so every byte is fetched once, coalesced.
+// F == 1, PureAnalog 'mean_analogs' without a threshold (the BASELINE configuration) or a single analog.  One 1024-thread
+// workgroup per cell; a thread keeps the window starts of its (up to kPhQ) queries in registers and the LDS array
+// (n + 1 doubles: all the LDS a workgroup can have at the BASELINE length) is filled three times per cell:
+//   1. sorted training values: every query finds its window of k nearest values (two branch-free bisections: position
+//      among the values, then window start among the k + 1 candidates), windows with a tie on their boundary take the
+//      exact walk;
+//   2. exclusive prefix sums of the centred analog values d = yx - mean(y), computed here from yx (blocked partial sums,
+//      wave scans) -> window means;
+//   3. exclusive prefix sums of d^2 -> spreads.
+// Every byte of the state is fetched once, coalesced: xs and yx (8 + 8 bytes per training sample; the fitted state holds
+// no prefix sums for this path).  The workgroup is alone on its CU (LDS), so nothing would overlap its memory phases with
+// its LDS phases: each thread therefore touches one word per 64-byte piece of what a later phase will read (yx during
+// the search, the next cell's xs and queries during the prefix phases) so that the fills find their lines in L2; the
+// touches are issued behind every load the phase itself waits for (loads return in order).
+// With skip_prob the exceedance-probability column is not written: it is 1 wherever the prediction is not NaN
+// (gard.py:346) and the staging transpose fills it in.
 constexpr int kPhQ = 16;  // queries per thread and LDS generation (1024 threads: series up to 16 384 queries per pass)
+
+// One word of every 64-byte piece of [p, p + n doubles), n <= 3 * 8 * 1024: the loads stay where they are written
+// (volatile) and their values are handed to touch_done() later, so that nothing waits for them in between.
+struct Touch {
+    unsigned w[3];
+};
+__device__ __forceinline__ Touch touch_lines(const double* p, int n, int tid, int nthr, bool on) {
+    Touch t;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = (tid + j * nthr) * 8;
+        t.w[j] = 0u;
+        if (on && i < n) t.w[j] = *reinterpret_cast<const volatile unsigned*>(p + i);
+    }
+    return t;
+}
+__device__ __forceinline__ void touch_done(const Touch& t, int32_t* status) {
+    if ((t.w[0] & t.w[1] & t.w[2]) == 0xdead0beeu && (t.w[0] ^ t.w[1]) == 0x12345u) atomicOr(status, 0);  // never met: keeps the loads
+}
+
+// a wave-uniform double, pinned to scalar registers (the allocator otherwise keeps such values in vector registers and,
+// in this kernel, spills them)
+__device__ __forceinline__ double uniform_f64(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+typedef __attribute__((address_space(1))) double global_f64;  // (pointers that travel inside PredictArgs are generic otherwise)
+
+// x / k for an integer-valued k with rk = RN(1 / k): quotient estimate, exact remainder, one correction (correctly rounded;
+// the hardware-assisted IEEE division costs ~10x as many instructions and this kernel needs two per query)
+__device__ __forceinline__ double div_by(double x, double kk, double rk) {
+    const double q = x * rk;
+    const double r = __builtin_fma(-q, kk, x);
+    return __builtin_fma(r, rk, q);
+}
+
+template <int PER>
 __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __restrict__ Xq /* [C][Tq] */, int64_t Tq, int64_t T,
                                                                int64_t C, const double* __restrict__ xs_all,
                                                                const int32_t* __restrict__ xi_all,
-                                                               const double* __restrict__ pq_all,
                                                                const double* __restrict__ ybar_all,
                                                                const double* __restrict__ yx_all, const double* __restrict__ Xc,
                                                                const double* __restrict__ yc,
                                                                const int32_t* __restrict__ fit_status, int32_t* status,
-                                                               double* scratch_d, int32_t* scratch_i, PredictArgs pa) {
+                                                               double* scratch_d, int32_t* scratch_i, PredictArgs pa, int skip_prob,
+                                                               long long* trace /* development library: phase clocks of block 0 */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ double wsum[16];
     double* buf = reinterpret_cast<double*>(smem_raw);  // n + 1 doubles
-    const int nthr = blockDim.x, tid = threadIdx.x;
+    const int nthr = blockDim.x;
     const int n = (int)T, k = pa.k;
+    const int per = (n + nthr - 1) / nthr;  // consecutive samples per thread in the prefix sums (<= PER)
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     double* sd = scratch_d + (int64_t)blockIdx.x * k * nthr;
     int32_t* si = scratch_i + (int64_t)blockIdx.x * k * nthr;
+    // The thread id is re-read behind an opaque barrier in every phase: otherwise the compiler computes the dozens of
+    // per-sample indices, predicates and LDS addresses of all phases once, ahead of the cell loop, and spills them.
+#define SD_TID()                                        \
+    int tid = (int)threadIdx.x;                         \
+    asm volatile("" : "+v"(tid));                       \
+    const int lane = tid & 63, wave = tid >> 6;         \
+    (void)lane;                                         \
+    (void)wave
+    const double kk = uniform_f64((double)k), rk = uniform_f64(1.0 / (double)k);
+    const int M = n - k > 0 ? n - k : 0;  // window starts 0 .. M
     int nsteps = 0;  // window refinement: the range p - k .. p holds at most k + 1 candidates
-    while ((1 << nsteps) < (k + 1 < n - k + 1 ? k + 1 : n - k + 1)) ++nsteps;
-    const double kk = (double)k;
+    while ((1 << nsteps) < (k + 1 < M + 1 ? k + 1 : M + 1)) ++nsteps;
+    const bool one_pass = Tq <= (int64_t)kPhQ * nthr;
     int64_t step, end;
+#ifdef SD_DEV
+    int traced = 0;
+#define SD_STAMP(slot)                                                                                                              \
+    do {                                                                                                                            \
+        if (trace != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && traced < 8) trace[traced * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define SD_STAMP(slot) do { } while (0)
+#endif
     for (int64_t c = first_cell(C, &step, &end); c < end; c += step) {
         const bool active = fit_status[c] == 0;
         const double* xg = xs_all + c * T;
-        const double2* pq = reinterpret_cast<const double2*>(pq_all) + c * (T + 1);
-        const double ybar = ybar_all[c];
+        const double* yx = yx_all + c * T;
+        const double ybar = uniform_f64(ybar_all[c]);
         for (int64_t q0 = 0; q0 < Tq; q0 += (int64_t)kPhQ * nthr) {
             // ---- generation 1: sorted training values -> window start of every query
             __syncthreads();
-            if (active)
-                for (int i = tid; i < n; i += nthr) buf[i] = xg[i];
-            if (tid == 0) buf[n] = inf;
+            SD_STAMP(0);
+            {
+                SD_TID();
+                double xv[PER];
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int j = tid + i * nthr;
+                    xv[i] = (active && j < n) ? xg[j] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int j = tid + i * nthr;
+                    if (j < n) buf[j] = xv[i];
+                }
+                if (tid == 0) buf[n] = inf;
+            }
             __syncthreads();
-            int Lw[kPhQ];
+            SD_STAMP(1);
+            SD_TID();
+            // the queries (used after the table is built), and behind them -- loads return in order -- the touches
+            const double* qrow = Xq + c * Tq + q0;  // (uniform) queries of this pass
+            const int nq = (int)(Tq - q0 < (int64_t)kPhQ * nthr ? Tq - q0 : (int64_t)kPhQ * nthr);
+            double qv[kPhQ];
+            unsigned hasmask = 0u;
+#pragma unroll
+            for (int i = 0; i < kPhQ; ++i) {
+                const int j = tid + i * nthr;
+                qv[i] = 0.0;
+                if (j < nq) {
+                    qv[i] = qrow[j];
+                    hasmask |= 1u << i;
+                }
+            }
+            const Touch warm_y = touch_lines(yx, n, tid, nthr, active);
+            SD_STAMP(2);
+            unsigned Lw2[kPhQ / 2];  // window starts, two 16-bit values per word
+#define SD_LW(i) ((int)(((i) & 1) ? (Lw2[(i) >> 1] >> 16) : (Lw2[(i) >> 1] & 0xffffu)))
             unsigned okmask = 0u, nanmask = 0u, walkmask = 0u;  // bit i: prefix-sum statistics / NaN output / exact walk
 #pragma unroll
             for (int i0 = 0; i0 < kPhQ; i0 += 2) {
                 double q[2];
                 bool has[2], ok[2];
+                int lo[2], hi[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int64_t tq = q0 + tid + (int64_t)(i0 + j) * nthr;
-                    has[j] = tq < Tq;
-                    q[j] = has[j] ? Xq[c * Tq + tq] : 0.0;
+                    has[j] = (hasmask >> (i0 + j)) & 1u;
+                    q[j] = qv[i0 + j];
                     ok[j] = active && has[j] && sd_finite(q[j]);
                     if (active && has[j] && !ok[j]) atomicOr(&status[c], SDI_NONFINITE);
                     if (!ok[j]) q[j] = 0.0;
                 }
-                int lo[2], hi[2], pos[2];
+                // position of the query among the sorted values (branch-free bisection; strides that are multiples of 16
+                // doubles are shortened by one: see the rank search in sd_bcsd_rs.hip), then the start of the window of k
+                // nearest values among the k + 1 candidates around it
+                int pos[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) pos[j] = -1;  // index of the last value known to be < q
 #pragma unroll 1
@@ -1376,7 +1498,7 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
                 for (int j = 0; j < 2; ++j) {
                     const int p = pos[j] + 1 + (buf[pos[j] + 1] < q[j] ? 1 : 0);
                     lo[j] = p - k > 0 ? p - k : 0;
-                    hi[j] = p < n - k ? p : n - k;
+                    hi[j] = p < M ? p : M;
                 }
 #pragma unroll 1
                 for (int s = 0; s < nsteps; ++s) {
@@ -1389,10 +1511,10 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
                         hi[j] = (act && !right) ? mid : hi[j];
                     }
                 }
+                Lw2[i0 >> 1] = (unsigned)lo[0] | ((unsigned)lo[1] << 16);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int i = i0 + j;
-                    Lw[i] = lo[j];
                     if (!has[j]) continue;
                     if (!ok[j]) {
                         nanmask |= 1u << i;
@@ -1402,60 +1524,145 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
                     const double dL = sq_dist(q[j], buf[L]), dR = sq_dist(q[j], buf[L + k - 1]);
                     const double worst = dL > dR ? dL : dR;
                     const bool sep_l = L == 0 || sq_dist(q[j], buf[L - 1]) > worst;
-                    const bool sep_r = L + k == n || sq_dist(q[j], buf[L + k]) > worst;
+                    const bool sep_r = L + k >= n || sq_dist(q[j], buf[L + k]) > worst;
                     if (sep_l && sep_r) okmask |= 1u << i;
-                    else walkmask |= 1u << i;  // a tie on the window boundary
+                    else walkmask |= 1u << i;  // a tie on the window boundary (or a bracket that missed)
                 }
             }
+            SD_STAMP(3);
 #pragma unroll 1
             for (int i = 0; walkmask >> i; ++i)  // exact (rdist, index)-ordered walk; writes its own output
                 if ((walkmask >> i) & 1u) {
                     const int64_t tq = q0 + tid + (int64_t)i * nthr;
                     f1_walk_query(0, pa, n, T, c, tq, Xq[c * Tq + tq], xg, xi_all + c * T, Xc + c * T, yc + c * T, sd, si, nthr);
                 }
+            touch_done(warm_y, status);
+            // ---- y in sorted-x order
+            __syncthreads();
+            SD_STAMP(4);
+            {
+                SD_TID();
+                double yv[PER];
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int j = tid + i * nthr;
+                    yv[i] = j < n ? yx[j] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int j = tid + i * nthr;
+                    if (j < n) buf[j] = yv[i];
+                }
+            }
+            // the next cell's sorted values and queries on their way into L2 (issued behind the loads above)
+            const bool more = one_pass && c + step < end;
+            const Touch warm_x = touch_lines(xg + step * T, n, threadIdx.x, nthr, more);
+            const Touch warm_q = touch_lines(Xq + (c + step) * Tq, (int)Tq, threadIdx.x, nthr, more);
+            __syncthreads();
+            SD_STAMP(5);
+            // (uniform) staging rows of this cell and pass: predictions, probabilities, spreads
+            global_f64* const orow = (global_f64*)(pa.out + c * 3 * pa.oc_Tq + q0);
+            global_f64* const prow = orow + pa.oc_Tq;
+            global_f64* const erow = prow + pa.oc_Tq;
             if (k == 1) {
-                // a single analog (best_analog, or n_analogs = 1: gard.py:291-296): generation 2 = y in sorted-x order
-                __syncthreads();
-                for (int i = tid; i < n; i += nthr) buf[i] = yx_all[c * T + i];
-                __syncthreads();
+                // a single analog (best_analog, or n_analogs = 1: gard.py:291-296)
 #pragma unroll
                 for (int i = 0; i < kPhQ; ++i) {
-                    const int64_t tq = q0 + tid + (int64_t)i * nthr;
-                    if ((okmask >> i) & 1u) {
-                        const double a1 = buf[Lw[i]];
+                    const int idx = tid + i * nthr;
+                    const bool okq = (okmask >> i) & 1u;
+                    if (okq || ((nanmask >> i) & 1u)) {
+                        const double a1 = buf[okq ? SD_LW(i) : 0];
                         const bool exc = !pa.has_thresh || a1 > pa.thresh;  // gard.py:307
-                        put_out(pa, tq, c, (pa.kind == SD_ANALOG_BEST || exc) ? a1 : 0.0,  // masked mean / weight: NaN -> 0 (gard.py:341)
-                                pa.has_thresh ? (exc ? 1.0 : 0.0) : 1.0,                // gard.py:343, 346
-                                exc ? 0.0 : nan);                                        // gard.py:342, 345
-                    } else if ((nanmask >> i) & 1u) {
-                        put_out(pa, tq, c, nan, nan, nan);
+                        orow[idx] = !okq ? nan : (pa.kind == SD_ANALOG_BEST || exc) ? a1 : 0.0;  // masked mean / weight: NaN -> 0 (gard.py:341)
+                        prow[idx] = !okq ? nan : pa.has_thresh ? (exc ? 1.0 : 0.0) : 1.0;          // gard.py:343, 346
+                        erow[idx] = !okq ? nan : exc ? 0.0 : nan;                                  // gard.py:342, 345
                     }
                 }
+                touch_done(warm_x, status);
+                touch_done(warm_q, status);
                 continue;
             }
-            // ---- generation 2: first prefix component -> window means
-            __syncthreads();
-            for (int i = tid; i <= n; i += nthr) buf[i] = pq[i].x;
-            __syncthreads();
-            double m1[kPhQ];
+            // ---- generation 2: exclusive prefix sums of d = yx - mean(y) -> window means
+            const int beg = per * tid;
+            double d[PER];
+            double a = 0.0, b = 0.0;
 #pragma unroll
-            for (int i = 0; i < kPhQ; ++i) m1[i] = (okmask >> i) & 1u ? (buf[Lw[i] + k] - buf[Lw[i]]) / kk : 0.0;
-            // ---- generation 3: second prefix component -> spreads, outputs
-            __syncthreads();
-            for (int i = tid; i <= n; i += nthr) buf[i] = pq[i].y;
-            __syncthreads();
+            for (int i = 0; i < PER; ++i) {
+                const int j = beg + i;
+                d[i] = (i < per && j < n) ? buf[j] - ybar : 0.0;
+                a += d[i];
+                b += d[i] * d[i];
+            }
+            double ia = a, ib = b;  // inclusive scans inside the wave
 #pragma unroll
-            for (int i = 0; i < kPhQ; ++i) {
-                const int64_t tq = q0 + tid + (int64_t)i * nthr;
-                if ((okmask >> i) & 1u) {
-                    const double var = (buf[Lw[i] + k] - buf[Lw[i]]) / kk - m1[i] * m1[i];
-                    put_out(pa, tq, c, ybar + m1[i], 1.0, sqrt(var > 0.0 ? var : 0.0));  // gard.py:329-333, 345-346
-                } else if ((nanmask >> i) & 1u) {
-                    put_out(pa, tq, c, nan, nan, nan);
+            for (int o = 1; o < 64; o <<= 1) {
+                const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
+                if (lane >= o) {
+                    ia += ta;
+                    ib += tb;
                 }
             }
+            __syncthreads();  // every thread has read its block of yx
+            if (lane == 63) wsum[wave] = ia;
+            __syncthreads();
+            double ra = ia - a;  // exclusive prefix at this thread's first sample
+            for (int w = 0; w < wave; ++w) ra += wsum[w];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int j = beg + i;
+                if (i < per && j <= n) buf[j] = ra;
+                ra += d[i];
+            }
+            if (tid == nthr - 1 && beg + per == n) buf[n] = ra;  // n = nthr * per: no thread starts at position n
+            __syncthreads();
+            SD_STAMP(6);
+            double m1[kPhQ];
+#pragma unroll
+            for (int i = 0; i < kPhQ; ++i) m1[i] = (okmask >> i) & 1u ? div_by(buf[SD_LW(i) + k] - buf[SD_LW(i)], kk, rk) : 0.0;
+            // ---- generation 3: exclusive prefix sums of d^2 -> spreads, outputs
+            __syncthreads();
+            if (lane == 63) wsum[wave] = ib;
+            __syncthreads();
+            double rb = ib - b;
+            for (int w = 0; w < wave; ++w) rb += wsum[w];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int j = beg + i;
+                if (i < per && j <= n) buf[j] = rb;
+                rb += d[i] * d[i];
+            }
+            if (tid == nthr - 1 && beg + per == n) buf[n] = rb;
+            __syncthreads();
+            SD_STAMP(7);
+#pragma unroll
+            for (int i = 0; i < kPhQ; ++i) {
+                const int idx = tid + i * nthr;
+                double pred, err;
+                if ((okmask >> i) & 1u) {
+                    const double var = div_by(buf[SD_LW(i) + k] - buf[SD_LW(i)], kk, rk) - m1[i] * m1[i];
+                    pred = ybar + m1[i];                 // gard.py:329-333
+                    err = sqrt(var > 0.0 ? var : 0.0);   // gard.py:345
+                } else if ((nanmask >> i) & 1u) {
+                    pred = err = nan;
+                } else {
+                    continue;
+                }
+                orow[idx] = pred;
+                erow[idx] = err;
+                if (!skip_prob) prow[idx] = pred != pred ? nan : 1.0;  // gard.py:346
+            }
+            SD_STAMP(8);
+            touch_done(warm_x, status);
+            touch_done(warm_q, status);
+            SD_STAMP(9);
+#ifdef SD_DEV
+            ++traced;
+#endif
         }
     }
+#undef SD_STAMP
+#undef SD_LW
+#undef SD_TID
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1766,11 +1973,6 @@ __global__ void __launch_bounds__(64) analog_bf2_predict_kernel(int mode, const 
 // the (rdist, index) selection stays exact.  Points now arrive out of index order: equal distances are decided by
 // the explicit index comparison against the heap root.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double uniform_f64(double v) {
-    const long long b = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
 __device__ __forceinline__ double wave_max_f64(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -2115,6 +2317,18 @@ __global__ void __launch_bounds__(256) analog_status_public_kernel(const int32_t
     }
 }
 
+// exclusive prefix sums of the centred analog values (analog_prefix_kernel), built when a kernel that reads them from
+// memory first runs on a state (calls on a context are serialised)
+int ensure_prefix_sums(sd_ctx* ctx, const sd_analog_state* st) {
+    if (st->pq != nullptr) return SD_OK;
+    sd_analog_state* ms = const_cast<sd_analog_state*>(st);
+    SD_HIP(sd_pool_malloc(ctx, (void**)&ms->pq, sizeof(double) * 2 * (size_t)(st->T + 1) * st->C));
+    const int nbp = (int)std::min<int64_t>(st->C, (int64_t)ctx->cu_count * 2);
+    SD_LAUNCH(ctx, "analog_prefix_kernel", analog_prefix_kernel, dim3(nbp), dim3(1024), 0, (const double*)st->yx, st->T, st->C, ms->pq,
+              ms->ybar, 1);
+    return SD_OK;
+}
+
 int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const double* Xq, int64_t ld, int64_t Tq, int k,
                    int kind, int has_thresh, double thresh, const int32_t* sample_dev, int64_t ld_s, double* out,
                    int64_t ld_out, int64_t* inds, double* dist, int32_t* cell_status) {
@@ -2175,14 +2389,23 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // single pass with only xs in LDS (statistics from the prefix sums, or the window of yx read from memory)
         const size_t lds_mean = sizeof(double) * (size_t)(T + 1);
-        const bool mean_only = (mode == 1 ? k >= 3 : (kind == SD_ANALOG_MEAN || kind == SD_ANALOG_WEIGHT || k == 1)) && st->pq != nullptr &&
+        const bool mean_only = (mode == 1 ? k >= 3 : (kind == SD_ANALOG_MEAN || kind == SD_ANALOG_WEIGHT || k == 1)) && st->ybar != nullptr &&
                                lds_mean <= ctx->lds_max && sd_dev_env("SD_ANALOG_NOPREFIX") == nullptr;
+        const bool phases = mean_only && mode == 0 && ((kind == SD_ANALOG_MEAN && !has_thresh) || k == 1) && T <= 1024 * 20 &&
+                            sd_dev_env("SD_ANALOG_NOPHASES") == nullptr;
+        const int skip_prob = phases && !has_thresh ? 1 : 0;  // the probability column is 1 wherever the prediction is not NaN (gard.py:346)
+        const size_t lds_mean3 = lds_mean;
         if (mean_only) {
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean));
-            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean3_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean));
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean3_kernel<8>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean3));
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean3_kernel<16>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean3));
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean3_kernel<20>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean3));
         }
+        if (mean_only && !phases) SD_TRY(ensure_prefix_sums(ctx, st));
         if (mean_only && mode == 1 && st->rx == nullptr) {
             // first regression on this state: the cross-term prefix sums (calls on a context are serialised)
             sd_analog_state* ms = const_cast<sd_analog_state*>(st);
@@ -2208,13 +2431,35 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
             const char* eqs = sd_dev_env("SD_ANALOG_QSPLIT");
             int qs = eqs ? atoi(eqs) : (mode == 1 ? 2 : 1);  // measured (ms per 16 384 cells), 1/2/4/8: regression 10.8/8.5/8.7/11.0, mean 5.5/5.7/6.4/8.3
             if (qs < 1 || nbc % (8 * qs) != 0 || cc < (int64_t)nbc || Tq < 4096) qs = 1;
-            if (mean_only && mode == 0 && ((kind == SD_ANALOG_MEAN && !has_thresh) || k == 1) && sd_dev_env("SD_ANALOG_NOPHASES") == nullptr) {
-                SD_LAUNCH(ctx, "analog_f1_mean3_kernel", analog_f1_mean3_kernel, dim3(nbc), dim3(nthr), lds_mean, (const double*)qc.p,
-                          Tq, T, cc, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
-                          (const double*)st->pq + 2 * cb * (T + 1), (const double*)st->ybar + cb, (const double*)st->yx + cb * T,
-                          (const double*)st->X + cb * T,
-                          (const double*)st->y + cb * T, (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb,
-                          sc_d.as<double>(), sc_i.as<int32_t>(), pw);
+            if (phases) {
+                const int per = (int)((T + nthr - 1) / nthr);
+                long long* trace_dev = nullptr;
+                sd_scratch trace_buf;
+                if (sd_dev_env("SD_M3_TRACE") != nullptr) {  // development library: phase clocks of the first cells of block 0
+                    SD_HIP(trace_buf.alloc(ctx, sizeof(long long) * 128));
+                    SD_HIP(hipMemsetAsync(trace_buf.p, 0, sizeof(long long) * 128, ctx->stream));
+                    trace_dev = trace_buf.as<long long>();
+                }
+#define SD_MEAN3(PER)                                                                                                                  \
+    SD_LAUNCH(ctx, "analog_f1_mean3_kernel", analog_f1_mean3_kernel<PER>, dim3(nbc), dim3(nthr), lds_mean3, (const double*)qc.p, Tq, T, \
+              cc, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T, (const double*)st->ybar + cb,                      \
+              (const double*)st->yx + cb * T, (const double*)st->X + cb * T, (const double*)st->y + cb * T,                           \
+              (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb, sc_d.as<double>(), sc_i.as<int32_t>(), pw, skip_prob, \
+              trace_dev)
+                if (per <= 8) SD_MEAN3(8);
+                else if (per <= 16) SD_MEAN3(16);
+                else SD_MEAN3(20);
+#undef SD_MEAN3
+                if (trace_dev != nullptr) {
+                    long long h[128];
+                    SD_HIP(hipMemcpyAsync(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+                    SD_HIP(hipStreamSynchronize(ctx->stream));
+                    for (int r = 0; r < 8; ++r) {
+                        fprintf(stderr, "mean3 trace cell %d:", r);
+                        for (int j = 1; j <= 9; ++j) fprintf(stderr, " %lld", h[r * 16 + j] - h[r * 16 + j - 1]);
+                        fprintf(stderr, "\n");
+                    }
+                }
             } else if (mean_only) {
                 SD_LAUNCH(ctx, "analog_f1_mean_kernel", analog_f1_mean_kernel, dim3(nbc), dim3(nthr), lds_mean, mode,
                           (const double*)qc.p, Tq, T, cc, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,
@@ -2230,8 +2475,8 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
                           (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb, sc_d.as<double>(), sc_i.as<int32_t>(), pw);
             }
             SD_LAUNCH(ctx, "analog_untranspose_kernel", analog_untranspose_kernel,
-                      dim3((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32), 3), dim3(256), 0, (const double*)oc.p, Tq, cc,
-                      out + cb, ld_out);
+                      dim3((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32), skip_prob ? 2 : 3), dim3(256), 0,
+                      (const double*)oc.p, Tq, cc, out + cb, ld_out, skip_prob);
         }
         SD_HIP(hipStreamSynchronize(ctx->stream));  // qc / oc go back to the block cache at scope exit
     } else if (f1) {
@@ -2364,21 +2609,23 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->xs, sizeof(double) * (size_t)T * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->xi, sizeof(int32_t) * (size_t)T * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->yx, sizeof(double) * (size_t)T * C));
-            SD_HIP(sd_pool_malloc(ctx, (void**)&st->pq, sizeof(double) * 2 * (size_t)(T + 1) * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->ybar, sizeof(double) * C));
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const int K2 = sd_dev_env("SD_ANALOG_SORT1") ? 0 : sort2_width(T, ctx->lds_max);
             if (K2 != 0) {
-                const Sort2Args a{st->X, T, 0, st->y, T, C, st->xs, st->xi, st->yx, st->pq, st->ybar};
+                // (no prefix sums yet: the BASELINE path -- analog_f1_mean3_kernel -- builds its own on chip; the kernels
+                // that read them from memory get them from ensure_prefix_sums on their first call)
+                const Sort2Args a{st->X, T, 0, st->y, T, C, st->xs, st->xi, st->yx, nullptr, st->ybar};
                 SD_TRY(launch_sort2_width(ctx, K2, a));
-            } else {  // (the fast sort writes the prefix sums itself)
+            } else {
+                SD_HIP(sd_pool_malloc(ctx, (void**)&st->pq, sizeof(double) * 2 * (size_t)(T + 1) * C));
                 int nb = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 4);
                 SD_LAUNCH(ctx, "analog_sort_kernel", analog_sort_kernel, dim3(nb), dim3(1024), lds, (const double*)st->X,
                           (const double*)st->y, T, C, st->xs, st->xi, st->yx);
                 const int nbp = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 2);
                 SD_LAUNCH(ctx, "analog_prefix_kernel", analog_prefix_kernel, dim3(nbp), dim3(1024), 0, (const double*)st->yx, T, C,
-                          st->pq, st->ybar);
+                          st->pq, st->ybar, 0);
             }
             SD_HIP(hipStreamSynchronize(ctx->stream));
         }

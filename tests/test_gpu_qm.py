@@ -184,8 +184,8 @@ def test_quantile_mapper_transformer():
                                           return_anoms=False)
         assert_close(m.transform(b), exp, what=f"quantile mapper {nfit}->{npred}")
         assert np.array_equal(pickle.loads(pickle.dumps(m)).transform(b), m.transform(b))
-    with pytest.raises(NotImplementedError):
-        QuantileMapper(detrend=True).fit(expected)
+    with pytest.raises(NotImplementedError):  # detrend=True itself runs on the engine (tests/test_gpu_detrend.py); non-default trend options do not
+        QuantileMapper(detrend=True, lt_kwargs={"lr_kwargs": {"fit_intercept": False}}).fit(expected)
     X = rng.standard_normal((200, 2, 2))
     pw = PointWiseDownscaler(QuantileMapper())
     pw.fit(GridArray(X, ("time", "y", "x")))
