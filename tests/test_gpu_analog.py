@@ -130,6 +130,31 @@ def test_regression_prefix_path_edges(ctx, case):
     assert_close(out, exp, what=f"regression {case}")
 
 
+@pytest.mark.parametrize("case", ["constant_y", "dry_spells", "wet_spells"])
+def test_pure_analog_constant_windows_full_length(ctx, case):
+    """PureAnalog mean / weight (gard.py:301-346) at the BASELINE series length with windows of identical analog values:
+    the prefix-sum differences of the mean path are then sums of equal numbers (expected spread 0: what is left is rounding
+    noise ~1e-8 of the data scale, inside the 1e-6 tolerance), with and without a threshold.  'dry_spells': y is 0 for every x below a cut (all windows left of it are
+    constant, those across it mix zeros and values); 'wet_spells': the other side; 'constant_y': everywhere."""
+    rng = np.random.default_rng(23)
+    T, Tq, C, k = 14600, 1200, 3, 30
+    X, Xq = rng.standard_normal((T, 1, C)), 1.2 * rng.standard_normal((Tq, 1, C))
+    y = 0.5 * X[:, 0, :] + rng.gamma(0.8, 3.0, (T, C))
+    if case == "constant_y":
+        y = np.full((T, C), 3.25)
+    elif case == "dry_spells":
+        y = np.where(X[:, 0, :] > 0.3, y, 0.0)
+    else:
+        y = np.where(X[:, 0, :] < -0.2, y, 1.5)
+    st = ctx.analog_fit(X, y)
+    for kind in ("mean_analogs", "weight_analogs"):
+        for thresh in (None, 0.0, 1.5):
+            out, status = ctx.analog_predict(st, Xq, k, KINDS[kind], thresh)
+            exp = ao.pointwise_analog(X, y, Xq, k, KINDS[kind], thresh)
+            assert (status == 0).all()
+            assert_close(out, exp, what=f"{case} {kind} thresh={thresh}")
+
+
 @pytest.mark.parametrize("F,T,Tq,C,k,data", [
     (3, 5000, 700, 3, 30, "normal"),     # slab much narrower than the series
     (3, 6000, 5000, 2, 30, "normal"),    # enough queries for the class order by default
