@@ -1335,32 +1335,13 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
 //      wave scans) -> window means;
 //   3. exclusive prefix sums of d^2 -> spreads.
 // Every byte of the state is fetched once, coalesced: xs and yx (8 + 8 bytes per training sample; the fitted state holds
-// no prefix sums for this path).  The workgroup is alone on its CU (LDS), so nothing would overlap its memory phases with
-// its LDS phases: each thread therefore touches one word per 64-byte piece of what a later phase will read (yx during
-// the search, the next cell's xs and queries during the prefix phases) so that the fills find their lines in L2; the
-// touches are issued behind every load the phase itself waits for (loads return in order).
+// no prefix sums for this path); every fill keeps all of a thread's loads in flight together (register staging).  The
+// workgroup is alone on its CU (LDS), so its memory phases and its LDS phases do not overlap; warming L2 for the next
+// phase with early one-word-per-line loads was tried and made the kernel 13 % slower (the lines are gone again before the
+// fill: 32 workgroups per XCD stream ~11 MB through a 4 MB L2) and doubled its counted fetch traffic.
 // With skip_prob the exceedance-probability column is not written: it is 1 wherever the prediction is not NaN
 // (gard.py:346) and the staging transpose fills it in.
 constexpr int kPhQ = 16;  // queries per thread and LDS generation (1024 threads: series up to 16 384 queries per pass)
-
-// One word of every 64-byte piece of [p, p + n doubles), n <= 3 * 8 * 1024: the loads stay where they are written
-// (volatile) and their values are handed to touch_done() later, so that nothing waits for them in between.
-struct Touch {
-    unsigned w[3];
-};
-__device__ __forceinline__ Touch touch_lines(const double* p, int n, int tid, int nthr, bool on) {
-    Touch t;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int i = (tid + j * nthr) * 8;
-        t.w[j] = 0u;
-        if (on && i < n) t.w[j] = *reinterpret_cast<const volatile unsigned*>(p + i);
-    }
-    return t;
-}
-__device__ __forceinline__ void touch_done(const Touch& t, int32_t* status) {
-    if ((t.w[0] & t.w[1] & t.w[2]) == 0xdead0beeu && (t.w[0] ^ t.w[1]) == 0x12345u) atomicOr(status, 0);  // never met: keeps the loads
-}
 
 // a wave-uniform double, pinned to scalar registers (the allocator otherwise keeps such values in vector registers and,
 // in this kernel, spills them)
@@ -1410,7 +1391,6 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
     const int M = n - k > 0 ? n - k : 0;  // window starts 0 .. M
     int nsteps = 0;  // window refinement: the range p - k .. p holds at most k + 1 candidates
     while ((1 << nsteps) < (k + 1 < M + 1 ? k + 1 : M + 1)) ++nsteps;
-    const bool one_pass = Tq <= (int64_t)kPhQ * nthr;
     int64_t step, end;
 #ifdef SD_DEV
     int traced = 0;
@@ -1448,7 +1428,7 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
             __syncthreads();
             SD_STAMP(1);
             SD_TID();
-            // the queries (used after the table is built), and behind them -- loads return in order -- the touches
+            // the queries
             const double* qrow = Xq + c * Tq + q0;  // (uniform) queries of this pass
             const int nq = (int)(Tq - q0 < (int64_t)kPhQ * nthr ? Tq - q0 : (int64_t)kPhQ * nthr);
             double qv[kPhQ];
@@ -1462,7 +1442,6 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
                     hasmask |= 1u << i;
                 }
             }
-            const Touch warm_y = touch_lines(yx, n, tid, nthr, active);
             SD_STAMP(2);
             unsigned Lw2[kPhQ / 2];  // window starts, two 16-bit values per word
 #define SD_LW(i) ((int)(((i) & 1) ? (Lw2[(i) >> 1] >> 16) : (Lw2[(i) >> 1] & 0xffffu)))
@@ -1536,7 +1515,6 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
                     const int64_t tq = q0 + tid + (int64_t)i * nthr;
                     f1_walk_query(0, pa, n, T, c, tq, Xq[c * Tq + tq], xg, xi_all + c * T, Xc + c * T, yc + c * T, sd, si, nthr);
                 }
-            touch_done(warm_y, status);
             // ---- y in sorted-x order
             __syncthreads();
             SD_STAMP(4);
@@ -1554,10 +1532,6 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
                     if (j < n) buf[j] = yv[i];
                 }
             }
-            // the next cell's sorted values and queries on their way into L2 (issued behind the loads above)
-            const bool more = one_pass && c + step < end;
-            const Touch warm_x = touch_lines(xg + step * T, n, threadIdx.x, nthr, more);
-            const Touch warm_q = touch_lines(Xq + (c + step) * Tq, (int)Tq, threadIdx.x, nthr, more);
             __syncthreads();
             SD_STAMP(5);
             // (uniform) staging rows of this cell and pass: predictions, probabilities, spreads
@@ -1578,8 +1552,6 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
                         erow[idx] = !okq ? nan : exc ? 0.0 : nan;                                  // gard.py:342, 345
                     }
                 }
-                touch_done(warm_x, status);
-                touch_done(warm_q, status);
                 continue;
             }
             // ---- generation 2: exclusive prefix sums of d = yx - mean(y) -> window means
@@ -1652,8 +1624,6 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
                 if (!skip_prob) prow[idx] = pred != pred ? nan : 1.0;  // gard.py:346
             }
             SD_STAMP(8);
-            touch_done(warm_x, status);
-            touch_done(warm_q, status);
             SD_STAMP(9);
 #ifdef SD_DEV
             ++traced;
