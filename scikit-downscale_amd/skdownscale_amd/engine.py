@@ -390,6 +390,10 @@ class Context:
     def qm_fit(self, X, y=None):
         """X, y [T, C] numpy or DeviceArray -> QmState (sorted series per cell); y=None keeps only the CDF of X
         (CunnaneTransformer)."""
+        X = self._field2("X", X)
+        y = self._field2("y", y, *X.shape)
+        if y is not None and isinstance(X, DeviceArray) != isinstance(y, DeviceArray):
+            raise ValueError("X and y must both be host arrays or both be DeviceArrays")
         h = C.c_void_p()
         if isinstance(X, DeviceArray):
             T, Cc = X.shape
@@ -405,7 +409,10 @@ class Context:
     def qm_cunnane(self, state, direction, X, extrapolate="both", n_endpoints=10, out=None):
         """CunnaneTransformer.transform (direction 0) / inverse_transform (1) of X [Tp, C] on the fitted CDFs."""
         Cc = state.info()["C"]
+        X = self._field2("X", X, None, Cc)
         status = np.empty(Cc, dtype=np.int32)
+        if extrapolate not in _lib.EXTRAP_CODES:
+            raise ValueError(f"unknown value for extrapolate: {extrapolate}")
         code = _lib.EXTRAP_CODES[extrapolate]
         if isinstance(X, DeviceArray):
             Tp = X.shape[0]
@@ -443,6 +450,10 @@ class Context:
     # ---- analogs ----
     def analog_fit(self, X, y):
         """X [T,F,C], y [T,C] numpy or DeviceArray."""
+        if not isinstance(X, DeviceArray):
+            X, y = _lib.as_f64(X), _lib.as_f64(y)
+        if len(X.shape) != 3 or tuple(y.shape) != (X.shape[0], X.shape[2]) or isinstance(X, DeviceArray) != isinstance(y, DeviceArray):
+            raise ValueError(f"expected X [T, F, C] and y [T, C] of the same kind, got {tuple(X.shape)} and {tuple(y.shape)}")
         h = C.c_void_p()
         if isinstance(X, DeviceArray):
             T, F, Cc = X.shape
@@ -457,6 +468,20 @@ class Context:
     def analog_predict(self, state, Xq, k, kind, thresh=None, sample_inds=None, want_neighbors=False, out=None):
         info = state.info()
         Cc = info["C"]
+        if not isinstance(Xq, DeviceArray):
+            Xq = _lib.as_f64(Xq)
+        if len(Xq.shape) != 3 or Xq.shape[1] != info["F"] or Xq.shape[2] != Cc:
+            raise ValueError(f"Xq: expected a [Tq, {info['F']}, {Cc}] field, got shape {tuple(Xq.shape)}")
+        k = int(k)
+        if k < 1 or k > info["T"]:
+            raise ValueError(f"k={k}: expected 1 <= k <= {info['T']} (the number of training samples)")
+        if sample_inds is not None:
+            if not isinstance(sample_inds, DeviceArray):
+                sample_inds = _lib.as_i32(sample_inds)
+            if tuple(sample_inds.shape) != (Xq.shape[0], Cc):
+                raise ValueError(f"sample_inds: expected shape {(Xq.shape[0], Cc)}, got {tuple(sample_inds.shape)}")
+            if not isinstance(sample_inds, DeviceArray) and len(sample_inds) and (np.min(sample_inds) < 0 or np.max(sample_inds) >= k):
+                raise ValueError(f"sample_inds must lie in [0, {k})")
         status = np.empty(Cc, dtype=np.int32)
         has_t, tv = (0, 0.0) if thresh is None else (1, float(thresh))
         if isinstance(Xq, DeviceArray):

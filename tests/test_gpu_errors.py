@@ -67,6 +67,17 @@ def test_analog_argument_errors(ctx):
         ctx.analog_fit(rng.standard_normal((40, 9, 2)), y)  # more features than the engine supports
     out, status = ctx.analog_predict(st, Xq, 40, 3)  # k == T is allowed
     assert np.isfinite(out).all()
+    # shapes the C ABI cannot check (raw pointers): refused by the wrappers
+    with pytest.raises(ValueError, match="expected X"):
+        ctx.analog_fit(X, y[:30])
+    with pytest.raises(ValueError, match="Xq: expected"):
+        ctx.analog_predict(st, Xq[:, :, :1], 5, 3)
+    with pytest.raises(ValueError, match="Xq: expected"):
+        ctx.analogreg_predict(st, rng.standard_normal((10, 2, 2)), 5)
+    with pytest.raises(ValueError, match="sample_inds: expected shape"):
+        ctx.analog_predict(st, Xq, 5, 1, sample_inds=np.zeros((3, 2), np.int32))
+    with pytest.raises(ValueError, match=r"sample_inds must lie in \[0, 5\)"):
+        ctx.analog_predict(st, Xq, 5, 1, sample_inds=np.full((10, 2), 5, np.int32))
 
 
 def test_qm_limits(ctx):
@@ -81,6 +92,15 @@ def test_qm_limits(ctx):
         ctx.qm_predict(st, 1, rng.standard_normal((T, 2)))  # EquidistantCdfMatcher ranks the new series
     out, _ = ctx.qm_predict(st, 0, rng.standard_normal((T, 2)))  # the regressor itself has no such limit
     assert np.isfinite(out).all()
+    with pytest.raises(ValueError, match="y: expected"):
+        ctx.qm_fit(rng.standard_normal((50, 2)), rng.standard_normal((40, 2)))
+    with pytest.raises(ValueError, match="X: expected"):
+        ctx.qm_predict(st, 0, rng.standard_normal((10, 3)))
+    cst = ctx.qm_fit(rng.standard_normal((50, 2)))
+    with pytest.raises(ValueError, match="X: expected"):
+        ctx.qm_cunnane(cst, 0, rng.standard_normal((10, 1)))
+    with pytest.raises(ValueError, match="unknown value for extrapolate"):
+        ctx.qm_cunnane(cst, 0, rng.standard_normal((10, 2)), extrapolate="sideways")
 
 
 def test_state_use_after_destroy_and_release_cached(ctx):
