@@ -463,6 +463,35 @@ def test_pointwise_downscaler_bcsd_grid():
         PointWiseDownscaler(object())
 
 
+def test_float32_inputs_follow_the_reference():
+    """float32 fields: the reference's np.sort / np.interp promote to float64 and its estimators return
+    float64 (checked against the reference: within 2e-7 of the float64 pipeline on the upcast inputs), while
+    PointWiseDownscaler allocates its result in X's dtype (core.py:119).  The engine upcasts once on the way in."""
+    from skdownscale_amd import BcsdPrecipitation, BcsdTemperature, GridArray, PointWiseDownscaler
+
+    rng = np.random.default_rng(4)
+    T, C = 1461, 6
+    index = pd.date_range("1990-01-01", periods=T)
+    X32 = (12 + 7 * rng.standard_normal((T, C))).astype(np.float32)
+    y32 = (10 + 5 * rng.standard_normal((T, C))).astype(np.float32)
+    gid = month_gid(index)
+    exp, _ = bo.pointwise_fit_predict(bo.TAS, X32.astype(np.float64), y32.astype(np.float64), X32.astype(np.float64), gid, gid)
+    m = BcsdTemperature().fit(pd.DataFrame(X32[:, :1], index=index), pd.DataFrame(y32[:, :1], index=index))
+    out = m.predict(pd.DataFrame(X32[:, :1], index=index))
+    assert out.values.dtype == np.float64
+    assert_close(out.values[:, 0], exp[:, 0], what="float32 DataFrame through the estimator")
+    mk = lambda a: GridArray(a.reshape(T, 2, 3), ("time", "y", "x"), {"time": index})  # noqa: E731
+    pw = PointWiseDownscaler(BcsdTemperature())
+    pw.fit(mk(X32), mk(y32))
+    res = pw.predict(mk(X32))
+    assert res.values.dtype == np.float32
+    np.testing.assert_allclose(res.values.reshape(T, C), exp.astype(np.float32), rtol=2e-6, atol=2e-6)
+    P32 = (np.abs(X32) + 0.1).astype(np.float32)
+    pexp, _ = bo.pointwise_fit_predict(bo.PR, P32.astype(np.float64), P32.astype(np.float64) + 0.5, P32.astype(np.float64), gid, gid)
+    mp = BcsdPrecipitation().fit(pd.DataFrame(P32[:, :1], index=index), pd.DataFrame(P32[:, :1] + np.float32(0.5), index=index))
+    assert_close(mp.predict(pd.DataFrame(P32[:, :1], index=index)).values[:, 0], pexp[:, 0], what="float32 precipitation")
+
+
 def test_per_group_kernel_width(dev_ctx, monkeypatch):
     """A 40-year daily series has 31-day months (1 240 samples: 21 per lane) and shorter ones (<= 1 216: 19 per lane):
     the shorter months get their own launch of the narrower kernels sharing the hand-off slabs.  The result must not
