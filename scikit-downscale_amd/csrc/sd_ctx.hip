@@ -5,6 +5,8 @@
 #include <cstring>
 #include <thread>
 
+#include <sys/mman.h>
+
 #include "sd_internal.h"
 
 static thread_local std::string g_last_error;
@@ -86,7 +88,14 @@ int sd_copy_h2d(sd_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return SD_OK;
 }
 
+void sd_advise_result_buffer(void* p, size_t bytes) {
+    const uintptr_t huge = (uintptr_t)2 << 20;
+    const uintptr_t lo = ((uintptr_t)p + huge - 1) & ~(huge - 1), hi = ((uintptr_t)p + bytes) & ~(huge - 1);
+    if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);  // (a hint: failure changes nothing)
+}
+
 int sd_copy_d2h(sd_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    sd_advise_result_buffer(dst, bytes);
     if (bytes < kDirectCopyBytes) {
         SD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         SD_HIP(hipStreamSynchronize(ctx->stream));

@@ -82,6 +82,10 @@ void sd_gt_cache_clear(sd_ctx* ctx);
 // sd_copy_d2h: ordered behind the work already queued on ctx->stream; returns when the host buffer is complete.
 int sd_copy_h2d(sd_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int sd_copy_d2h(sd_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+// asks for transparent huge pages on the 2 MB-aligned interior of a host range that is about to be written for the first
+// time (a fresh result array; NumPy does the same for its own large allocations): first-touch faults of 4 KB pages cap a
+// copy at ~14 GB/s on the GPU box, of huge pages at > 100 GB/s (csrc/microbench/pcie_rate.hip)
+void sd_advise_result_buffer(void* p, size_t bytes);
 
 // Device memory through the context's block cache (exact-size reuse).  Blocks go back with sd_pool_release;
 // the cache is bounded by pool_cap (a quarter of the device memory) and emptied by sd_ctx_release_cached /

@@ -2,6 +2,7 @@
 import ctypes as C
 
 import numpy as np
+import pandas as pd
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -145,3 +146,23 @@ def test_large_host_copies_take_the_staged_path(ctx):
     d = ctx.to_device(a)
     assert np.array_equal(d.to_host(), a)
     d.free()
+
+
+def test_large_host_predict_matches_resident(ctx):
+    """sd_bcsd_fit / sd_bcsd_predict on host buffers of several hundred MB (staged copies, many chunks): same bits as the
+    resident path; per-cell status and masked cells land in the right columns."""
+    from skdownscale_amd import synth
+
+    T, C = 14_600, 4_700  # 549 MB per field
+    index = pd.date_range("1980-01-01", periods=T)
+    cells = np.arange(C)
+    X, y, Xp = (synth.tas_field(name, 3, index, cells, 10_000) for name in ("X_hist", "y_obs", "X_fut"))
+    X[0, 17] = np.nan        # masked cell (core.py:35-37)
+    Xp[100, 4_650] = np.inf  # non-finite predict sample
+    gid = (np.asarray(index.month) - 1).astype(np.int32)
+    st = ctx.bcsd_fit(0, X, y, gid, 12, True)
+    out, status = ctx.bcsd_predict(st, Xp, gid)
+    dout, dstatus = ctx.bcsd_predict(st, ctx.to_device(Xp), gid)
+    assert np.array_equal(status, dstatus) and status[17] == 1 and status[4_650] == 2 and (np.delete(status, [17, 4_650]) == 0).all()
+    assert np.array_equal(out, dout.to_host(), equal_nan=True)
+    assert np.isnan(out[:, 17]).all() and np.isnan(out[:, 4_650]).all() and np.isfinite(out[:, 4_649]).all()
