@@ -173,12 +173,18 @@ __global__ void __launch_bounds__(1024) analog_sort_kernel(const double* __restr
 // keys_only: only xs and xi are produced (feature 0 of an F > 1 training set, or of a query series: x_stride is the
 // distance between the series of consecutive cells); non-finite keys sort as 0 (their cell / query is flagged elsewhere,
 // NaNs must not enter the min/max networks).
-template <int K>
+constexpr long long kTagMask = 0x3fff;      // 14 bits: series of up to 16 384 samples
+constexpr unsigned kTagPadHi = 0x7fe00000u;  // upper word of the pad keys (>= 8.98e307: beyond any data the fast path accepts)
+
+// TAGGED = true: the index-tag pass (below); cells it cannot serve are appended to `worklist` and the TAGGED = false
+// instance (two sorts, any data) walks that list afterwards.  TAGGED = false with worklist == nullptr: every cell.
+template <int K, bool TAGGED>
 __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __restrict__ Xc, int64_t x_stride, int keys_only,
                                                             const double* __restrict__ yc,
                                                             int64_t T, int64_t C, double* __restrict__ xs,
                                                             int32_t* __restrict__ xi, double* __restrict__ yx,
-                                                            double* __restrict__ pq_all, double* __restrict__ ybar_all) {
+                                                            double* __restrict__ pq_all, double* __restrict__ ybar_all,
+                                                            int32_t* worklist, int32_t* work_count) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int np = (n + K - 1) / K * K;
@@ -186,11 +192,12 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
     int* xch = reinterpret_cast<int*>(buf + np + 1);        // nthr + 1 ints (also 3 x 16 doubles of reduction scratch)
     double* red = reinterpret_cast<double*>(xch);
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
-    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+    const int64_t nitems = (!TAGGED && worklist != nullptr) ? (int64_t)*work_count : C;
+    for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int64_t c = (!TAGGED && worklist != nullptr) ? (int64_t)worklist[item] : item;
         const double* x = Xc + c * x_stride;
-        __syncthreads();
-        {
-            // coalesced load (all K + 1 requests of a thread in flight together), blocked read below
+        auto load_x = [&]() {
+            // coalesced load (all K + 1 requests of a thread in flight together), blocked reads afterwards
             double xv[K + 1];
 #pragma unroll
             for (int t = 0; t <= K; ++t) {
@@ -202,8 +209,97 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
                 const int i = tid + t * nthr;
                 if (i <= np) buf[i] = (i < n && !sd_finite(xv[t])) ? 0.0 : xv[t];
             }
-        }
+        };
         __syncthreads();
+        load_x();
+        __syncthreads();
+        if constexpr (TAGGED) {
+            // ---- fast path: the training index rides through the sort in the 14 low mantissa bits of the key.  The sorted
+            // order is then (upper 50 bits of x, index); it equals the (x, index) order whenever no two neighbouring sorted
+            // keys share their upper 50 bits (checked: equal values, values closer than 2^-38 relative, and cells whose
+            // magnitudes reach the pad range take the two-sort path below).  The tags of the sorted keys are xi, and xs / yx
+            // are x / y gathered through them from LDS: 2 x K random LDS reads per thread instead of the 14 x K of the
+            // first-position search.
+            double t[K];
+            bool odd = false;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = K * tid + i;
+                const long long b = __double_as_longlong(buf[j < np ? j : np] + 0.0);  // (lane stride K is odd: conflict-free); -0.0 -> +0.0: they tie as values
+                odd |= j < n && (unsigned)((b >> 32) & 0x7fffffff) >= kTagPadHi;
+                const long long key = j < n ? ((b & ~(long long)kTagMask) | (long long)j) : (((long long)kTagPadHi << 32) | (long long)j);
+                t[i] = __longlong_as_double(key);
+            }
+            __syncthreads();
+            sdsort::block_merge_sort<K>(t, buf, np, xch, tid, nthr);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = K * tid + i;
+                if (j + 1 < n) odd |= ((__double_as_longlong(buf[j]) ^ __double_as_longlong(buf[j + 1])) >> 14) == 0;
+            }
+            if (__syncthreads_or(odd) == 0) {
+                unsigned short tg[K];
+#pragma unroll
+                for (int s2 = 0; s2 < K; ++s2) {
+                    const int pos = tid + s2 * nthr;
+                    tg[s2] = pos < n ? (unsigned short)(__double_as_longlong(buf[pos]) & kTagMask) : 0;
+                    if (pos < n) xi[c * T + pos] = (int)tg[s2];
+                }
+                __syncthreads();  // every tag is in registers: the array is free
+                {
+                    double xv[K];
+#pragma unroll
+                    for (int s2 = 0; s2 < K; ++s2) {
+                        const int pos = tid + s2 * nthr;
+                        xv[s2] = pos < n ? x[pos] : 0.0;
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < K; ++s2) {
+                        const int pos = tid + s2 * nthr;
+                        if (pos < n) buf[pos] = sd_finite(xv[s2]) ? xv[s2] : 0.0;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int s2 = 0; s2 < K; ++s2) {
+                    const int pos = tid + s2 * nthr;
+                    if (pos < n) xs[c * T + pos] = buf[tg[s2]];
+                }
+                if (keys_only) continue;
+                __syncthreads();
+                const double* yy = yc + c * T;
+                double ysum = 0.0;
+                {
+                    double yv[K];
+#pragma unroll
+                    for (int s2 = 0; s2 < K; ++s2) {
+                        const int pos = tid + s2 * nthr;
+                        yv[s2] = pos < n ? yy[pos] : 0.0;
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < K; ++s2) {
+                        const int pos = tid + s2 * nthr;
+                        if (pos < n) buf[pos] = yv[s2];
+                        ysum += yv[s2];
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) ysum += __shfl_xor(ysum, o, 64);
+                if (lane == 0) red[wave] = ysum;  // (xch is free: the sort is over)
+                __syncthreads();
+#pragma unroll
+                for (int s2 = 0; s2 < K; ++s2) {
+                    const int pos = tid + s2 * nthr;
+                    if (pos < n) yx[c * T + pos] = buf[tg[s2]];
+                }
+                double tot = 0.0;
+                for (int w = 0; w < 16; ++w) tot += red[w];
+                if (tid == 0) ybar_all[c] = tot / (double)n;
+                continue;
+            }
+            if (tid == 0) worklist[atomicAdd(work_count, 1)] = (int32_t)c;  // left to the two-sort instance
+            continue;
+        }
         double v[K], orig[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) {
@@ -363,11 +459,27 @@ template <int K>
 int launch_sort2(sd_ctx* ctx, const Sort2Args& a) {
     const int np = (int)((a.T + K - 1) / K * K);
     const size_t lds = sizeof(double) * (size_t)(np + 1) + sizeof(int) * 1025;
-    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort2_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort2_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort2_kernel<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
     const int nb = (int)std::min<int64_t>(a.C, (int64_t)ctx->cu_count * 4);
-    SD_LAUNCH(ctx, "analog_sort2_kernel", analog_sort2_kernel<K>, dim3(nb), dim3(1024), lds, a.X, a.x_stride, a.keys_only, a.y, a.T,
-              a.C, a.xs, a.xi, a.yx, a.pq, a.ybar);
+    // index-tag pass first (series of up to 16 384 samples, no prefix sums asked for), then the cells it handed back
+    const bool tagged = a.T <= kTagMask + 1 && a.pq == nullptr && a.C < ((int64_t)1 << 31) && sd_dev_env("SD_ANALOG_NOTAGS") == nullptr;
+    sd_scratch list;
+    int32_t* worklist = nullptr;
+    int32_t* work_count = nullptr;
+    if (tagged) {
+        SD_HIP(list.alloc(ctx, sizeof(int32_t) * (size_t)(a.C + 1)));
+        work_count = list.as<int32_t>();
+        worklist = work_count + 1;
+        SD_HIP(hipMemsetAsync(work_count, 0, sizeof(int32_t), ctx->stream));
+        SD_LAUNCH(ctx, "analog_sort2_kernel", (analog_sort2_kernel<K, true>), dim3(nb), dim3(1024), lds, a.X, a.x_stride, a.keys_only, a.y,
+                  a.T, a.C, a.xs, a.xi, a.yx, a.pq, a.ybar, worklist, work_count);
+    }
+    SD_LAUNCH(ctx, "analog_sort2_exact_kernel", (analog_sort2_kernel<K, false>), dim3(tagged ? std::min(nb, 256) : nb), dim3(1024), lds, a.X,
+              a.x_stride, a.keys_only, a.y, a.T, a.C, a.xs, a.xi, a.yx, a.pq, a.ybar, worklist, work_count);
+    if (tagged) SD_HIP(hipStreamSynchronize(ctx->stream));  // the list goes back to the block cache
     return SD_OK;
 }
 

@@ -43,7 +43,8 @@ def main():
         total, detail = 0.0, {}
         for kname, launches in roof["launches_per_step"].items():
             # bench.py names (SD_LAUNCH) are prefixes / variants of the symbol names: bcsd_rs_rank_kernel = bcsd_rs_kernel<K, 3, ...>
-            sym = {"bcsd_rs_rank_kernel": "bcsd_rs_kernel", "bcsd_rs_apply_kernel": "bcsd_rs_kernel", "bcsd_rs_fit_kernel": "bcsd_rs_kernel"}.get(kname, kname)
+            sym = {"bcsd_rs_rank_kernel": "bcsd_rs_kernel", "bcsd_rs_apply_kernel": "bcsd_rs_kernel", "bcsd_rs_fit_kernel": "bcsd_rs_kernel",
+                   "analog_sort2_exact_kernel": "analog_sort2_kernel"}.get(kname, kname)
             f, w = fetch.get(sym, 0.0) * FETCH_CORRECTION, write.get(sym, 0.0)
             detail[kname] = {"symbol": sym, "fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "launches_per_step": launches}
             total += (f + w) * launches
