@@ -203,12 +203,27 @@ def main():
 
     from skdownscale_amd import _lib, synth
     from skdownscale_amd.engine import Context
-    from skdownscale_amd.shard import Communicator
+    from skdownscale_amd.shard import Communicator, Rendezvous
 
     config = args.config or (2 if world == 1 else 5)
     wl = WORKLOADS[config]
-    ctx = Context(local_rank)
-    comm = Communicator.from_env(ctx) if world > 1 else None
+    import ctypes
+
+    ndev = ctypes.c_int(0)
+    _lib.check(_lib.load().sd_device_count(ctypes.byref(ndev)))
+    ctx = Context(local_rank % max(1, ndev.value))  # (more ranks than GPUs -- a test on a small box -- share devices)
+    # control plane (barrier, max-over-ranks clock): a TCP star around rank 0; data path (gather of the predicted fields):
+    # RCCL through the engine's C ABI.  The throughput line does not depend on the second one coming up.
+    rdv = Rendezvous(rank, world) if world > 1 else None
+    comm, comm_error = None, None
+    if world > 1:
+        try:
+            comm = Communicator.from_env(ctx, rendezvous=rdv)
+        except Exception as e:  # noqa: BLE001
+            comm_error = f"{type(e).__name__}: {e}"
+        if rdv.allreduce_max(0.0 if comm is not None else 1.0) > 0.0 and comm is not None:  # all ranks or none
+            comm.close()
+            comm, comm_error = None, "communicator creation failed on another rank"
     info = ctx.device_info()
     T = args.times
     C = args.cells or wl["cells"]
@@ -259,8 +274,8 @@ def main():
 
     def barrier():
         ctx.synchronize()
-        if comm is not None:
-            comm.barrier()
+        if rdv is not None:
+            rdv.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -274,8 +289,8 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
     prof = ctx.prof()
-    if comm is not None:
-        elapsed = comm.allreduce_max(elapsed)
+    if rdv is not None:
+        elapsed = rdv.allreduce_max(elapsed)
 
     # ---- N > 1: the same step followed by the gather of the predicted field to rank 0 (cell chunks: a chunk's transfer
     # over xGMI overlaps the next chunk's kernels) ----
@@ -302,12 +317,14 @@ def main():
             for _ in range(args.gather_steps):
                 gather_step()
             barrier()
-            gdt = comm.allreduce_max((time.perf_counter() - g0) / args.gather_steps)
+            gdt = rdv.allreduce_max((time.perf_counter() - g0) / args.gather_steps)
             gather = {"value_with_gather": C * world / gdt, "ms_per_step_with_gather": gdt * 1e3, "steps": args.gather_steps,
                       "cell_chunks": nchunk, "root_layout": "[chunk][rank][T][cells of the chunk], received in place over xGMI",
                       "gathered_GB_per_step": 8.0 * T * C * (world - 1) / 1e9}
         except Exception as e:  # noqa: BLE001  (never lose the throughput line over the second measurement)
             gather = {"value_with_gather": None, "error": str(e)}
+    elif world > 1 and comm is None:
+        gather = {"value_with_gather": None, "error": f"no RCCL communicator: {comm_error}"}
 
     # ---- parity spot check: part of the cpu_baseline leg (the oracle's first run is compared with the engine's
     # output for the same cells, outside the timed region) ----
@@ -348,9 +365,11 @@ def main():
         except Exception as e:  # noqa: BLE001
             e2e = {"value": None, "error": str(e)}
 
-    if comm is not None:
-        comm.barrier()
-        comm.close()
+    if rdv is not None:
+        rdv.barrier()
+        if comm is not None:
+            comm.close()
+        rdv.close()
     if rank != 0:
         return
 

@@ -65,6 +65,105 @@ def exchange_unique_id(rank, world, make_id, addr=None, port=None, timeout=300.0
         time.sleep(0.05)
 
 
+class Rendezvous:
+    """Control plane of a one-node job: a TCP star around rank 0 (persistent connections), found through the launcher's
+    ``MASTER_ADDR`` / ``MASTER_PORT`` (+ PORT_OFFSET).  Carries what is not worth a GPU collective -- RCCL's unique id, the
+    barrier and the max-over-ranks of a wall-clock time -- and keeps a job's timing independent of the data-path library."""
+
+    def __init__(self, rank, world, addr=None, port=None, timeout=300.0):
+        import struct
+
+        self._struct = struct
+        self.rank, self.world = int(rank), int(world)
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + PORT_OFFSET)
+        self.peers, self.root = {}, None
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            try:
+                while len(self.peers) < self.world - 1:
+                    conn, _peer = srv.accept()
+                    conn.settimeout(timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    (r,) = struct.unpack("<i", self._recv(conn, 4))
+                    self.peers[r] = conn
+            finally:
+                srv.close()
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    conn = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise TimeoutError(f"rank {self.rank}: no rendezvous at {addr}:{port} within {timeout} s") from None
+                    time.sleep(0.05)
+            conn.settimeout(timeout)
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            conn.sendall(struct.pack("<i", self.rank))
+            self.root = conn
+
+    @classmethod
+    def from_env(cls, timeout=300.0):
+        return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), timeout=timeout)
+
+    @staticmethod
+    def _recv(conn, n):
+        buf = b""
+        while len(buf) < n:
+            chunk = conn.recv(n - len(buf))
+            if not chunk:
+                raise ConnectionError("rendezvous peer closed the connection")
+            buf += chunk
+        return buf
+
+    def broadcast(self, payload=None):
+        """bytes from rank 0 to everybody (``payload`` is read on rank 0 only)"""
+        if self.world == 1:
+            return payload
+        st = self._struct
+        if self.rank == 0:
+            msg = st.pack("<q", len(payload)) + payload
+            for conn in self.peers.values():
+                conn.sendall(msg)
+            return payload
+        (n,) = st.unpack("<q", self._recv(self.root, 8))
+        return self._recv(self.root, n)
+
+    def allreduce_max(self, value):
+        """max of a float over the ranks (also a barrier: nobody returns before everybody has arrived)"""
+        if self.world == 1:
+            return float(value)
+        st = self._struct
+        if self.rank == 0:
+            m = float(value)
+            for conn in self.peers.values():
+                m = max(m, st.unpack("<d", self._recv(conn, 8))[0])
+            for conn in self.peers.values():
+                conn.sendall(st.pack("<d", m))
+            return m
+        self.root.sendall(st.pack("<d", float(value)))
+        return st.unpack("<d", self._recv(self.root, 8))[0]
+
+    def barrier(self):
+        self.allreduce_max(0.0)
+
+    def close(self):
+        for conn in list(self.peers.values()) + ([self.root] if self.root is not None else []):
+            try:
+                conn.close()
+            except OSError:
+                pass
+        self.peers, self.root = {}, None
+
+
 class Communicator:
     """RCCL communicator of the engine (one rank per process / GPU)."""
 
@@ -77,8 +176,9 @@ class Communicator:
         self.handle = h
 
     @classmethod
-    def from_env(cls, ctx, timeout=300.0):
-        """rank / world / rendezvous address from the launcher's environment"""
+    def from_env(cls, ctx, timeout=300.0, rendezvous=None):
+        """rank / world / rendezvous address from the launcher's environment; with a ``Rendezvous`` the unique id travels over
+        its connections (otherwise rank 0 serves it once on MASTER_PORT + PORT_OFFSET)"""
         from ._lib import check
 
         rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,6 +188,8 @@ class Communicator:
             check(ctx.lib.sd_comm_unique_id(buf))
             return buf.raw
 
+        if rendezvous is not None:
+            return cls(ctx, rank, world, rendezvous.broadcast(make_id() if rank == 0 else None))
         return cls(ctx, rank, world, exchange_unique_id(rank, world, make_id, timeout=timeout))
 
     def close(self):

@@ -341,3 +341,38 @@ def test_pointwise_runner_xarray():
     assert isinstance(predc, xr.DataArray) and dict(predc.sizes) == dict(y.sizes)
     assert predc.chunks == yc.chunks
     np.testing.assert_allclose(predc.values, pred.values, rtol=1e-12)
+
+
+RDV_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.path.join(r"{root}", "scikit-downscale_amd"))
+from skdownscale_amd.shard import Rendezvous
+rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+rdv = Rendezvous(rank, world, addr="127.0.0.1", port=port, timeout=60.0)
+payload = rdv.broadcast(bytes(range(128)) if rank == 0 else None)
+assert payload == bytes(range(128))
+for step in range(3):
+    m = rdv.allreduce_max(10.0 * step + rank)
+    assert m == 10.0 * step + world - 1, (rank, step, m)
+rdv.barrier()
+rdv.close()
+print("ok", rank)
+"""
+
+
+def test_tcp_rendezvous_three_ranks(tmp_path):
+    """the control plane of bench.py at N > 1 (unique-id broadcast, barrier, max-over-ranks clock): three processes on CPU"""
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "rdv_worker.py"
+    script.write_text(RDV_WORKER.format(root=ROOT))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in (2, 1, 0)]  # the clients start first and retry until rank 0 listens
+    outs = [p.communicate(timeout=120) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0 and out.startswith("ok"), (out, err)
