@@ -170,21 +170,28 @@ def end_to_end(ctx, index, seed, c_full, n_cells=8192):
     cells = np.arange(n_cells)
     X, y, Xp = (synth.tas_field(name, seed, index, cells, c_full) for name in ("X_hist", "y_obs", "X_fut"))
     gid = (np.asarray(index.month) - 1).astype(np.int32)
-    times = []
-    for it in range(7):  # the first passes wake the copy engines / the link up after the CPU legs (the first ones run ~1.6x slower)
-        t0 = time.perf_counter()
-        st = ctx.bcsd_fit(_lib.BCSD_TAS, X, y, gid, 12, True)
-        out, _ = ctx.bcsd_predict(st, Xp, gid)  # a fresh result array every pass
-        dt = time.perf_counter() - t0
-        st.close()
-        if it >= 2:
-            times.append(dt)
-    best, median = min(times), sorted(times)[len(times) // 2]
+    def passes(n, reuse):
+        times, buf = [], (np.empty_like(Xp) if reuse else None)
+        for it in range(n):
+            t0 = time.perf_counter()
+            st = ctx.bcsd_fit(_lib.BCSD_TAS, X, y, gid, 12, True)
+            out, _ = ctx.bcsd_predict(st, Xp, gid, out=buf)
+            dt = time.perf_counter() - t0
+            st.close()
+            del out
+            if it >= 2:  # the first passes create the staging buffers, the device blocks and (reuse) touch the result buffer
+                times.append(dt)
+        return sorted(times)[len(times) // 2], min(times)
+
+    fresh, fresh_best = passes(5, False)   # a new NumPy result array every pass: its first-touch page faults are in the time
+    reused, reused_best = passes(7, True)  # the caller's result buffer, reused (a pipeline writing one slab after the other)
     moved = 4 * X.nbytes
-    return {"value": n_cells / median, "unit": "cells/s", "cells": n_cells, "seconds": median, "best_seconds": best, "passes": len(times),
-            "warmup_passes": 2, "host_bytes_moved": moved, "effective_GBps": moved / median / 1e9,
-            "path": "sd_bcsd_fit + sd_bcsd_predict on pageable NumPy arrays (H2D of X_hist, y_obs, X_fut; D2H into a fresh result array); "
-                    "median of the timed passes"}
+    return {"value": n_cells / reused, "unit": "cells/s", "cells": n_cells, "seconds": reused, "best_seconds": reused_best,
+            "host_bytes_moved": moved, "effective_GBps": moved / reused / 1e9,
+            "fresh_result_array": {"value": n_cells / fresh, "seconds": fresh, "best_seconds": fresh_best, "effective_GBps": moved / fresh / 1e9},
+            "path": "sd_bcsd_fit + sd_bcsd_predict on pageable NumPy arrays (H2D of X_hist, y_obs, X_fut; D2H of the result), median of "
+                    "the timed passes; value: result buffer reused across passes; fresh_result_array: np.empty per pass (first-touch "
+                    "page faults of ~1 GB included: 4 KB pages fault at ~14 GB/s on this host unless free huge pages are at hand)"}
 
 
 # ---- the benchmark ----------------------------------------------------------------------------------------------------

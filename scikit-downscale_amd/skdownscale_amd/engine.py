@@ -347,7 +347,10 @@ class Context:
         else:
             Xp = _lib.as_f64(Xp)
             Tp = Xp.shape[0]
-            out = np.empty((Tp, Cc))
+            if out is None:
+                out = np.empty((Tp, Cc))
+            elif not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == (Tp, Cc) and out.flags["C_CONTIGUOUS"]):
+                raise ValueError(f"out: expected a C-contiguous float64 array of shape {(Tp, Cc)}")  # (a reused result buffer)
             check(self.lib.sd_bcsd_predict(self.handle, state.vptr, ptr(Xp), ptr(gid_p), Tp, ptr(out), ptr(status)))
         return out, status
 
