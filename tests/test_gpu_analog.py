@@ -130,6 +130,24 @@ def test_regression_prefix_path_edges(ctx, case):
     assert_close(out, exp, what=f"regression {case}")
 
 
+@pytest.mark.parametrize("T,Tq,k", [(2000, 20000, 30), (16384, 16385, 1), (1024, 40000, 200), (700, 14600, 700)])
+def test_mean_path_many_queries_and_size_limits(ctx, T, Tq, k):
+    """the BASELINE kernel (mean_analogs without a threshold, or one analog) beyond one pass of queries (16 x 1024 per
+    workgroup pass), at the longest series the index tags of the fit serve (16 384), with k up to the series length"""
+    rng = np.random.default_rng(T + k)
+    C = 2
+    X, Xq = rng.standard_normal((T, 1, C)), 1.1 * rng.standard_normal((Tq, 1, C))
+    y = 0.5 * X[:, 0, :] + rng.standard_normal((T, C))
+    st = ctx.analog_fit(X, y)
+    kind = "mean_analogs" if k > 1 else "best_analog"
+    out, status = ctx.analog_predict(st, Xq, k, KINDS[kind])
+    assert (status == 0).all()
+    sel = np.unique(np.concatenate([np.arange(300), np.arange(Tq - 300, Tq), rng.integers(0, Tq, 400)]))  # (the oracle is a loop)
+    exp = ao.pointwise_analog(X, y, Xq[sel], k, KINDS[kind], None)
+    assert_close(out[sel], exp, what=f"mean path T={T} Tq={Tq} k={k}")
+    assert np.isfinite(out).all()
+
+
 @pytest.mark.parametrize("case", ["constant_y", "dry_spells", "wet_spells"])
 def test_pure_analog_constant_windows_full_length(ctx, case):
     """PureAnalog mean / weight (gard.py:301-346) at the BASELINE series length with windows of identical analog values:
