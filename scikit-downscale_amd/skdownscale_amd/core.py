@@ -17,8 +17,8 @@ import numpy as np
 import pandas as pd
 
 from . import _lib
-from .bcsd import BcsdBase, BcsdGridModel, check_supported
-from .gard import AnalogBase, AnalogGridModel, AnalogRegression, PureAnalog, PureRegression, RegressionGridModel
+from .bcsd import BcsdBase, check_supported
+from .gard import AnalogGridModel, AnalogRegression, PureAnalog, PureRegression, RegressionGridModel
 from .quantile import (CunnaneGridModel, CunnaneTransformer, QmGridModel, QuantileMapper, QuantileMapperGridModel,
                        QuantileMappingReressor, check_extrapolate)
 

@@ -13,7 +13,6 @@ from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.exceptions import NotFittedError
 from sklearn.utils import check_array
 
-from . import _lib
 from .engine import default_context
 
 FittedLine = collections.namedtuple("FittedLine", ["coef_", "intercept_"])  # the lr_model_ attributes trend.py:50-51 leaves behind
