@@ -492,6 +492,36 @@ def test_float32_inputs_follow_the_reference():
     assert_close(mp.predict(pd.DataFrame(P32[:, :1], index=index)).values[:, 0], pexp[:, 0], what="float32 precipitation")
 
 
+def test_pointwise_downscaler_xarray_inputs_on_the_engine():
+    """xarray DataArrays in and out of the batched BCSD path (core.py:225-336), whole and spatially chunked; get_attr with a
+    template.  Uses the real xarray where installed, else the stand-in of tests/xarray_stub (see its docstring)."""
+    xr = pytest.importorskip("xarray")
+    from skdownscale_amd import BcsdTemperature, GridArray, PointWiseDownscaler
+
+    g = load("g7_masked")
+    index, index_p, X, y, Xp = tas_inputs(g)
+    T = X.shape[0]
+    mk = lambda a, idx: xr.DataArray(a.reshape(T, 2, 3), dims=("time", "y", "x"), coords={"time": idx, "y": np.arange(2), "x": np.arange(3)})  # noqa: E731
+    mg = lambda a, idx: GridArray(a.reshape(T, 2, 3), ("time", "y", "x"), {"time": idx, "y": np.arange(2), "x": np.arange(3)})  # noqa: E731
+    ref = PointWiseDownscaler(BcsdTemperature())
+    ref.fit(mg(X, index), mg(y, index))
+    expected = ref.predict(mg(Xp, index_p)).values
+    pw = PointWiseDownscaler(BcsdTemperature())
+    pw.fit(mk(X, index), mk(y, index))
+    out = pw.predict(mk(Xp, index_p))
+    assert isinstance(out, xr.DataArray) and tuple(out.dims) == ("time", "y", "x")
+    assert np.array_equal(out.values, expected, equal_nan=True)
+    assert_close(out.values.reshape(T, 6), g["out_anoms"], what="xarray in / out")
+    chunked = PointWiseDownscaler(BcsdTemperature())
+    chunked.fit(mk(X, index).chunk({"y": 1, "x": 2}), mk(y, index).chunk({"y": 1, "x": 2}))
+    outc = chunked.predict(mk(Xp, index_p).chunk({"y": 1, "x": 2}))
+    assert isinstance(outc, xr.DataArray) and np.array_equal(outc.values, expected, equal_nan=True)
+    template = xr.DataArray(np.zeros((12, 2, 3)), dims=("month", "y", "x"), coords={"month": np.arange(1, 13)})
+    yc = pw.get_attr("y_climo_", template_output=template)
+    assert isinstance(yc, xr.DataArray) and dict(yc.sizes) == {"month": 12, "y": 2, "x": 3}
+    np.testing.assert_allclose(yc.values, ref.get_attr("y_climo_").values, rtol=0, atol=0, equal_nan=True)
+
+
 def test_per_group_kernel_width(dev_ctx, monkeypatch):
     """A 40-year daily series has 31-day months (1 240 samples: 21 per lane) and shorter ones (<= 1 216: 19 per lane):
     the shorter months get their own launch of the narrower kernels sharing the hand-off slabs.  The result must not

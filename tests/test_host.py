@@ -313,8 +313,10 @@ def test_pointwise_runner_restated(shape, chunks):
 
 
 def test_pointwise_runner_xarray():
-    """The same through xarray objects, numpy- and dask-backed (test_pointwise_runner.py:13-63) -- runs where xarray is
-    installed."""
+    """The same through xarray objects (test_pointwise_runner.py:13-63): Dataset / DataArray in, DataArray out, chunked inputs
+    block by block with the chunk structure preserved.  Where xarray is not installed (this container, the GPU box) the
+    minimal stand-in of tests/xarray_stub runs instead -- it has xarray's dims / coords / isel / to_array / chunk metadata
+    but nothing lazy."""
     xr = pytest.importorskip("xarray")
     from sklearn.linear_model import LinearRegression
     from sklearn.pipeline import Pipeline
@@ -326,16 +328,44 @@ def test_pointwise_runner_xarray():
     times = pd.date_range("2000-01-01", periods=100)
     ds = xr.Dataset({k: (("time", "y", "x"), rng.random((100, 2, 3))) for k in "abc"}, coords={"time": times})
     y = xr.DataArray(rng.random((100, 2, 3)), dims=("time", "y", "x"), coords={"time": times})
-    model = PointWiseDownscaler(Pipeline([("scaler", StandardScaler()), ("lr", LinearRegression())]))
+    pipe = lambda: Pipeline([("scaler", StandardScaler()), ("lr", LinearRegression())])  # noqa: E731
+    model = PointWiseDownscaler(pipe())
     model.fit(ds, y)
     pred = model.predict(ds)
     assert isinstance(pred, xr.DataArray) and dict(pred.sizes) == dict(y.sizes)
-    try:
-        import dask  # noqa: F401
-    except ImportError:
+    expected = np.empty((100, 2, 3))
+    X3 = np.stack([ds[k].values for k in "abc"], axis=1)  # [time, variable, y, x]
+    for j in range(2):
+        for i in range(3):
+            expected[:, j, i] = pipe().fit(X3[:, :, j, i], y.values[:, j, i]).predict(X3[:, :, j, i])
+    np.testing.assert_allclose(pred.values, expected, rtol=1e-12)
+    # y with its spatial dims in another order is aligned by name (core.py:86-93 selects y[index] by dimension name)
+    yt = xr.DataArray(y.values.transpose(0, 2, 1), dims=("time", "x", "y"), coords={"time": times})
+    model_t = PointWiseDownscaler(pipe())
+    model_t.fit(ds, yt)
+    np.testing.assert_allclose(model_t.predict(ds).values, expected, rtol=1e-12)
+    # transformers and attributes come back as xarray objects as well
+    scaler = PointWiseDownscaler(StandardScaler())
+    scaler.fit(ds)
+    xt = scaler.transform(ds)
+    assert isinstance(xt, xr.DataArray) and xt.sizes["variable"] == 3
+    np.testing.assert_allclose(scaler.inverse_transform(xt).values[:, 0], ds["a"].values, rtol=1e-9)
+    template = xr.DataArray(np.zeros((3, 2, 3)), dims=("var", "y", "x"), coords={"var": np.arange(3)})
+    scale = scaler.get_attr("scale_", dtype="float64", template_output=template)
+    assert isinstance(scale, xr.DataArray) and dict(scale.sizes) == {"var": 3, "y": 2, "x": 3}
+    np.testing.assert_allclose(scale.values[0], ds["a"].values.std(axis=0), rtol=1e-9)
+    if xr.__version__.endswith("stub"):
+        chunked = True
+    else:
+        try:
+            import dask  # noqa: F401
+            chunked = True
+        except ImportError:
+            chunked = False
+    if not chunked:
         return
     dsc, yc = ds.chunk({"y": 1, "x": 1}), y.chunk({"y": 1, "x": 1})
-    model = PointWiseDownscaler(Pipeline([("scaler", StandardScaler()), ("lr", LinearRegression())]))
+    model = PointWiseDownscaler(pipe())
     model.fit(dsc, yc)
     predc = model.predict(dsc)
     assert isinstance(predc, xr.DataArray) and dict(predc.sizes) == dict(y.sizes)
