@@ -500,6 +500,7 @@ def test_pointwise_downscaler_xarray_inputs_on_the_engine():
 
     g = load("g7_masked")
     index, index_p, X, y, Xp = tas_inputs(g)
+    X[0, 1] = X[0, 4] = y[0, 1] = np.nan  # the masked cells of the golden case (core.py:35-37)
     T = X.shape[0]
     mk = lambda a, idx: xr.DataArray(a.reshape(T, 2, 3), dims=("time", "y", "x"), coords={"time": idx, "y": np.arange(2), "x": np.arange(3)})  # noqa: E731
     mg = lambda a, idx: GridArray(a.reshape(T, 2, 3), ("time", "y", "x"), {"time": idx, "y": np.arange(2), "x": np.arange(3)})  # noqa: E731
