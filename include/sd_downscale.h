@@ -184,7 +184,8 @@ int sd_bcsd_state_destroy(sd_bcsd_state* st);
  * X: [T,F,C], y: [T,C], Xq: [Tq,F,C]; out: [Tq,3,C] columns pred / exceedance_prob /
  * prediction_error (gard.py:254-255).  inds: int64 [Tq,k,C] training indices, ascending distance
  * (may be NULL); dist: float64 [Tq,k,C] (may be NULL).  sample_inds: int32 [Tq,C], required for
- * SD_ANALOG_SAMPLE (the host draws them with np.random.randint like gard.py:315). */
+ * SD_ANALOG_SAMPLE (the host draws them with np.random.randint like gard.py:315).  k == 1 is 'best_analog' whatever
+ * `kind` says (gard.py:291-296). */
 int sd_analog_fit(sd_ctx* ctx, const double* X, const double* y, int64_t T, int F, int64_t C, sd_analog_state** out);
 int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t ld, int64_t T, int F, int64_t C,
                       sd_analog_state** out);

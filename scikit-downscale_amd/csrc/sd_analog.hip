@@ -2422,6 +2422,9 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
     SD_HIP(hipSetDevice(ctx->device));
     const int64_t C = st->C, T = st->T;
     const int F = st->F;
+    // PureAnalog.predict with a single analog is 'best_analog' whatever the configured kind (gard.py:291-296: n_analogs == 1);
+    // the entry point sees k only, so a one-sample training set (k_ = 1 with n_analogs > 1) is treated the same way
+    if (mode == 0 && k == 1) kind = SD_ANALOG_BEST;
     PredictArgs pa;
     pa.k = k;
     pa.kind = kind;

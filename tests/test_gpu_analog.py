@@ -130,6 +130,22 @@ def test_regression_prefix_path_edges(ctx, case):
     assert_close(out, exp, what=f"regression {case}")
 
 
+def test_single_analog_is_best_analog_whatever_the_kind(ctx):
+    """gard.py:291-296: n_analogs == 1 turns every kind into 'best_analog' (the analog itself, also when a threshold masks
+    it) -- at the C ABI as well, not only in the estimator class"""
+    rng = np.random.default_rng(31)
+    X, Xq = rng.standard_normal((500, 1, 3)), rng.standard_normal((120, 1, 3))
+    y = rng.standard_normal((500, 3))
+    st = ctx.analog_fit(X, y)
+    for thresh in (None, 0.0):
+        best, _ = ctx.analog_predict(st, Xq, 1, KINDS["best_analog"], thresh)
+        assert_close(best, ao.pointwise_analog(X, y, Xq, 1, KINDS["best_analog"], thresh), what=f"best thresh={thresh}")
+        for kind in ("mean_analogs", "weight_analogs"):
+            out, _ = ctx.analog_predict(st, Xq, 1, KINDS[kind], thresh)
+            assert np.array_equal(out, best, equal_nan=True), (kind, thresh)
+            assert_close(out, ao.pointwise_analog(X, y, Xq, 1, KINDS[kind], thresh), what=f"{kind} k=1 thresh={thresh}")
+
+
 @pytest.mark.parametrize("T,Tq,k", [(2000, 20000, 30), (16384, 16385, 1), (1024, 40000, 200), (700, 14600, 700)])
 def test_mean_path_many_queries_and_size_limits(ctx, T, Tq, k):
     """the BASELINE kernel (mean_analogs without a threshold, or one analog) beyond one pass of queries (16 x 1024 per

@@ -31,24 +31,33 @@ def main(n_cases=40, seed=0):
             # tie-heavy data on a dyadic grid: sums are exact, so the tie structure does not depend on the order of
             # the climatology / rolling sums (with inexact decimals it does -- in the reference as well)
             q = float(rng.choice([1, 4, 16]))
-            f = (lambda n: np.round((10 + 3 * rng.standard_normal((n, C))) * q) / q) if rng.random() < 0.4 else (lambda n: 10 + 3 * rng.standard_normal((n, C)))
+            dyadic = rng.random() < 0.4
+            f = (lambda n: np.round((10 + 3 * rng.standard_normal((n, C))) * q) / q) if dyadic else (lambda n: 10 + 3 * rng.standard_normal((n, C)))
             X, y, Xp = f(T), f(T) + 20, f(Tp)
+            # qm_kwargs={'detrend': True}: continuous data only (a removed line turns exact ties into rounding-level near-ties,
+            # whose order is unpinned in the reference as well), segments the register-sort kernels serve
+            longest = max(np.bincount(gid, minlength=G).max(), np.bincount(gid_p, minlength=G).max())
+            detrend = bool(not dyadic and longest <= 2112 and rng.random() < 0.5)
+            if detrend:
+                X, y, Xp = (a + 1e-3 * rng.standard_normal() * np.arange(len(a))[:, None] for a in (X, y, Xp))
             if kind == 1:
                 X, y, Xp = np.abs(X) * (rng.random(X.shape) > 0.4), np.abs(y) + 0.1, np.abs(Xp) * (rng.random(Xp.shape) > 0.4)
             ra = bool(rng.integers(0, 2))
-            exp, est = bo.pointwise_fit_predict(kind, X, y, Xp, gid, gid_p, G=G, return_anoms=ra)
-            st = ctx.bcsd_fit(kind, X, y, gid, G, ra)
+            exp, est = bo.pointwise_fit_predict(kind, X, y, Xp, gid, gid_p, G=G, return_anoms=ra, detrend=detrend)
+            st = ctx.bcsd_fit(kind, X, y, gid, G, ra, detrend=detrend)
             out, status = ctx.bcsd_predict(st, Xp, gid_p)
             assert np.array_equal(status, est), (it, status, est)
-            assert_close(out, exp, what=f"case {it} bcsd kind={kind} G={G} T={T} Tp={Tp} C={C}")
-            fused, _ = ctx.bcsd_fit_predict(kind, ctx.to_device(X), ctx.to_device(y), gid, G, ctx.to_device(Xp), gid_p, ra)
+            assert_close(out, exp, what=f"case {it} bcsd kind={kind} G={G} T={T} Tp={Tp} C={C} detrend={detrend}")
+            fused, _ = ctx.bcsd_fit_predict(kind, ctx.to_device(X), ctx.to_device(y), gid, G, ctx.to_device(Xp), gid_p, ra, detrend=detrend)
             assert_close(fused.to_host(), exp, what=f"case {it} fused")
         elif what == "analog":
             F = int(rng.choice([1, 1, 1, 2, 4]))
-            T = int(rng.integers(40, 3000))
-            Tq = int(rng.integers(1, 600))
+            T = int(rng.integers(40, 3000)) if rng.random() < 0.8 else int(rng.integers(5000, 16385))
+            Tq = int(rng.integers(1, 600)) if rng.random() < 0.8 else int(rng.integers(15000, 20000))
             C = int(rng.integers(1, 6))
             k = int(rng.integers(1, min(T, 64)))
+            if F > 1:
+                T, Tq = min(T, 3000), min(Tq, 600)  # (the oracle is a Python loop over queries)
             quant = rng.random() < 0.4
             X = rng.standard_normal((T, F, C))
             Xq = rng.standard_normal((Tq, F, C))
@@ -60,8 +69,10 @@ def main(n_cases=40, seed=0):
             kk = 1 if kind == 0 else k
             thresh = None if rng.random() < 0.5 else 0.0
             out, _ = ctx.analog_predict(st, Xq, kk, kind, thresh)
-            exp = ao.pointwise_analog(X, y, Xq, kk, kind, thresh)
-            assert_close(out, exp, what=f"case {it} analog F={F} T={T} Tq={Tq} k={kk} kind={kind} thresh={thresh} quant={quant}")
+            sel = np.arange(Tq) if Tq <= 800 else np.unique(rng.integers(0, Tq, 800))
+            exp = ao.pointwise_analog(X, y, Xq[sel], kk, kind, thresh)
+            assert_close(out[sel], exp, what=f"case {it} analog F={F} T={T} Tq={Tq} k={kk} kind={kind} thresh={thresh} quant={quant}")
+            Xq = Xq[sel[:200]]
             out, _ = ctx.analogreg_predict(st, Xq, k)
             # k <= F + 1 is under-determined: the reference's lstsq cut-off (eps * max(k, F)) sits at the rounding level of
             # the centred analogs, its answer flips between the minimum-norm solution and noise -- unpinned
