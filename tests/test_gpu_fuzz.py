@@ -1,5 +1,5 @@
 """GPU: randomised parity sweep (random sizes, group layouts, tie-heavy dyadic data, kinds) of the BCSD, analog and
-quantile-mapping paths against the oracles; the generator lives in tools/dev/fuzz_gpu.py."""
+quantile-mapping paths (incl. detrended BCSD, thresholded regressions, every extrapolate mode) against the oracles; the generator lives in tools/dev/fuzz_gpu.py."""
 import os
 import sys
 
@@ -13,4 +13,4 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def test_random_configurations(seed):
     import fuzz_gpu
 
-    fuzz_gpu.main(30, seed)
+    fuzz_gpu.main(45, seed)

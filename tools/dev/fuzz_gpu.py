@@ -18,7 +18,7 @@ def main(n_cases=40, seed=0):
     ctx = default_context()
     rng = np.random.default_rng(seed)
     for it in range(n_cases):
-        what = rng.choice(["bcsd", "analog", "qm", "knn", "cunnane", "linreg"])
+        what = rng.choice(["bcsd", "analog", "qm", "knn", "cunnane", "linreg", "linreg_thresh", "analogreg_thresh", "qm_modes"])
         if what == "bcsd":
             kind = int(rng.integers(0, 2))
             G = int(rng.choice([1, 3, 12, 12, 12]))
@@ -132,6 +132,62 @@ def main(n_cases=40, seed=0):
             exp = ao.pointwise_pure_regression(X, y, Xq)
             assert_close(out[:, 0], exp[:, 0], rtol=1e-8, scale=float(np.std(y)), what=f"case {it} linreg F={F} T={T} C={C}")
             assert_close(out[:, 2], exp[:, 2], rtol=1e-8, scale=float(np.std(y)), what=f"case {it} linreg fit error")
+        elif what == "linreg_thresh":
+            # PureRegression(thresh): logistic exceedance model + linear model on the exceeding samples (gard.py:416-470)
+            F = int(rng.integers(1, 6))
+            T = int(rng.integers(60, 3000))
+            Tq = int(rng.integers(1, 300))
+            C = int(rng.integers(1, 40))
+            X = rng.standard_normal((T, F, C)) * rng.choice([1.0, 10.0, 0.01], (1, F, 1))
+            y = np.einsum("tfc,fc->tc", X / np.abs(X).max(axis=0, keepdims=True), rng.standard_normal((F, C))) + rng.standard_normal((T, C))
+            Xq = X[rng.integers(0, T, Tq)] * 1.1
+            thresh = float(np.quantile(y, rng.uniform(0.2, 0.8)))
+            st = ctx.linreg_fit(X, y, thresh)
+            out, status = ctx.linreg_predict(st, Xq)
+            for c in range(C):
+                exc = y[:, c] > thresh
+                if exc.all() or exc.sum() <= F + 1:
+                    continue  # (the threshold is dropped / the subset fit is under-determined: covered by the tests)
+                exp = ao.pure_regression_thresh(X[:, :, c], y[:, c], Xq[:, :, c], thresh)[0]
+                assert_close(out[:, [0, 2], c], exp[:, [0, 2]], scale=float(np.std(y[:, c])), what=f"case {it} linreg thresh F={F} T={T} cell {c}")
+                assert np.abs(out[:, 1, c] - exp[:, 1]).max() < 1e-6, f"case {it} linreg thresh probability F={F} T={T} cell {c}"
+        elif what == "analogreg_thresh":
+            # AnalogRegression(thresh): per query, logistic model over the analogs + linear model on the exceeding ones
+            F = int(rng.integers(1, 4))
+            T = int(rng.integers(150, 2500))
+            Tq = int(rng.integers(1, 120))
+            C = int(rng.integers(1, 4))
+            k = int(rng.integers(24, 64))
+            X, Xq = rng.standard_normal((T, F, C)), rng.standard_normal((Tq, F, C))
+            y = 0.3 * X.sum(axis=1) + rng.standard_normal((T, C))
+            thresh = float(np.median(y))
+            st = ctx.analog_fit(X, y)
+            out, status = ctx.analogreg_predict(st, Xq, k, thresh)
+            try:
+                exp = ao.pointwise_analog(X, y, Xq, k, None, thresh=thresh, regression=True)
+            except ValueError:
+                print(f"case {it}: analogreg_thresh one-class query (skipped)", flush=True)
+                continue
+            assert_close(out[:, [0, 2]], exp[:, [0, 2]], what=f"case {it} analogreg thresh F={F} T={T} k={k}")
+            assert np.abs(out[:, 1] - exp[:, 1]).max() < 1e-6, f"case {it} analogreg thresh probability F={F} T={T} k={k}"
+        elif what == "qm_modes":
+            # QuantileMappingReressor / EquidistantCdfMatcher with synthetic end points, samples inside the fitted range
+            T = int(rng.integers(25, 6000))
+            Tp = int(rng.integers(1, 4000))
+            C = int(rng.integers(1, 10))
+            ne = int(rng.integers(2, 12))
+            X, y = 5 + 2 * rng.standard_normal((T, C)), 15 + 3 * rng.standard_normal((T, C))
+            lo, hi = X.min(axis=0), X.max(axis=0)
+            Xp = lo + (hi - lo) * rng.random((Tp, C))
+            st = ctx.qm_fit(X, y)
+            for ex in ("min", "max", "both"):
+                out, _ = ctx.qm_predict(st, 0, Xp, ex, ne)
+                assert_close(out, qo.pointwise_qm("qmr", X, y, Xp, ex, ne), what=f"case {it} qmr T={T} Tp={Tp} {ex} n_endpoints={ne}")
+                for kind, code in (("difference", 1), ("ratio", 2)):
+                    out, _ = ctx.qm_predict(st, code, Xp, ex, ne)
+                    exp = qo.pointwise_qm("ecm", X, y, Xp, ex, ne, kind=kind)
+                    fin = np.isfinite(exp) & np.isfinite(out)
+                    assert_close(out[fin], exp[fin], what=f"case {it} ecm {kind} T={T} Tp={Tp} {ex} n_endpoints={ne}")
         else:
             T = int(rng.integers(21, 9000))
             Tp = int(rng.integers(1, 9000))
