@@ -18,7 +18,7 @@ def main(n_cases=40, seed=0):
     ctx = default_context()
     rng = np.random.default_rng(seed)
     for it in range(n_cases):
-        what = rng.choice(["bcsd", "analog", "qm", "knn", "cunnane", "linreg", "linreg_thresh", "analogreg_thresh", "qm_modes"])
+        what = rng.choice(["bcsd", "analog", "qm", "knn", "cunnane", "linreg", "linreg_thresh", "analogreg_thresh", "qm_modes", "nasanex"])
         if what == "bcsd":
             kind = int(rng.integers(0, 2))
             G = int(rng.choice([1, 3, 12, 12, 12]))
@@ -132,6 +132,37 @@ def main(n_cases=40, seed=0):
             exp = ao.pointwise_pure_regression(X, y, Xq)
             assert_close(out[:, 0], exp[:, 0], rtol=1e-8, scale=float(np.std(y)), what=f"case {it} linreg F={F} T={T} C={C}")
             assert_close(out[:, 2], exp[:, 2], rtol=1e-8, scale=float(np.std(y)), what=f"case {it} linreg fit error")
+        elif what == "nasanex":
+            # time_grouper='daily_nasa-nex': 366 overlapping day-of-year groups in fit, day-of-month keys + rolling mean over
+            # months in predict (bcsd.py:36-55, 247-267), random calendars, with and without detrended mapping
+            import pandas as pd
+
+            from skdownscale_amd.groupers import padded_doy_table
+
+            start = pd.Timestamp("1970-01-01") + pd.Timedelta(days=int(rng.integers(0, 3000)))
+            index = pd.date_range(start, periods=int(rng.integers(3 * 366, 9 * 366)))
+            pstart = start + pd.Timedelta(days=int(rng.integers(0, 2000)))
+            index_p = pd.date_range(pstart, periods=int(rng.integers(40, 6 * 366)))
+            C = int(rng.integers(1, 6))
+            kind = int(rng.integers(0, 2))
+            detrend = bool(rng.random() < 0.4)
+            T, Tp = len(index), len(index_p)
+            X, y, Xp = (12 + 6 * rng.standard_normal((n, C)) for n in (T, T, Tp))
+            if kind == 1:
+                X, y, Xp = np.abs(X) * (rng.random(X.shape) > 0.3), np.abs(y) + 0.2, np.abs(Xp) * (rng.random(Xp.shape) > 0.3)
+            order, offsets = padded_doy_table(index)
+            gq, gt = np.asarray(index_p.day, dtype=np.int32) - 1, np.asarray(index_p.month, dtype=np.int32) - 1
+            st = ctx.bcsd_fit_groups(kind, X, y, order, offsets, return_anoms=False, detrend=detrend)
+            out, status = ctx.bcsd_predict_trend(st, Xp, gq, gt, 12)
+            assert (status == 0).all()
+            table = bo.padded_doy_table(index)
+            for c in range(C):
+                s1, _ = bo.bcsd_fit_cell(kind, X[:, c], y[:, c], None, table=table, return_anoms=False, detrend=detrend)
+                if kind == 0:
+                    exp, _ = bo.bcsd_predict_trend_cell(s1, Xp[:, c], gq, gt, return_anoms=False)
+                else:
+                    exp, _ = bo.bcsd_predict_cell(s1, Xp[:, c], gq, return_anoms=False)
+                assert_close(out[:, c], exp, what=f"case {it} nasanex kind={kind} T={T} Tp={Tp} detrend={detrend} cell {c}")
         elif what == "linreg_thresh":
             # PureRegression(thresh): logistic exceedance model + linear model on the exceeding samples (gard.py:416-470)
             F = int(rng.integers(1, 6))
