@@ -214,27 +214,35 @@ int sdo_bcsd_fit_predict(int kind, const double* X, const double* y, const doubl
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
-    /* Cells are processed in blocks of 8 (one 64-byte line of the [T, C] field): the block's columns are
-     * gathered into contiguous per-cell series first, so the strided field is touched once per line. */
-    const int64_t nblk = (C + 7) / 8;
+    /* Cells are processed in panels of PW adjacent cells: a thread copies the panel's [T, PW] strip into per-cell
+     * series (rows of PW * 8 contiguous bytes: a 64-byte gather per row kept 128 threads waiting on the TLB), runs the
+     * per-cell model on the contiguous series and scatters the result strip back.  Panels are dealt out statically,
+     * each thread walks a contiguous range of cells. */
+    enum { PW = 64 };
+    const int64_t npan = (C + PW - 1) / PW;
 #pragma omp parallel
     {
         double* buf = (double*)malloc(sizeof(double) * 8 * (size_t)nmax);
-        double* cx = (double*)malloc(sizeof(double) * 8 * (size_t)(2 * T + 2 * Tp));
-        double* cy = cx + 8 * T;
-        double* cp = cy + 8 * T;
-        double* co = cp + 8 * Tp;
-#pragma omp for schedule(dynamic, 1)
-        for (int64_t b = 0; b < nblk; ++b) {
-            const int64_t c0 = b * 8;
-            const int w = (int)((C - c0) < 8 ? (C - c0) : 8);
-            for (int64_t t = 0; t < T; ++t)
+        double* cx = (double*)malloc(sizeof(double) * PW * (size_t)(2 * T + 2 * Tp));
+        double* cy = cx + (size_t)PW * T;
+        double* cp = cy + (size_t)PW * T;
+        double* co = cp + (size_t)PW * Tp;
+#pragma omp for schedule(static)
+        for (int64_t b = 0; b < npan; ++b) {
+            const int64_t c0 = b * PW;
+            const int w = (int)((C - c0) < PW ? (C - c0) : PW);
+            for (int64_t t = 0; t < T; ++t) {
+                const double* xr = X ? X + t * C + c0 : NULL;
+                const double* yr = y + t * C + c0;
                 for (int k = 0; k < w; ++k) {
-                    if (X) cx[k * T + t] = X[t * C + c0 + k];
-                    cy[k * T + t] = y[t * C + c0 + k];
+                    if (xr) cx[k * T + t] = xr[k];
+                    cy[k * T + t] = yr[k];
                 }
-            for (int64_t t = 0; t < Tp; ++t)
-                for (int k = 0; k < w; ++k) cp[k * Tp + t] = Xp[t * C + c0 + k];
+            }
+            for (int64_t t = 0; t < Tp; ++t) {
+                const double* pr = Xp + t * C + c0;
+                for (int k = 0; k < w; ++k) cp[k * Tp + t] = pr[k];
+            }
             for (int k = 0; k < w; ++k) {
                 const int st = bcsd_cell(kind, X ? cx + k * T : NULL, cy + k * T, 1, cp + k * Tp, 1, ord, off, ordp, offp, G,
                                          return_anoms, co + k * Tp, 1, buf, nmax);
@@ -242,8 +250,10 @@ int sdo_bcsd_fit_predict(int kind, const double* X, const double* y, const doubl
                 if (st != ST_OK)
                     for (int64_t t = 0; t < Tp; ++t) co[k * Tp + t] = NAN; /* core.py:119 */
             }
-            for (int64_t t = 0; t < Tp; ++t)
-                for (int k = 0; k < w; ++k) out[t * C + c0 + k] = co[k * Tp + t];
+            for (int64_t t = 0; t < Tp; ++t) {
+                double* orow = out + t * C + c0;
+                for (int k = 0; k < w; ++k) orow[k] = co[k * Tp + t];
+            }
         }
         free(buf);
         free(cx);
