@@ -22,8 +22,11 @@ adds the gather to rank 0 over xGMI, chunked by cells so that a chunk's transfer
 reports `value_with_gather`.
 
 Also in the line: `roofline` (algorithmic bytes / kernel time from HIP events on the engine's stream), `end_to_end` (the
-host-buffer API on NumPy arrays: PCIe inclusive), `cpu_baseline` (plain-C port, OpenMP on one socket) and
-`cpu_baseline_numpy` (the per-cell NumPy restatement on one core), both on bounded samples, rank 0 at N = 1 only.
+host-buffer API on NumPy arrays: PCIe inclusive), `pointwise_end_to_end` (the same through
+PointWiseDownscaler on host grids), `cpu_baseline` (per config: plain-C port with OpenMP for the BCSD flavours, the NumPy restatement
+on one process per core for PureAnalog; one thread / process per physical core of one socket), `cpu_baseline_numpy` (the per-cell
+NumPy restatement on one core) and `cpu_baseline_numpy_socket` (the same on one process per physical core), all on bounded samples,
+rank 0 at N = 1 only; `parity_check` compares the engine's output for the first cells with the oracle's for every config.
 """
 from __future__ import annotations
 
@@ -69,14 +72,16 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline, cpu_baseline_numpy and end_to_end")
     ap.add_argument("--check-cells", type=int, default=32, help="cells verified against the oracle outside the timed region")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)  # internal: one process of the N-process NumPy leg
     return ap.parse_args()
 
 
 # ---- CPU baselines (rank 0, N = 1; outside every timed region) ------------------------------------------------------
 
 def host_cpu_info():
-    """model / sockets / cores from lscpu, and the hardware threads of socket 0"""
+    """model / sockets / cores from lscpu; the hardware threads of socket 0 and one hardware thread per physical core of it"""
     info = {"model": None, "sockets": None, "cores_per_socket": None, "threads_per_core": None}
+    allowed = os.sched_getaffinity(0)
     try:
         for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
             k, _, v = line.partition(":")
@@ -89,77 +94,171 @@ def host_cpu_info():
                 info["cores_per_socket"] = int(v)
             elif k == "Thread(s) per core":
                 info["threads_per_core"] = int(v)
-        cpus = []
-        for line in subprocess.run(["lscpu", "-p=CPU,SOCKET"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+        cpus, first_of_core = [], {}
+        for line in subprocess.run(["lscpu", "-p=CPU,CORE,SOCKET"], capture_output=True, text=True, timeout=10).stdout.splitlines():
             if line and not line.startswith("#"):
-                cpu, sock = line.split(",")[:2]
-                if sock in ("0", ""):
+                cpu, core, sock = (line.split(",") + ["", ""])[:3]
+                if sock in ("0", "") and int(cpu) in allowed:
                     cpus.append(int(cpu))
-        allowed = os.sched_getaffinity(0)
-        info["socket0_cpus"] = sorted(set(cpus) & allowed) or sorted(allowed)
+                    first_of_core.setdefault(core, int(cpu))
+        info["socket0_cpus"] = sorted(cpus) or sorted(allowed)
+        info["socket0_cores"] = sorted(first_of_core.values()) or sorted(allowed)
     except Exception:  # noqa: BLE001
-        info["socket0_cpus"] = sorted(os.sched_getaffinity(0))
+        info["socket0_cpus"] = sorted(allowed)
+        info["socket0_cores"] = sorted(allowed)
     return info
 
 
-def cpu_baseline(index, seed, c_full, target_seconds, check=None):
-    """(B) the plain-C restatement (oracle/sd_oracle.c, 'port': OpenMP over cell blocks) on the hardware threads of ONE
-    socket, bounded sample; (A) the per-cell NumPy restatement (oracle/bcsd_oracle.py: the reference's steps per cell and
-    month -- sort, searchsorted, interp) on one core.  The first (small) C run doubles as the checker of the engine's
-    output: ``check(exp)`` receives the oracle's result for the first cells (outside the timed region)."""
+def host_fields(kind, seed, T, cells, c_full):
+    """the workload's synthetic fields for the given cells on the host (bit-identical mirror of the device generator)"""
+    from skdownscale_amd import synth
+
+    if kind == "bcsd_tas":
+        index = synth.daily_calendar(T)
+        return tuple(synth.tas_field(name, seed, index, cells, c_full) for name in ("X_hist", "y_obs", "X_fut"))
+    if kind == "bcsd_pr":
+        return tuple(synth.pr_field(name, seed, T, cells, c_full) for name in ("X_hist", "y_obs", "X_fut"))
+    return synth.analog_fields(seed, T, cells, c_full)  # X [T,1,C], y [T,C], Xq [T,1,C]
+
+
+def numpy_cells(kind, fields, gid, lo, hi):
+    """the per-cell NumPy restatement of the reference's loop (core.py:69-143) over cells [lo, hi) of `fields`"""
+    if kind == "analog":
+        X, y, Xq = fields
+        try:  # the reference's own neighbour search (gard.py:58-87: sklearn KDTree, gard.py:292: tree.query(X, k))
+            from sklearn.neighbors import KDTree
+        except ImportError:  # brute-force restatement (~25 s per cell)
+            import analog_oracle
+
+            return analog_oracle.pointwise_analog(X[:, :, lo:hi], y[:, lo:hi], Xq[:, :, lo:hi], 30, analog_oracle.KIND_MEAN)
+        out = np.empty((Xq.shape[0], 3, hi - lo))
+        for c in range(lo, hi):
+            _, inds = KDTree(X[:, :, c]).query(Xq[:, :, c], k=30)
+            analogs = y[:, c][inds]                      # gard.py:301
+            out[:, 0, c - lo] = analogs.mean(axis=1)      # gard.py:329-333 (kind='mean_analogs')
+            out[:, 1, c - lo] = 1.0                       # gard.py:346
+            out[:, 2, c - lo] = analogs.std(axis=1)       # gard.py:345
+        return out
+    import bcsd_oracle
+
+    X, y, Xp = fields
+    out, _ = bcsd_oracle.pointwise_fit_predict(0 if kind == "bcsd_tas" else 1, X[:, lo:hi], y[:, lo:hi], Xp[:, lo:hi], gid, gid)
+    return out
+
+
+def _numpy_worker(job):
+    """one process of the N-process NumPy leg: pinned to one core, its own cells, runs until the deadline"""
+    kind, seed, T, c_full, first, count, seconds, cpu = job
+    try:
+        os.sched_setaffinity(0, {cpu})
+    except OSError:
+        pass
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "scikit-downscale_amd"))
+    from skdownscale_amd import synth
+
+    gid = (np.asarray(synth.daily_calendar(T).month) - 1).astype(np.int32)
+    fields = host_fields(kind, seed, T, np.arange(first, first + count), c_full)
+    numpy_cells(kind, fields, gid, 0, 1)  # imports, first-touch
+    t0, done = time.perf_counter(), 0
+    while done < count and (done == 0 or time.perf_counter() - t0 < seconds):
+        numpy_cells(kind, fields, gid, done, done + 1)
+        done += 1
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline(kind, T, seed, c_full, target_seconds, check=None):
+    """CPU legs of one workload, on ONE socket of the GPU box, bounded samples, outside every timed region:
+      port        BCSD: the plain-C restatement (oracle/sd_oracle.c, OpenMP, contiguous cell panels per thread), one thread per
+                  physical core; PureAnalog: the reference's per-cell steps (sklearn KDTree + NumPy) on one process per physical core
+      numpy_1     the per-cell NumPy restatement of the reference's loop on one core
+      numpy_n     the same on one process per physical core of the socket
+    The oracle's result for the first cells is handed to ``check`` (parity of the engine's output for the same cells)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from skdownscale_amd import synth
 
     cpu = host_cpu_info()
+    cores = cpu["socket0_cores"]
     before = os.sched_getaffinity(0)
-    os.sched_setaffinity(0, cpu["socket0_cpus"])  # before the OpenMP runtime starts its threads
+    gid = (np.asarray(synth.daily_calendar(T).month) - 1).astype(np.int32)
+    socket_note = (f"{cpu['model']}, socket 0 of {cpu['sockets']} ({cpu['cores_per_socket']} cores x {cpu['threads_per_core']} "
+                   f"threads per socket), one thread / process per physical core: {len(cores)}")
+    port = numpy_1 = numpy_n = parity = None
     try:
-        import bcsd_oracle
-        import c_oracle
+        os.sched_setaffinity(0, cores)  # before the OpenMP runtime starts its threads
+        # ---- parity of the engine's output for the first cells (small oracle run) ----
+        n_chk = 16 if kind == "analog" else 64
+        chk_fields = host_fields(kind, seed, T, np.arange(n_chk), c_full)
+        if kind == "analog":
+            exp = numpy_cells(kind, chk_fields, gid, 0, n_chk)
+        else:
+            import c_oracle
 
-        if not c_oracle.available():
-            return None, None, None
-        threads = min(c_oracle.max_threads(), len(cpu["socket0_cpus"]))
-        gid = (np.asarray(index.month) - 1).astype(np.int32)
-
-        def fields(n):
-            cells = np.arange(n)
-            return tuple(synth.tas_field(name, seed, index, cells, c_full) for name in ("X_hist", "y_obs", "X_fut"))
-
-        def run(n, seconds=0.0):
-            X, y, Xp = fields(n)
-            spent, reps, out = 0.0, 0, None
-            while reps == 0 or (spent < seconds and reps < 16):
-                t0 = time.perf_counter()
-                out, _ = c_oracle.bcsd_fit_predict(0, X, y, Xp, gid, gid, nthreads=threads)
-                spent += time.perf_counter() - t0
-                reps += 1
-            return spent, reps, out
-
-        n0 = 4 * threads
-        dt, _, exp = run(n0)
+            exp = (c_oracle.bcsd_fit_predict(0 if kind == "bcsd_tas" else 1, *chk_fields, gid, gid, nthreads=len(cores))[0]
+                   if c_oracle.available() else numpy_cells(kind, chk_fields, gid, 0, n_chk))
         parity = check(exp) if check is not None else None
-        n = int(max(n0, min(n0 / dt * target_seconds, 8192)))
-        dt, reps, _ = run(n, target_seconds)
-        socket_note = (f"{cpu['model']}, socket 0 of {cpu['sockets']} ({cpu['cores_per_socket']} cores x {cpu['threads_per_core']} "
-                       f"threads per socket)")
-        port = {"value": n * reps / dt, "unit": "cells/s", "cores": threads, "kind": "port", "cpu": socket_note,
-                "sample": f"{n} cells x {len(index)} steps x {reps} passes, oracle/sd_oracle.c (OpenMP, {threads} threads pinned to "
-                          f"socket 0), {dt:.1f} s"}
-        # (A) one core, NumPy per cell: a few cells are enough (~0.1 s each)
-        os.sched_setaffinity(0, cpu["socket0_cpus"][:1])
-        X, y, Xp = fields(2048)
+        # ---- port ----
+        if kind != "analog":
+            import c_oracle
+
+            if c_oracle.available():
+                threads = min(c_oracle.max_threads(), len(cores))
+                k = 0 if kind == "bcsd_tas" else 1
+
+                base = host_fields(kind, seed, T, np.arange(1024), c_full)  # (generating the fields on the host is slow:
+
+                def run(n, seconds):                                          #  1 024 distinct cells, repeated up to n)
+                    f = tuple(np.ascontiguousarray(np.tile(a, (1, (n + 1023) // 1024))[:, :n]) for a in base)
+                    spent, reps = 0.0, 0
+                    while reps == 0 or (spent < seconds and reps < 32):
+                        t0 = time.perf_counter()
+                        c_oracle.bcsd_fit_predict(k, *f, gid, gid, nthreads=threads)
+                        spent += time.perf_counter() - t0
+                        reps += 1
+                    return spent, reps
+
+                n0 = 64 * threads  # one 64-cell panel per thread
+                dt, _ = run(n0, 0.0)
+                n = int(max(n0, min(n0 / dt * target_seconds, 16384))) // (64 * threads) * (64 * threads)
+                dt, reps = run(n, target_seconds)
+                port = {"value": n * reps / dt, "unit": "cells/s", "cores": threads, "kind": "port", "cpu": socket_note,
+                        "sample": f"{n} cells x {T} steps x {reps} passes, oracle/sd_oracle.c ({'BcsdTemperature' if k == 0 else 'BcsdPrecipitation'} "
+                                  f"flavour; OpenMP, {threads} threads = one per physical core of socket 0, static 64-cell panels), {dt:.1f} s"}
+        # ---- NumPy on one core ----
+        os.sched_setaffinity(0, cores[:1])
+        n1 = 256
+        f1 = host_fields(kind, seed, T, np.arange(n1), c_full)
+        numpy_cells(kind, f1, gid, 0, 1)
         t0, done = time.perf_counter(), 0
-        while done < 2048 and (done == 0 or time.perf_counter() - t0 < 0.4 * target_seconds):
-            bcsd_oracle.pointwise_fit_predict(0, X[:, done:done + 1], y[:, done:done + 1], Xp[:, done:done + 1], gid, gid)
+        while done < n1 and (done == 0 or time.perf_counter() - t0 < 0.3 * target_seconds):
+            numpy_cells(kind, f1, gid, done, done + 1)
             done += 1
-        dtn = time.perf_counter() - t0
-        numpy_leg = {"value": done / dtn, "unit": "cells/s", "cores": 1, "kind": "port", "cpu": cpu["model"],
-                     "sample": f"{done} cells x {len(index)} steps, oracle/bcsd_oracle.py (per-cell NumPy loop: np.sort, "
-                               f"np.searchsorted, np.interp per month), {dtn:.1f} s"}
-        return port, numpy_leg, parity
+        dt1 = time.perf_counter() - t0
+        what = ("per-cell sklearn KDTree.query(k=30) + NumPy mean / std of the analogs (what gard.py:58-87, 273-346 does per cell)" if kind == "analog"
+                else "oracle/bcsd_oracle.py (per-cell NumPy loop: np.sort, np.searchsorted, np.interp per month)")
+        numpy_1 = {"value": done / dt1, "unit": "cells/s", "cores": 1, "kind": "port", "cpu": cpu["model"],
+                   "sample": f"{done} cells x {T} steps, {what}, {dt1:.1f} s"}
+        # ---- NumPy on one process per physical core ----
+        os.sched_setaffinity(0, cores)
+        per = max(4, int(done / dt1 * 0.5 * target_seconds) + 1)
+        jobs = [(kind, seed, T, c_full, i * per, per, 0.5 * target_seconds, c) for i, c in enumerate(cores)]
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", ",".join(str(v) for v in job)],
+                                  stdout=subprocess.PIPE, text=True) for job in jobs]  # plain child processes: no GPU state inherited
+        res = []
+        for pr in procs:
+            o, _ = pr.communicate(timeout=120 + 4 * target_seconds)
+            d, e = o.strip().split()[-2:]
+            res.append((int(d), float(e)))
+        tot = sum(r[0] for r in res)
+        wall = max(r[1] for r in res)
+        numpy_n = {"value": tot / wall, "unit": "cells/s", "cores": len(cores), "kind": "port", "cpu": socket_note,
+                   "sample": f"{tot} cells x {T} steps over {len(cores)} processes (each pinned to one physical core of socket 0, "
+                             f"{wall:.1f} s), {what}"}
+        if kind == "analog":
+            port = dict(numpy_n)
     finally:
         os.sched_setaffinity(0, before)
+    return port, numpy_1, numpy_n, parity
 
 
 def end_to_end(ctx, index, seed, c_full, n_cells=8192):
@@ -194,10 +293,50 @@ def end_to_end(ctx, index, seed, c_full, n_cells=8192):
                     "page faults of ~1 GB included: 4 KB pages fault at ~14 GB/s on this host unless free huge pages are at hand)"}
 
 
+def pointwise_end_to_end(index, seed, c_full, n_cells=8192):
+    """The drop-in surface a user of the reference calls: PointWiseDownscaler(BcsdTemperature()).fit(X, y).predict(X_fut) on
+    host arrays of one grid (core.py:198-336) -- wrappers, validation, H2D / D2H copies and a fitted state included.
+    Bounded sample; never the headline value."""
+    import pandas as pd  # noqa: F401  (the estimators take a DatetimeIndex)
+
+    from skdownscale_amd import BcsdTemperature, PointWiseDownscaler, synth
+    from skdownscale_amd.core import GridArray
+
+    cells = np.arange(n_cells)
+    ny = 64
+    nx = n_cells // ny
+    X, y, Xp = (synth.tas_field(name, seed, index, cells, c_full).reshape(len(index), ny, nx) for name in ("X_hist", "y_obs", "X_fut"))
+    dims = ("time", "y", "x")
+    mk = lambda a: GridArray(a, dims, {"time": index})  # noqa: E731
+    Xg, yg, Xpg = mk(X), mk(y), mk(Xp)
+    times = []
+    for it in range(5):
+        t0 = time.perf_counter()
+        model = PointWiseDownscaler(BcsdTemperature(return_anoms=True))
+        model.fit(Xg, yg)
+        res = model.predict(Xpg)
+        _ = np.asarray(res.values if hasattr(res, "values") else res)
+        dt = time.perf_counter() - t0
+        del model, res
+        if it >= 2:
+            times.append(dt)
+    med = sorted(times)[len(times) // 2]
+    moved = 4 * X.nbytes
+    return {"value": n_cells / med, "unit": "cells/s", "cells": n_cells, "seconds": med, "best_seconds": min(times),
+            "effective_GBps": moved / med / 1e9,
+            "path": "PointWiseDownscaler(BcsdTemperature()).fit(X, y) + .predict(X_fut) on host GridArrays [time, 64, 128] "
+                    "(estimator wrappers, validation, H2D of three fields, fitted state, D2H of the result), median of 3 timed passes"}
+
+
 # ---- the benchmark ----------------------------------------------------------------------------------------------------
 
 def main():
     args = parse()
+    if args.cpu_worker:
+        kind, seed, T, c_full, first, count, seconds, cpu = args.cpu_worker.split(",")
+        done, dt = _numpy_worker((kind, int(seed), int(T), int(c_full), int(first), int(count), float(seconds), int(cpu)))
+        print(done, dt)
+        return
     if args.gpus > 1 and "RANK" not in os.environ:  # started by hand: re-launch one process per GPU
         os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                                    "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29531"),
@@ -333,42 +472,42 @@ def main():
     elif world > 1 and comm is None:
         gather = {"value_with_gather": None, "error": f"no RCCL communicator: {comm_error}"}
 
-    # ---- parity spot check: part of the cpu_baseline leg (the oracle's first run is compared with the engine's
-    # output for the same cells, outside the timed region) ----
+    # ---- parity spot check: part of the cpu_baseline leg (the oracle's result for the first cells is compared with the
+    # engine's output for the same cells, outside the timed region) ----
     def check_parity(exp):
         import ctypes as Cc
 
-        n = min(args.check_cells, C, exp.shape[1])
+        n = min(args.check_cells, C, exp.shape[-1])
         if n <= 0 or c_off != 0:
             return None
-        rows = np.unique(np.linspace(0, T - 1, 96).astype(np.int64))  # 96 sampled rows x n cells
+        rows_per_t = 3 if wl["kind"] == "analog" else 1                # `out` is [T, C] or [T, 3, C]
+        ts = np.unique(np.linspace(0, T - 1, 96).astype(np.int64))      # 96 sampled time steps x n cells
+        exp2 = exp.reshape(T * rows_per_t, exp.shape[-1])
+        rows = (ts[:, None] * rows_per_t + np.arange(rows_per_t)[None, :]).ravel()
         got = np.empty((len(rows), n))
-        for i, t in enumerate(rows):
-            ctx.lib.sd_memcpy_d2h(ctx.handle, got[i].ctypes.data_as(Cc.c_void_p), Cc.c_void_p(out.ptr + int(t) * C * 8), n * 8)
-        ref = exp[rows][:, :n]
+        for i, r in enumerate(rows):
+            ctx.lib.sd_memcpy_d2h(ctx.handle, got[i].ctypes.data_as(Cc.c_void_p), Cc.c_void_p(out.ptr + int(r) * C * 8), n * 8)
+        ref = exp2[rows][:, :n]
         err = np.abs(got - ref)
-        tol = 1e-6 * np.std(exp) + 1e-6 * np.abs(ref)
-        return "ok" if bool((err <= tol).all()) and bool((status[:n] == 0).all()) else f"FAILED max_err={err.max():.3e}"
+        tol = 1e-6 * np.nanstd(exp) + 1e-6 * np.abs(ref)
+        ok = bool((err <= tol).all()) and bool((np.asarray(status)[:n] == 0).all())
+        return "ok" if ok else f"FAILED max_err={np.nanmax(err):.3e}"
 
-    parity = baseline = numpy_leg = e2e = None
+    parity = baseline = numpy_1 = numpy_n = e2e = pw_e2e = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            if wl["kind"] == "bcsd_tas":
-                step()  # `out` holds the full-grid result again
-                baseline, numpy_leg, parity = cpu_baseline(index, args.seed, c_full, args.cpu_baseline_seconds, check_parity)
-            else:
-                baseline, numpy_leg, _ = cpu_baseline(index, args.seed, c_full, args.cpu_baseline_seconds)
-                note = " (BcsdTemperature port: the C / NumPy restatements timed here cover the BCSD path only)"
-                for leg in (baseline, numpy_leg):
-                    if leg:
-                        leg["sample"] += note
+            step()  # `out` holds the full-grid result again
+            ctx.synchronize()
+            baseline, numpy_1, numpy_n, parity = cpu_baseline(wl["kind"], T, args.seed, c_full, args.cpu_baseline_seconds, check_parity)
         except Exception as e:  # noqa: BLE001
-            parity = f"not run: {e}"
+            parity = f"not run: {type(e).__name__}: {e}"
         try:
             for d in list(fields.values()) + [out]:
                 d.free()
             ctx.release_cached()
-            e2e = end_to_end(ctx, index, args.seed, c_full)
+            if wl["kind"] == "bcsd_tas":
+                e2e = end_to_end(ctx, index, args.seed, c_full)
+                pw_e2e = pointwise_end_to_end(index, args.seed, c_full)
         except Exception as e:  # noqa: BLE001
             e2e = {"value": None, "error": str(e)}
 
@@ -418,10 +557,14 @@ def main():
         line.update(gather)
     if baseline is not None:  # rank 0 at N = 1 only
         line["cpu_baseline"] = baseline
-    if numpy_leg is not None:
-        line["cpu_baseline_numpy"] = numpy_leg
+    if numpy_1 is not None:
+        line["cpu_baseline_numpy"] = numpy_1
+    if numpy_n is not None:
+        line["cpu_baseline_numpy_socket"] = numpy_n
     if e2e is not None:
         line["end_to_end"] = e2e
+    if pw_e2e is not None:
+        line["pointwise_end_to_end"] = pw_e2e
     print(json.dumps(line), flush=True)
 
 

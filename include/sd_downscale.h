@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SD_VERSION 100
+#define SD_VERSION 101  /* bump on every change of an exported signature: the Python loader refuses other versions */
 
 /* return codes */
 #define SD_OK 0

@@ -171,12 +171,16 @@ int sd_comm_gather_field(sd_comm* c, const double* local_dev, int64_t T, const i
     if (c->rank == root) {
         size_t off = 0;
         SD_NCCL(g_rccl.GroupStart());
+        int first_error = 0;  // a failing Recv must not leave the group open: close it, then report
         for (int r = 0; r < c->world; ++r) {
             const size_t n = (size_t)T * (size_t)cells[r];
-            if (r != root && n > 0) SD_NCCL(g_rccl.Recv(root_dev + off, n, kNcclFloat64, r, c->comm, c->stream));
+            if (r != root && n > 0 && first_error == 0)
+                first_error = (int)g_rccl.Recv(root_dev + off, n, kNcclFloat64, r, c->comm, c->stream);
             off += n;
         }
-        SD_NCCL(g_rccl.GroupEnd());
+        const int end_error = (int)g_rccl.GroupEnd();
+        if (first_error != 0 || end_error != 0)
+            return sd_set_error(SD_ERR_HIP, "RCCL error %d in the gather's receive group", first_error != 0 ? first_error : end_error);
         off = 0;
         for (int r = 0; r < root; ++r) off += (size_t)T * (size_t)cells[r];
         if (mine > 0) SD_HIP(hipMemcpyAsync(root_dev + off, local_dev, mine * sizeof(double), hipMemcpyDeviceToDevice, c->stream));

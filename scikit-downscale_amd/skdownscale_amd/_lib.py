@@ -104,6 +104,7 @@ SIGNATURES = {
 }
 
 _libs = {}
+ABI_VERSION = 101  # include/sd_downscale.h: SD_VERSION
 
 
 class EngineError(RuntimeError):
@@ -129,6 +130,10 @@ def load(path=None):
         fn.restype = _int
     lib.sd_last_error.argtypes = []
     lib.sd_last_error.restype = C.c_char_p
+    got = lib.sd_version()
+    if got != ABI_VERSION:  # a stale build would be called with misaligned arguments
+        raise EngineError(f"{path} implements version {got} of the C ABI, this package binds version {ABI_VERSION} "
+                          "(include/sd_downscale.h: SD_VERSION): rebuild it with `python __graft_entry__.py`")
     _libs[path] = lib
     return lib
 

@@ -315,6 +315,17 @@ class Context:
                                               int(return_anoms), C.byref(h)))
         return BcsdState(self, h.value, self.lib.sd_bcsd_state_destroy)
 
+    def _result_buffer(self, out, shape, on_device):
+        """the caller's result buffer, checked (a wrong one would be written past its end), or a fresh one"""
+        if out is None:
+            return self.empty(shape) if on_device else np.empty(shape)
+        if on_device:
+            if not isinstance(out, DeviceArray) or tuple(out.shape) != tuple(shape) or out.dtype != np.float64 or out.ld < shape[-1]:
+                raise ValueError(f"out: expected a float64 DeviceArray of shape {tuple(shape)}")
+        elif not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == tuple(shape) and out.flags["C_CONTIGUOUS"]):
+            raise ValueError(f"out: expected a C-contiguous float64 array of shape {tuple(shape)}")
+        return out
+
     def bcsd_predict_trend(self, state, Xp, gid_p, gid_trend, G_trend, out=None):
         """Predict with a climate-trend grouper of its own: rolling mean over ``gid_trend`` groups, climatologies and
         quantile mapping over ``gid_p`` (groups of the state) -- bcsd.py:247-267."""
@@ -324,12 +335,11 @@ class Context:
         gid_p = self._group_ids("group_id", gid_p, Tp, info["G"])
         gid_trend = self._group_ids("trend_group_id", gid_trend, Tp, G_trend)
         status = np.empty(Cc, dtype=np.int32)
+        out = self._result_buffer(out, (Tp, Cc), isinstance(Xp, DeviceArray))
         if isinstance(Xp, DeviceArray):
-            out = self.empty((Tp, Cc)) if out is None else out
             check(self.lib.sd_bcsd_predict_trend_dev(self.handle, state.vptr, Xp.vptr, Xp.ld, ptr(gid_p), ptr(gid_trend), G_trend, Tp,
                                                      out.vptr, out.ld, ptr(status)))
         else:
-            out = np.empty((Tp, Cc))
             check(self.lib.sd_bcsd_predict_trend(self.handle, state.vptr, ptr(Xp), ptr(gid_p), ptr(gid_trend), G_trend, Tp, ptr(out),
                                                  ptr(status)))
         return out, status
@@ -342,15 +352,12 @@ class Context:
         status = np.empty(Cc, dtype=np.int32)
         if isinstance(Xp, DeviceArray):
             Tp = Xp.shape[0]
-            out = self.empty((Tp, Cc)) if out is None else out
+            out = self._result_buffer(out, (Tp, Cc), True)
             check(self.lib.sd_bcsd_predict_dev(self.handle, state.vptr, Xp.vptr, Xp.ld, ptr(gid_p), Tp, out.vptr, out.ld, ptr(status)))
         else:
             Xp = _lib.as_f64(Xp)
             Tp = Xp.shape[0]
-            if out is None:
-                out = np.empty((Tp, Cc))
-            elif not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == (Tp, Cc) and out.flags["C_CONTIGUOUS"]):
-                raise ValueError(f"out: expected a C-contiguous float64 array of shape {(Tp, Cc)}")  # (a reused result buffer)
+            out = self._result_buffer(out, (Tp, Cc), False)  # (a reused result buffer)
             check(self.lib.sd_bcsd_predict(self.handle, state.vptr, ptr(Xp), ptr(gid_p), Tp, ptr(out), ptr(status)))
         return out, status
 

@@ -8,8 +8,9 @@ gather of the predicted field ``out[Tp, C_local]`` to the root.
 (``sd_comm_*``, csrc/sd_comm.hip) -- no PyTorch.  The ranks find each other through the launcher's environment
 (``RANK``, ``WORLD_SIZE``, ``MASTER_ADDR``, ``MASTER_PORT``: what ``python -m torch.distributed.run`` or any other
 launcher exports); rank 0 hands RCCL's 128-byte unique id to the others over a TCP socket.
-``gather_field`` (torch.distributed) remains for hosts whose fields already live in torch tensors and for the CPU
-test of the partition logic (gloo).
+``HostCommunicator`` runs the same gather -- same layout code, same call -- on NumPy arrays over the rendezvous sockets:
+the sink of a sharded ``PointWiseDownscaler`` (whose results are host arrays anyway) and the way the layout logic is
+exercised with two processes on a machine without GPUs (tests/test_host.py).
 """
 from __future__ import annotations
 
@@ -92,6 +93,9 @@ class Rendezvous:
                     conn.settimeout(timeout)
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     (r,) = struct.unpack("<i", self._recv(conn, 4))
+                    if r < 1 or r >= self.world or r in self.peers:  # not one of this job's ranks (or a second claim of one)
+                        conn.close()
+                        continue
                     self.peers[r] = conn
             finally:
                 srv.close()
@@ -155,6 +159,32 @@ class Rendezvous:
     def barrier(self):
         self.allreduce_max(0.0)
 
+    def gather_bytes(self, payload, into=None):
+        """every rank's ``payload`` (bytes-like) to rank 0: returns the list of per-rank buffers there (``into``: writable
+        per-rank memoryviews to receive into, avoiding copies), None elsewhere"""
+        if self.rank != 0:
+            view = memoryview(payload).cast("B")
+            self.root.sendall(self._struct.pack("<q", view.nbytes))
+            self.root.sendall(view)
+            return None
+        out = [None] * self.world
+        out[0] = memoryview(payload).cast("B") if into is None else into[0]
+        if into is not None:
+            into[0][:] = memoryview(payload).cast("B")
+        for r, conn in self.peers.items():
+            (n,) = self._struct.unpack("<q", self._recv(conn, 8))
+            buf = memoryview(bytearray(n)) if into is None else into[r]
+            if buf.nbytes != n:
+                raise ValueError(f"rank {r} sent {n} bytes, expected {buf.nbytes}")
+            got = 0
+            while got < n:
+                k = conn.recv_into(buf[got:], n - got)
+                if k == 0:
+                    raise ConnectionError("rendezvous peer closed the connection")
+                got += k
+            out[r] = buf
+        return out
+
     def close(self):
         for conn in list(self.peers.values()) + ([self.root] if self.root is not None else []):
             try:
@@ -164,7 +194,43 @@ class Rendezvous:
         self.peers, self.root = {}, None
 
 
-class Communicator:
+class _GatherLayout:
+    """The gather of a predicted field to a root, shared by the RCCL and the socket transport.  Every rank holds a contiguous
+    [T, C_r] block; the root receives all of them into ONE buffer laid out [rank][T][C_r] (ragged shards back to back, no
+    concatenation copy) and gets one [T, C_r] view per rank.  Subclasses provide ``_alloc(n)`` (buffer of n float64),
+    ``_view(buffer, offset, shape)`` (a view that keeps ``buffer`` alive), ``_nbytes(buffer)`` and ``_transport(...)``."""
+
+    rank = 0
+    world = 1
+
+    def gather_field(self, local, cells, root=0, root_buffer=None, wait=True):
+        """``cells`` = C_r of every rank.  On the root returns the list of per-rank views into ``root_buffer`` (allocated
+        when None: sum(cells) * T doubles); elsewhere None."""
+        cells = np.ascontiguousarray(cells, dtype=np.int64)
+        if cells.shape != (self.world,):
+            raise ValueError(f"cells: expected {self.world} entries (one per rank), got shape {cells.shape}")
+        if not 0 <= int(root) < self.world:
+            raise ValueError(f"root={root} outside [0, {self.world})")
+        T = int(local.shape[0])
+        ld = getattr(local, "ld", local.shape[-1])
+        if len(local.shape) != 2 or ld != local.shape[1] or local.shape[1] != cells[self.rank]:
+            raise ValueError("gather_field needs a contiguous [T, cells[rank]] field")
+        views = None
+        if self.rank == root:
+            need = int(cells.sum()) * T
+            if root_buffer is None:
+                root_buffer = self._alloc(need)
+            elif self._nbytes(root_buffer) < need * 8:
+                raise ValueError(f"root_buffer holds {self._nbytes(root_buffer)} bytes, the gathered field needs {need * 8}")
+            views, off = [], 0
+            for r in range(self.world):
+                views.append(self._view(root_buffer, off, (T, int(cells[r]))))  # (each view pins root_buffer)
+                off += T * int(cells[r])
+        self._transport(local, T, cells, root_buffer, int(root), wait)
+        return views
+
+
+class Communicator(_GatherLayout):
     """RCCL communicator of the engine (one rank per process / GPU)."""
 
     def __init__(self, ctx, rank, world, unique_id):
@@ -215,35 +281,77 @@ class Communicator:
         check(self.ctx.lib.sd_comm_allreduce_max(self.handle, float(value), ctypes.byref(out)))
         return out.value
 
-    def gather_field(self, local, cells, root=0, root_buffer=None, wait=True):
-        """Gather the contiguous [T, C_local] DeviceArray ``local`` of every rank to ``root``.  ``cells`` = C_local of every
-        rank.  On the root returns the list of per-rank views [T, cells[r]] into ``root_buffer`` (allocated when None:
-        sum(cells) * T doubles, shards back to back -- no concatenation copy); elsewhere None."""
+    # ---- transport: grouped ncclSend / ncclRecv into the root's buffer (csrc/sd_comm.hip) ----
+    def _alloc(self, n):
+        return self.ctx.empty((int(n),))
+
+    @staticmethod
+    def _nbytes(buf):
+        return buf.nbytes
+
+    def _view(self, buf, off, shape):
+        from .engine import DeviceArray
+
+        return DeviceArray(self.ctx, shape, np.float64, dptr=buf.ptr + int(off) * 8, owner=False, base=buf)
+
+    def _transport(self, local, T, cells, root_buffer, root, wait):
         from ._lib import check
 
-        cells = np.ascontiguousarray(cells, dtype=np.int64)
-        T = local.shape[0]
-        if local.ld != local.shape[1] or local.shape[1] != cells[self.rank]:
-            raise ValueError("gather_field needs a contiguous [T, cells[rank]] field")
-        views = None
-        if self.rank == root:
-            if root_buffer is None:
-                root_buffer = self.ctx.empty((int(cells.sum()) * T,))
-            views, off = [], 0
-            for r in range(self.world):
-                n = T * int(cells[r])
-                views.append(self.ctx.wrap(root_buffer.ptr + off * 8, (T, int(cells[r]))))
-                off += n
-            self._root_buffer = root_buffer  # keeps the allocation alive with the views
         check(self.ctx.lib.sd_comm_gather_field(self.handle, local.vptr, T, cells.ctypes.data_as(ctypes.c_void_p),
-                                                None if root_buffer is None else root_buffer.vptr, int(root), 1 if wait else 0))
-        return views
+                                                None if root_buffer is None else root_buffer.vptr, root, 1 if wait else 0))
 
     def wait(self):
         from ._lib import check
 
         check(self.ctx.lib.sd_comm_wait(self.handle))
 
+
+class HostCommunicator(_GatherLayout):
+    """The same gather for NumPy arrays, carried by the rendezvous sockets (root = rank 0 of the star)."""
+
+    def __init__(self, rendezvous):
+        self.rdv = rendezvous
+        self.rank, self.world = rendezvous.rank, rendezvous.world
+
+    def barrier(self):
+        self.rdv.barrier()
+
+    def allreduce_max(self, value):
+        return self.rdv.allreduce_max(value)
+
+    def _alloc(self, n):
+        return np.empty(int(n), dtype=np.float64)
+
+    @staticmethod
+    def _nbytes(buf):
+        return buf.nbytes
+
+    @staticmethod
+    def _view(buf, off, shape):
+        n = int(np.prod(shape, dtype=np.int64))
+        return buf.reshape(-1)[int(off):int(off) + n].reshape(shape)  # NumPy views keep their base alive
+
+    def _transport(self, local, T, cells, root_buffer, root, wait):
+        if root != 0:
+            raise ValueError("the socket transport gathers to rank 0 (the root of the rendezvous star)")
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        if self.world == 1:
+            root_buffer.reshape(-1)[:local.size] = local.reshape(-1)
+            return
+        into = None
+        if self.rank == 0:
+            flat, into, off = memoryview(root_buffer.reshape(-1)).cast("B"), [], 0
+            for r in range(self.world):
+                n = T * int(cells[r]) * 8
+                into.append(flat[off:off + n])
+                off += n
+        self.rdv.gather_bytes(local, into)
+
+    def wait(self):
+        pass
+
+    def close(self):
+        pass
 
 
 def cell_partition(n_cells: int, world: int):
@@ -259,35 +367,3 @@ def cell_partition(n_cells: int, world: int):
 
 def local_cells(n_cells: int, world: int, rank: int):
     return cell_partition(n_cells, world)[rank]
-
-
-def gather_field(local, n_cells: int, dst: int = 0, group=None):
-    """Gather ``local`` [..., C_local] (torch tensor, cells on the last axis) to ``dst``.
-
-    Ragged blocks are padded to the widest block for the collective and trimmed on the root.
-    Returns the [..., n_cells] tensor on ``dst`` and None elsewhere.
-    """
-    import torch
-    import torch.distributed as dist
-
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    bounds = cell_partition(n_cells, world)
-    width = max(e - s for s, e in bounds)
-    lead = tuple(local.shape[:-1])
-    send = local
-    if local.shape[-1] != width:
-        send = torch.zeros(lead + (width,), dtype=local.dtype, device=local.device)
-        send[..., : local.shape[-1]] = local
-    send = send.contiguous()
-    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, bufs, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return torch.cat([b[..., : e - s] for b, (s, e) in zip(bufs, bounds)], dim=-1)
-
-
-def assemble(blocks, n_cells: int):
-    """NumPy twin of the root-side concatenation (used by tests)."""
-    out = np.concatenate(blocks, axis=-1)
-    assert out.shape[-1] == n_cells
-    return out

@@ -47,6 +47,9 @@ class LinearTrendTransformer(TransformerMixin, BaseEstimator):
         n, cells = Xv.shape
         self._state = default_context().linreg_fit(index_feature(n, cells), Xv)
         e = self._state.export()
+        bad = np.flatnonzero(np.asarray(e["status"]) != 0)
+        if bad.size:  # (check_array has refused NaN / inf already: anything else the engine flags must not pass silently)
+            raise ValueError(f"LinearTrendTransformer.fit: the engine reported status {int(e['status'][bad[0]])} for column {int(bad[0])}")
         self.lr_model_ = FittedLine(e["coef"].T.copy(), e["intercept"].copy())  # sklearn: coef_ [n_targets, 1], intercept_ [n_targets]
         self._export = e
         self.n_features_in_ = cells

@@ -97,10 +97,11 @@ def test_cell_partition():
 WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist
-sys.path[:0] = [os.path.join(r"{root}", "scikit-downscale_amd"), os.path.join(r"{root}", "oracle")]
+sys.path[:0] = [os.path.join(r"{root}", "scikit-downscale_amd"), os.path.join(r"{root}", "oracle"), os.path.join(r"{root}", "tests")]
 import bcsd_oracle as bo
 from skdownscale_amd import synth
-from skdownscale_amd.shard import gather_field, local_cells
+from skdownscale_amd.shard import local_cells
+from _torch_gather import gather_field
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 C, T = 7, 731
@@ -132,6 +133,75 @@ def test_sharded_gather_world_size_2_gloo(tmp_path):
                           "--master-port", "29617", str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "GATHER_OK" in res.stdout
+
+
+PRODUCT_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path[:0] = [os.path.join(r"{root}", "scikit-downscale_amd"), os.path.join(r"{root}", "oracle")]
+import bcsd_oracle as bo
+from skdownscale_amd import synth
+from skdownscale_amd.shard import HostCommunicator, Rendezvous, cell_partition
+rdv = Rendezvous.from_env()                   # RANK / WORLD_SIZE / MASTER_* from the launcher, like bench.py
+comm = HostCommunicator(rdv)                  # the product's gather call, bytes carried by sockets instead of RCCL
+rank, world = comm.rank, comm.world
+C, T = 11, 400
+index = synth.daily_calendar(T)
+gid = bo.month_group_id(index)
+bounds = cell_partition(C, world)             # ragged: 4 + 4 + 3 cells
+s, e = bounds[rank]
+f = lambda n, cells: synth.tas_field(n, 1, index, cells, C)
+mine = np.arange(s, e)
+out, _ = bo.pointwise_fit_predict(bo.TAS, f("X_hist", mine), f("y_obs", mine), f("X_fut", mine), gid, gid)  # stand-in for the engine
+cells = np.array([b - a for a, b in bounds])
+for buf in (None, np.full(T * C + 5, -1.0) if rank == 0 else None):   # engine-allocated and caller-supplied root buffer
+    views = comm.gather_field(np.ascontiguousarray(out), cells, 0, buf)
+    if rank == 0:
+        allc = np.arange(C)
+        exp, _ = bo.pointwise_fit_predict(bo.TAS, f("X_hist", allc), f("y_obs", allc), f("X_fut", allc), gid, gid)
+        assert len(views) == world and [v.shape for v in views] == [(T, int(c)) for c in cells]
+        base = views[0].base if views[0].base is not None else views[0]
+        assert all(np.shares_memory(v, base) for v in views), "the per-rank views share the root buffer"
+        # root layout [rank][T][C_r]: shard r starts T * sum(cells[:r]) doubles into the buffer
+        flat = np.asarray(base).reshape(-1)
+        for r, v in enumerate(views):
+            off = T * int(cells[:r].sum())
+            assert np.shares_memory(v, flat[off:off + v.size]) and np.array_equal(flat[off:off + v.size].reshape(v.shape), v)
+        full = np.concatenate(views, axis=1)
+        assert np.array_equal(full, exp), "sharded + gathered result differs from the unsharded result"
+        if buf is not None:
+            assert np.all(flat[T * C:] == -1.0), "nothing written past the gathered field"
+    else:
+        assert views is None
+if rank == 0:
+    for bad in ([4, 4], [[4, 4, 3]]):
+        try:
+            comm.gather_field(np.zeros((T, 4)), bad)
+            raise SystemExit("cells of the wrong shape accepted")
+        except ValueError:
+            pass
+    try:
+        comm.gather_field(np.ascontiguousarray(out), cells, 0, np.empty(T * C - 1))
+        raise SystemExit("short root buffer accepted")
+    except ValueError:
+        pass
+    print("PRODUCT_GATHER_OK")
+rdv.barrier()
+rdv.close()
+'''
+
+
+def test_product_gather_layout_three_ranks_on_cpu(tmp_path):
+    """The layout logic of the product gather (cell_partition -> [rank][T][C_r] root buffer -> per-rank views -> equality with
+    the unsharded result) with three processes on CPU: ``HostCommunicator`` is ``Communicator`` with the RCCL call replaced
+    by a socket copy behind the same ``gather_field`` (same shared layout code, skdownscale_amd/shard.py:_GatherLayout)."""
+    script = tmp_path / "worker.py"
+    script.write_text(PRODUCT_WORKER.format(root=ROOT))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+                          "--master-port", "29641", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "PRODUCT_GATHER_OK" in res.stdout
 
 
 def test_padded_doy_grouper_matches_the_reference():
