@@ -8,7 +8,7 @@ from .core import GridArray, GridDataset, PointWiseDownscaler
 from .gard import AnalogGridModel, AnalogRegression, PureAnalog, PureRegression, RegressionGridModel
 from .groupers import DAY_GROUPER, MONTH_GROUPER, PaddedDOYGrouper
 from .quantile import (CunnaneGridModel, CunnaneTransformer, EquidistantCdfMatcher, QmGridModel, QuantileMapper,
-                       QuantileMapperGridModel, QuantileMappingReressor)
+                       QuantileMapperGridModel, QuantileMappingReressor, TrendAwareQuantileMappingRegressor)
 from .trend import LinearTrendTransformer
 
 __all__ = [
@@ -24,7 +24,7 @@ __all__ = [
     "GridDataset",
     "BcsdGridModel",
     "AnalogGridModel",
-    "QuantileMappingReressor",
+    "QuantileMappingReressor", "TrendAwareQuantileMappingRegressor",
     "QuantileMapper",
     "EquidistantCdfMatcher",
     "QmGridModel",

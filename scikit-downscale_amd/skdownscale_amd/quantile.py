@@ -363,3 +363,54 @@ class EquidistantCdfMatcher(QuantileMappingReressor):
         if self.max_ratio is not None:  # the reference calls np.min(ratio, max_ratio) (quantile.py:621-622) and fails
             raise NotImplementedError("EquidistantCdfMatcher(max_ratio=...) is not supported")
         return _lib.QM_EDCDF_DIFFERENCE if self.kind == "difference" else _lib.QM_EDCDF_RATIO
+
+
+class TrendAwareQuantileMappingRegressor(RegressorMixin, BaseEstimator):
+    """Experimental meta estimator for trend-aware quantile mapping (quantile.py:639-716): X and y lose their least-squares
+    lines (``LinearTrendTransformer``, one batched line fit on the engine each), ``qm_estimator`` maps the detrended series,
+    and the prediction gets the centred trend line of the new X plus the change of its mean back.
+
+    Parameters
+    ----------
+    qm_estimator : a quantile-mapping regressor of this package (``QuantileMappingReressor``, ``EquidistantCdfMatcher``)
+    trend_transformer : ``LinearTrendTransformer`` or None (default: ``LinearTrendTransformer()``)
+
+    The reference only sets ``trend_transformer`` when None is passed (quantile.py:655-656: any other argument leaves the
+    attribute unset and ``fit`` raises AttributeError); here a given transformer is kept.
+    """
+
+    def __init__(self, qm_estimator=None, trend_transformer=None):
+        from .trend import LinearTrendTransformer
+
+        self.qm_estimator = qm_estimator
+        self.trend_transformer = LinearTrendTransformer() if trend_transformer is None else trend_transformer
+
+    @staticmethod
+    def _column(a):
+        a = np.asarray(getattr(a, "values", a), dtype=np.float64)
+        return a.reshape(len(a), -1)
+
+    def fit(self, X, y):
+        import copy
+
+        if self.qm_estimator is None:
+            raise AttributeError("'NoneType' object has no attribute 'fit'")  # what the reference does with its default
+        Xv, yv = self._column(X), self._column(y)
+        self._X_mean_fit = Xv.mean(axis=0)  # quantile.py:673-674
+        self._y_mean_fit = yv.mean(axis=0)
+        y_detrend = copy.deepcopy(self.trend_transformer).fit_transform(yv)  # quantile.py:676-680
+        x_detrend = copy.deepcopy(self.trend_transformer).fit_transform(Xv)
+        self.qm_estimator.fit(x_detrend, y_detrend)  # quantile.py:682
+        return self
+
+    def predict(self, X):
+        import copy
+
+        Xv = self._column(X)
+        X_trend = copy.deepcopy(self.trend_transformer)
+        x_detrend = X_trend.fit_transform(Xv)  # quantile.py:700-701
+        y_hat = np.asarray(self.qm_estimator.predict(x_detrend), dtype=np.float64).reshape(-1, 1)  # quantile.py:703
+        delta = (Xv.mean(axis=0) - self._X_mean_fit) + self._y_mean_fit  # quantile.py:707: projected change + observed mean
+        trendline = X_trend.trendline(Xv)  # quantile.py:711-712
+        trendline = trendline - trendline.mean()
+        return y_hat + trendline + delta  # quantile.py:715

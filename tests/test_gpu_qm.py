@@ -305,3 +305,41 @@ def test_pointwise_transformers_are_batched():
     bad[5, 0, 0] = np.nan
     with pytest.raises(ValueError, match="NaN"):
         pw.transform(GridArray(bad, dims))
+
+
+@pytest.mark.parametrize("name", ["qmr", "qmr_both", "ecm"])
+def test_trend_aware_quantile_mapping_regressor_matches_the_reference(name):
+    """g16_trend_aware.npz: TrendAwareQuantileMappingRegressor of the real reference (quantile.py:639-716) around
+    QuantileMappingReressor (extrapolate None / 'both') and EquidistantCdfMatcher, fit on 1 400 drifting samples, predict on
+    1 900: detrending, mapping, trend line and mean change all through the engine's estimators."""
+    import pandas as pd
+
+    from skdownscale_amd import (EquidistantCdfMatcher, QuantileMappingReressor, TrendAwareQuantileMappingRegressor, synth)
+
+    g = load("g16_trend_aware")
+    T, Tp, C = int(g["T"]), int(g["Tp"]), int(g["C"])
+    index = pd.date_range(str(g["start"]), periods=T)
+    index_p = pd.date_range(str(g["pstart"]), periods=Tp)
+    cells = np.arange(C)
+    X = synth.tas_field("X_hist", 7 + 16, index, cells, 1000) + 3e-3 * np.arange(T)[:, None]
+    y = synth.tas_field("y_obs", 7 + 16, index, cells, 1000) + 2e-3 * np.arange(T)[:, None]
+    Xp = synth.tas_field("X_fut", 7 + 16, index_p, cells, 1000) + 4e-3 * np.arange(Tp)[:, None]
+    make = {"qmr": lambda: QuantileMappingReressor(), "qmr_both": lambda: QuantileMappingReressor(extrapolate="both"),
+            "ecm": lambda: EquidistantCdfMatcher()}[name]
+    exp = g[f"out_{name}"]
+    for c in range(C):
+        m = TrendAwareQuantileMappingRegressor(make()).fit(X[:, c:c + 1], y[:, c:c + 1])
+        out = m.predict(Xp[:, c:c + 1])
+        assert out.shape == (Tp, 1)
+        if name == "qmr_both":  # detrended samples beyond the fitted range carry the +-1e20 node noise of quantile.py:338-346
+            err = np.abs(out[:, 0] - exp[:, c])
+            assert np.median(err) <= 1e-6 * np.std(exp[:, c]) and (err <= 1e-3 * np.std(exp[:, c])).all(), err.max()
+        else:
+            assert_close(out[:, 0], exp[:, c], scale=float(np.std(exp[:, c])), what=f"trend-aware {name} cell {c}")
+    # DataFrame inputs (what the reference's class expects) and a given trend transformer
+    from skdownscale_amd import LinearTrendTransformer
+
+    m = TrendAwareQuantileMappingRegressor(make(), LinearTrendTransformer()).fit(pd.DataFrame(X[:, :1], index=index), pd.DataFrame(y[:, :1], index=index))
+    out = m.predict(pd.DataFrame(Xp[:, :1], index=index_p))
+    if name != "qmr_both":
+        assert_close(out[:, 0], exp[:, 0], scale=float(np.std(exp[:, 0])), what=f"trend-aware {name} (DataFrames)")
