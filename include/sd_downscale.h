@@ -131,7 +131,7 @@ int sd_synth_fill(sd_ctx* ctx, double* out_dev, int64_t T, int64_t C, int64_t ld
  * SD_BCSD_RETURN_ANOMS (bcsd.py:27,266-267 / 170-185) | SD_BCSD_QM_DETREND (qm_kwargs={'detrend': True}: quantile.py:95-98,
  * 128-145 -- every group's series loses its least-squares line over the sample index, trend.py:51-83, before the CDFs are
  * built; the predict line is added back re-based on the fitted intercept).  Plain 0 / 1 keep their old meaning.  Detrended
- * mapping serves group segments of up to 2112 samples (SD_ERR_UNSUPPORTED beyond). */
+ * mapping serves group segments of up to 19 456 samples (SD_ERR_UNSUPPORTED beyond). */
 #define SD_BCSD_RETURN_ANOMS 1
 #define SD_BCSD_QM_DETREND 2
 int sd_bcsd_fit(sd_ctx* ctx, int kind, const double* X, const double* y, const int32_t* group_id, int G, int64_t T,

@@ -619,13 +619,38 @@ __device__ __forceinline__ double block_sum(double v, double* red /* 16 doubles 
     return t;
 }
 
+// Least-squares line of a blocked series (thread t holds samples j = K * t + i, valid while j < n) over j = 0 .. n-1:
+// trend.py:51 (LinearRegression on np.arange(len(X))), centred sums like sd_wave.h: trend_line.  Every thread of the
+// workgroup calls it (two block reductions).
+template <int K>
+__device__ __forceinline__ void block_trend_line(const double (&v)[K], int n, int tid, double* red, int lane, int wave, double* slope,
+                                                 double* icpt) {
+    const double tbar = 0.5 * (double)(n - 1);
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) s += K * tid + i < n ? v[i] : 0.0;
+    const double vbar = block_sum(s, red, lane, wave) / (double)n;
+    double sxy = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const int j = K * tid + i;
+        sxy += j < n ? ((double)j - tbar) * (v[i] - vbar) : 0.0;
+    }
+    sxy = block_sum(sxy, red, lane, wave);
+    const double dn = (double)n;
+    const double sxx = dn * (dn * dn - 1.0) / 12.0;
+    const double a = n > 1 ? sxy / sxx : 0.0;
+    *slope = a;
+    *icpt = vbar - a * tbar;
+}
+
 template <int K>
 __global__ void __launch_bounds__(1024) bcsd_long_fit_kernel(int kind, const double* __restrict__ X, const double* __restrict__ y,
                                                              int64_t ld, const int32_t* __restrict__ order,
                                                              const int32_t* __restrict__ goff, int G, int64_t T, int64_t C,
                                                              int return_anoms, double* __restrict__ ys,
                                                              double* __restrict__ x_climo, double* __restrict__ y_climo,
-                                                             int32_t* status) {
+                                                             int32_t* status, int detrend, double* __restrict__ y_trend) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int64_t c = blockIdx.x;
     const int g = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
@@ -672,6 +697,20 @@ __global__ void __launch_bounds__(1024) bcsd_long_fit_kernel(int kind, const dou
         v[i] = buf[j < np ? j : np];
     }
     __syncthreads();
+    if (detrend) {  // quantile.py:95-98: the CDF is fitted on y minus its least-squares line (trend.py:65,83)
+        double a, b;
+        block_trend_line<K>(v, n, tid, red, lane, wave, &a, &b);
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int j = K * tid + i;
+            if (j < n) v[i] = v[i] - ((double)j * a + b);
+        }
+        if (tid == 0) {
+            y_trend[2 * (c * G + g)] = a;
+            y_trend[2 * (c * G + g) + 1] = b;
+        }
+        __syncthreads();  // red aliases the sort's exchange area
+    }
     sdsort::block_merge_sort<K>(v, buf, np, xch, tid, nthr);  // quantile.py:462 np.sort
     double* dst = ys + c * T + beg;
     for (int i = tid; i < n; i += nthr) dst[i] = buf[i];
@@ -682,10 +721,11 @@ __global__ void __launch_bounds__(1024) bcsd_long_predict_kernel(
     int kind, const double* __restrict__ Xp, int64_t ld, const int32_t* __restrict__ order_p,
     const int32_t* __restrict__ goff_p, const int32_t* __restrict__ goff_f, int G, int64_t Tf, int64_t C, int return_anoms,
     const double* __restrict__ ys, const double* __restrict__ x_climo, const double* __restrict__ y_climo,
-    const int32_t* __restrict__ fit_status, int32_t* status, double* __restrict__ out, int64_t ld_out) {
+    const int32_t* __restrict__ fit_status, int32_t* status, double* __restrict__ out, int64_t ld_out, int detrend,
+    const double* __restrict__ y_trend) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int64_t c = blockIdx.x;
-    const int g = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+    const int g = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int begp = goff_p[g], m = goff_p[g + 1] - begp;
     const int begf = goff_f[g], n = goff_f[g + 1] - begf;
     if (m == 0) return;
@@ -735,6 +775,16 @@ __global__ void __launch_bounds__(1024) bcsd_long_predict_kernel(
         u[i] = j < m ? x - sh : inf;
     }
     __syncthreads();
+    double ta = 0.0, tb = 0.0;  // detrend: the predict segment's own line (quantile.py:128-132)
+    if (detrend) {
+        block_trend_line<K>(u, m, tid, reinterpret_cast<double*>(xch), lane, wave, &ta, &tb);
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int j = K * tid + i;
+            if (j < m) u[i] = u[i] - ((double)j * ta + tb);  // trend.py:65,83
+        }
+        __syncthreads();
+    }
     {
         double v[K];
 #pragma unroll
@@ -762,7 +812,9 @@ __global__ void __launch_bounds__(1024) bcsd_long_predict_kernel(
         if (active) {
             const int cnt = pos[i] + 1 + (buf[pos[i] + 1] <= u[i] ? 1 : 0);
             const int r = cnt > 0 ? cnt - 1 : 0;
-            const double q = inverse_cdf(pp_at(r, dm), ysg, n, dn, tf);
+            double q = inverse_cdf(pp_at(r, dm), ysg, n, dn, tf);
+            if (detrend)  // quantile.py:140-145: the predict line comes back, re-based on the fitted intercept
+                q = (q + ((double)j * ta + tb)) - (tb - y_trend[2 * (c * G + g) + 1]);
             if (kind == SD_BCSD_TAS) {
                 res = shift[i] + q;                // bcsd.py:263
                 if (return_anoms) res = res - yc;  // bcsd.py:266-267
@@ -793,7 +845,7 @@ int launch_long_fit(sd_ctx* ctx, int kind, const double* X, const double* y, int
                                (int)lds));
     SD_LAUNCH(ctx, "bcsd_long_fit_kernel", bcsd_long_fit_kernel<K>, dim3((unsigned)C, (unsigned)G), dim3(1024), lds, kind, X, y, ld,
               (const int32_t*)gt.order.p, (const int32_t*)gt.off.p, G, T, C, return_anoms, st->ys, st->x_climo, st->y_climo,
-              st->status);
+              st->status, st->detrend, st->y_trend);
     return SD_OK;
 }
 
@@ -807,7 +859,7 @@ int launch_long_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, 
     SD_LAUNCH(ctx, "bcsd_long_predict_kernel", bcsd_long_predict_kernel<K>, dim3((unsigned)st->C, (unsigned)st->G), dim3(1024), lds,
               st->kind, Xp, ld, (const int32_t*)gt.order.p, (const int32_t*)gt.off.p, (const int32_t*)st->goff_dev, st->G, st->T,
               st->C, st->return_anoms, (const double*)st->ys, (const double*)st->x_climo, (const double*)st->y_climo,
-              (const int32_t*)st->status, status_p, out, ld_out);
+              (const int32_t*)st->status, status_p, out, ld_out, st->detrend, (const double*)st->y_trend);
     return SD_OK;
 }
 
@@ -905,9 +957,9 @@ static int predict_with_table(sd_ctx* ctx, const sd_bcsd_state* st, const double
     const int nmax_all = gt.nmax > st->nmax ? gt.nmax : st->nmax;
     const bool rs = use_rs_path(nmax_all, ld > ld_out ? ld : ld_out);
     const bool lng = !rs && use_long_path(nmax_all, ctx->lds_max) && long_width(gt.nmax, ctx->lds_max) != 0;
-    if (st->detrend && !rs)
+    if (st->detrend && !rs && !lng)
         return sd_set_error(SD_ERR_UNSUPPORTED, "detrended quantile mapping serves group segments of up to %d samples (longest here: %d)",
-                            64 * 33, nmax_all);
+                            1024 * 19, nmax_all);
     if (!rs && !lng) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 2, &W, &stride));
     QTables qt;
     if (rs) {
@@ -974,9 +1026,9 @@ static int fit_with_table(sd_ctx* ctx, int kind, const double* X_dev, const doub
     if (!rs && !lng) SD_TRY(pick_tile_width(ctx->lds_max, gt.nmax, 1, &W, &stride));
     sd_bcsd_state* st = nullptr;
     int rc = alloc_state(ctx, kind, G, T, C, options, &st);
-    if (rc == SD_OK && st->detrend && !rs)
+    if (rc == SD_OK && st->detrend && !rs && !lng)
         rc = sd_set_error(SD_ERR_UNSUPPORTED, "detrended quantile mapping serves group segments of up to %d samples (longest here: %d)",
-                          64 * 33, gt.nmax);
+                          1024 * 19, gt.nmax);
     if (rc != SD_OK) {
         sd_bcsd_state_destroy(st);
         return rc;

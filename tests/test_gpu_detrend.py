@@ -173,13 +173,44 @@ def test_bcsd_detrend_vs_oracle(ctx, kind, T, Tp, C):
     assert not np.allclose(plain, out)  # the option does something
 
 
-def test_bcsd_detrend_long_segments_are_refused(ctx):
-    """segments beyond the register-sort kernels (2112 samples) have no detrended path: SD_ERR_UNSUPPORTED"""
+def test_bcsd_detrend_long_segments_match_the_oracle(ctx):
+    """segments beyond the register-sort kernels (> 2 112 samples) take the workgroup-sort kernels, which detrend as well
+    (csrc/sd_bcsd.hip: bcsd_long_*): both kinds, fit longer / shorter than predict, against the pinned oracle; beyond
+    19 456 samples the engine still refuses"""
     rng = np.random.default_rng(1)
-    X = rng.standard_normal((3000, 4))
-    gid = np.zeros(3000, dtype=np.int32)
+    for kind, T, Tp in ((0, 3000, 3000), (0, 5000, 2600), (1, 2500, 4100)):
+        t, tp = np.arange(T)[:, None], np.arange(Tp)[:, None]
+        X = rng.standard_normal((T, 3)) * 3 + 2e-3 * t
+        y = rng.standard_normal((T, 3)) * 4 + 1e-3 * t
+        Xp = rng.standard_normal((Tp, 3)) * 3 + 3e-3 * tp
+        if kind == 1:
+            X, y, Xp = np.abs(X) + 0.1, np.abs(y) + 0.1, np.abs(Xp) + 0.1
+        gid, gid_p = np.zeros(T, dtype=np.int32), np.zeros(Tp, dtype=np.int32)
+        exp, _ = bo.pointwise_fit_predict(kind, X, y, Xp, gid, gid_p, G=1, detrend=True)
+        out, status = ctx.bcsd_predict(ctx.bcsd_fit(kind, X, y, gid, 1, True, detrend=True), Xp, gid_p)
+        assert (status == 0).all()
+        assert_close(out, exp, what=f"long detrended segment kind={kind} T={T} Tp={Tp}")
+    big = rng.standard_normal((20000, 2))
     with pytest.raises(NotImplementedError, match="detrended quantile mapping"):
-        ctx.bcsd_fit(0, X, X + 1, gid, 1, True, detrend=True)
-    st = ctx.bcsd_fit(0, X[:2000], X[:2000] + 1, gid[:2000], 1, True, detrend=True)
-    with pytest.raises(NotImplementedError, match="detrended quantile mapping"):
-        ctx.bcsd_predict(st, X, gid)
+        ctx.bcsd_fit(0, big, big + 1, np.zeros(20000, dtype=np.int32), 1, True, detrend=True)
+
+
+def test_quantile_mapper_detrend_on_a_40_year_daily_series():
+    """g17_detrend_long.npz: QuantileMapper(detrend=True) of the real reference fitted on whole 14 600-sample series (one
+    segment per cell: quantile.py:81-147), transform of a series of the same length and of a 16 000-sample one."""
+    from skdownscale_amd import QuantileMapper, synth
+
+    g = load("g17_detrend_long")
+    C = int(g["C"])
+    cells = np.arange(C)
+    index, index_p = synth.daily_calendar(14600), synth.daily_calendar(16000)
+    X = synth.tas_field("X_hist", 7 + 17, index, cells, 1000) + 1e-4 * np.arange(14600)[:, None] * (1 + cells)
+    Xs = synth.tas_field("X_fut", 7 + 17, index, cells, 1000) + 2e-4 * np.arange(14600)[:, None]
+    Xl = synth.tas_field("X_fut", 7 + 18, index_p, cells, 1000) + 2e-4 * np.arange(16000)[:, None]
+    for name, B in (("same", Xs), ("longer", Xl)):
+        for c in range(C):
+            m = QuantileMapper(detrend=True).fit(X[:, c:c + 1])
+            out = m.transform(B[:, c:c + 1])
+            assert_close(out[:, 0], g[f"out_{name}"][:, c], what=f"QuantileMapper(detrend=True) 14 600 samples, {name}, cell {c}")
+            line = np.array([float(np.ravel(m.x_trend_fit_.lr_model_.coef_)[0]), float(np.ravel(m.x_trend_fit_.lr_model_.intercept_)[0])])
+            assert np.allclose(line, g[f"line_{name}"][c], rtol=1e-9, atol=1e-12)
