@@ -90,6 +90,75 @@ class GridArray:
         return f"<GridArray {self.sizes}>"
 
 
+class LazyGridArray(GridArray):
+    """Result of predict / transform / inverse_transform on a spatially chunked GridArray: like the reference's
+    ``xr.map_blocks`` result (core.py:256-262, 300-336) the blocks are computed when they are asked for.  ``iter_blocks()``
+    yields ``(selection, GridArray)`` one spatial block at a time -- nothing but the current block is held --, ``values``
+    assembles (and keeps) the whole field.  Only the first block is computed up front: it tells dims, dtype and the sizes of
+    the non-spatial dims."""
+
+    def __init__(self, thunks, first, spatial_dims, sizes, chunksizes, coords, name=None):
+        self._thunks = list(thunks)  # [(selection, callable -> GridArray)]
+        self._first = first
+        self._full = None
+        self.dims = tuple(first.dims)
+        all_sizes = dict(first.sizes)
+        all_sizes.update({d: int(sizes[d]) for d in spatial_dims})
+        self._shape = tuple(all_sizes[d] for d in self.dims)
+        self._dtype = first.dtype
+        self.coords = dict(coords)
+        self.name = name
+        self.chunksizes = {d: (tuple(chunksizes[d]) if d in chunksizes else (all_sizes[d],)) for d in self.dims}
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def sizes(self):
+        return dict(zip(self.dims, self._shape))
+
+    @property
+    def computed(self):
+        return self._full is not None
+
+    def iter_blocks(self):
+        for i, (sel, thunk) in enumerate(self._thunks):
+            if i == 0 and self._first is not None:
+                yield sel, self._first
+            else:
+                yield sel, thunk()
+
+    @property
+    def values(self):
+        if self._full is None:
+            with np.errstate(invalid="ignore"):
+                full = np.full(self._shape, np.nan, dtype=self._dtype)
+            for sel, block in self.iter_blocks():
+                full[tuple(sel.get(d, slice(None)) for d in self.dims)] = block.values
+            self._full, self._first = full, None
+        return self._full
+
+    def compute(self):
+        return GridArray(self.values, self.dims, self.coords, self.name).chunk({d: self.chunksizes[d][0] for d in self.dims})
+
+    def chunk(self, chunks):
+        return self.compute().chunk(chunks)
+
+    def isel(self, **indexers):
+        return self.compute().isel(**indexers)
+
+    def transpose(self, *dims):
+        return self.compute().transpose(*dims)
+
+    def __repr__(self):
+        return f"<LazyGridArray {self.sizes} blocks={len(self._thunks)} computed={self.computed}>"
+
+
 class GridDataset(dict):
     """Ordered mapping name -> GridArray (stand-in for xarray.Dataset)."""
 
@@ -265,33 +334,41 @@ class PointWiseDownscaler:
         assembled along the spatial dims (core.py:300-336 maps ``_predict_wrapper`` over the blocks)."""
         mdl = self._models
         was_x = _is_xarray(X)
+        feature_dim = kwargs.get("feature_dim", DEFAULT_FEATURE_DIM)
+
+        def run(sel, child):
+            rg, _ = _to_grid(getattr(child, method)(_unchunked(_isel(X, sel)), **kwargs), feature_dim)
+            return rg
+
+        if not was_x:  # GridArray / GridDataset: blocks on demand (like the reference's map_blocks result)
+            thunks = [(sel, (lambda s=sel, c=child: run(s, c))) for sel, child in mdl.blocks]
+            first = thunks[0][1]()
+            probe = X[list(X)[0]] if isinstance(X, GridDataset) else X
+            coords = {k: v for k, v in first.coords.items() if k not in mdl.spatial_dims}
+            for k in mdl.spatial_dims:
+                if k in getattr(probe, "coords", {}):
+                    coords[k] = probe.coords[k]
+            return LazyGridArray(thunks, first, mdl.spatial_dims, mdl.sizes, mdl.chunksizes, coords)
         out = None
         for sel, child in mdl.blocks:
-            res = getattr(child, method)(_unchunked(_isel(X, sel)), **kwargs)
-            rg, _ = _to_grid(res, kwargs.get("feature_dim", DEFAULT_FEATURE_DIM))
+            rg = run(sel, child)
             if out is None:
                 sizes = dict(rg.sizes)
                 sizes.update(mdl.sizes)
                 full = np.full([sizes[d] for d in rg.dims], np.nan, dtype=rg.dtype)
                 coords = {k: v for k, v in rg.coords.items() if k not in mdl.spatial_dims}
-                probe = X[list(X)[0]] if isinstance(X, GridDataset) else X
-                out = (full, rg.dims, coords, {} if was_x else dict(getattr(probe, "coords", {})))
+                out = (full, rg.dims, coords)
             out[0][tuple(sel.get(d, slice(None)) for d in out[1])] = rg.values
-        full, out_dims, coords, xg_coords = out
-        if was_x:
-            import xarray as xr
+        full, out_dims, coords = out
+        import xarray as xr
 
-            xc = {k: v for k, v in X.coords.items() if set(v.dims) <= set(out_dims)}
-            xc.update({k: ((k,), v) for k, v in coords.items() if k in out_dims and k not in xc})
-            res = xr.DataArray(full, dims=out_dims, coords=xc)
-            try:  # like the reference's map_blocks result: same spatial chunk structure (needs dask)
-                return res.chunk({d: mdl.chunksizes[d] for d in mdl.spatial_dims})
-            except Exception:  # noqa: BLE001
-                return res
-        for k in mdl.spatial_dims:
-            if k in xg_coords:
-                coords[k] = xg_coords[k]
-        return GridArray(full, out_dims, coords).chunk({d: mdl.chunksizes[d][0] for d in mdl.spatial_dims})
+        xc = {k: v for k, v in X.coords.items() if set(v.dims) <= set(out_dims)}
+        xc.update({k: ((k,), v) for k, v in coords.items() if k in out_dims and k not in xc})
+        res = xr.DataArray(full, dims=out_dims, coords=xc)
+        try:  # like the reference's map_blocks result: same spatial chunk structure (needs dask; without it the eager array)
+            return res.chunk({d: mdl.chunksizes[d] for d in mdl.spatial_dims})
+        except Exception:  # noqa: BLE001
+            return res
 
     def _batched(self):
         m = self._model

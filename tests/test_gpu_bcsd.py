@@ -647,8 +647,19 @@ def test_chunked_grids_and_attributes_on_the_engine():
     blocked.fit(X.chunk({"y": 2, "x": 2}), y.chunk({"y": 2, "x": 2}))
     assert isinstance(blocked._models, _BlockedModels) and len(blocked._models.blocks) == 6
     got = blocked.predict(X.chunk({"y": 2, "x": 2}))
+    # the result of a chunked grid is lazy like the reference's map_blocks result: blocks on demand, one at a time ...
+    from skdownscale_amd.core import LazyGridArray
+
+    assert isinstance(got, LazyGridArray) and not got.computed and got.shape == expected.shape and got.dims == expected.dims
     assert got.chunksizes["y"] == (2, 1) and got.chunksizes["x"] == (2, 2, 1)
-    assert np.array_equal(np.isnan(got.values), np.isnan(expected.values))
+    seen = 0
+    for sel, block in got.iter_blocks():
+        ref_block = expected.values[tuple(sel.get(d, slice(None)) for d in expected.dims)]
+        assert block.shape == ref_block.shape and np.array_equal(np.isnan(block.values), np.isnan(ref_block))
+        np.testing.assert_allclose(block.values[~np.isnan(ref_block)], ref_block[~np.isnan(ref_block)], rtol=1e-12)
+        seen += 1
+    assert seen == 6 and not got.computed  # ... and nothing assembled until .values is asked for
+    assert np.array_equal(np.isnan(got.values), np.isnan(expected.values)) and got.computed
     np.testing.assert_allclose(got.values[~np.isnan(got.values)], expected.values[~np.isnan(expected.values)], rtol=1e-12)
     # attributes: scalars on the model grid, array-valued ones through a template (group axis first)
     n = whole.get_attr("n_features_in_", "int64")

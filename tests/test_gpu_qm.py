@@ -343,3 +343,56 @@ def test_trend_aware_quantile_mapping_regressor_matches_the_reference(name):
     out = m.predict(pd.DataFrame(Xp[:, :1], index=index_p))
     if name != "qmr_both":
         assert_close(out[:, 0], exp[:, 0], scale=float(np.std(exp[:, 0])), what=f"trend-aware {name} (DataFrames)")
+
+
+def test_pointwise_transformers_match_the_reference_loop():
+    """g18_pointwise_transformers.npz: the reference's per-cell loop (core.py:146-197, 340-425) over a 2 x 3 grid with one
+    masked cell -- CunnaneTransformer.transform / inverse_transform, QuantileMapper.transform, and the attributes
+    get_attr stacks (CunnaneTransformer.cdf_, BcsdTemperature.y_climo_) -- against the batched PointWiseDownscaler."""
+    import pandas as pd
+
+    from skdownscale_amd import BcsdTemperature, CunnaneTransformer, GridArray, PointWiseDownscaler, QuantileMapper, synth
+
+    g = load("g18_pointwise_transformers")
+    ny, nx, T, Tz = (int(g[k]) for k in ("ny", "nx", "T", "Tz"))
+    C = ny * nx
+    cells = np.arange(C)
+    index = pd.date_range(str(g["start"]), periods=T)
+    X = synth.tas_field("X_hist", 7 + 19, index, cells, 1000)
+    y = synth.tas_field("y_obs", 7 + 19, index, cells, 1000)
+    Z = synth.tas_field("X_fut", 7 + 19, index[:Tz], cells, 1000)
+    for a in (X, y, Z):
+        a[:, 4] = np.nan  # the masked cell (first sample NaN: core.py:35-37)
+    dims = ("time", "y", "x")
+    grid = lambda a, idx: GridArray(a.reshape(len(a), ny, nx), dims, {"time": idx})  # noqa: E731
+    masked = np.isnan(g["ct_fwd"][0])
+    assert masked.sum() == 1 and masked[4]
+    # CunnaneTransformer: transform (inside the fitted range) and inverse_transform of a probability ramp
+    pw = PointWiseDownscaler(CunnaneTransformer())
+    pw.fit(grid(X, index))
+    Zc = np.clip(Z, np.nanmin(X, axis=0), np.nanmax(X, axis=0))
+    Zc[:, 4] = np.nan
+    fwd = pw.transform(grid(Zc, index[:Tz]))
+    assert fwd.dims == ("time", "variable", "y", "x")
+    assert_close(fwd.values[:, 0].reshape(Tz, C), g["ct_fwd"], scale=1.0, what="PointWiseDownscaler(CunnaneTransformer).transform")
+    pp = np.repeat(g["pp"][:, None], C, axis=1)
+    pp[:, 4] = np.nan
+    inv = pw.inverse_transform(GridArray(pp.reshape(-1, ny, nx), dims))
+    assert_close(inv.values[:, 0].reshape(-1, C), g["ct_inv"], what="PointWiseDownscaler(CunnaneTransformer).inverse_transform")
+    # the fitted CDFs of the cells, as get_attr's per-cell estimators hold them (cdf_ is a (pp, vals) pair in the reference too)
+    for c in range(C):
+        est = pw._cell_model(c, {})
+        if masked[c]:
+            assert est is None
+        else:
+            assert_close(np.asarray(est.cdf_.vals).reshape(-1), g["ct_cdf"][:, c], what=f"cdf_.vals of cell {c}")
+    # QuantileMapper.transform
+    pq = PointWiseDownscaler(QuantileMapper())
+    pq.fit(grid(X, index))
+    out = pq.transform(grid(Z, index[:Tz]))
+    assert_close(out.values[:, 0].reshape(Tz, C), g["qm_fwd"], what="PointWiseDownscaler(QuantileMapper).transform")
+    # get_attr of a fitted BCSD grid: the monthly climatologies of every cell
+    pb = PointWiseDownscaler(BcsdTemperature())
+    pb.fit(grid(X, index), grid(y, index))
+    climo = pb.get_attr("y_climo_")
+    assert_close(np.asarray(climo.values).reshape(12, C), g["y_climo"], what="get_attr('y_climo_')")
