@@ -474,6 +474,51 @@ def main():
     elif world > 1 and comm is None:
         gather = {"value_with_gather": None, "error": f"no RCCL communicator: {comm_error}"}
 
+    # ---- N > 1: the other sink -- every rank copies its own shard to host memory over its own PCIe link (N links in
+    # parallel instead of N - 1 xGMI links into one GPU); cell chunks, a copy thread drains chunk i while chunk i + 1 computes ----
+    if world > 1 and wl["kind"] != "analog" and args.gather_steps > 0:
+        host = None
+        try:
+            import ctypes as Cc
+            import threading
+
+            from skdownscale_amd.shard import cell_partition
+
+            nchunk = max(1, min(args.gather_chunks, C // 8))
+            bounds = cell_partition(C, nchunk)
+            dev = [ctx.empty((T, e - s)) for s, e in bounds]
+            hostbuf = [np.empty((T, e - s)) for s, e in bounds]
+            for hb in hostbuf:
+                hb.fill(0.0)  # touch the pages outside the timed region
+
+            def drain(i):
+                ctx.lib.sd_memcpy_d2h(ctx.handle, hostbuf[i].ctypes.data_as(Cc.c_void_p), dev[i].vptr, hostbuf[i].nbytes)
+
+            def host_step():
+                th = None
+                for i, (s, e) in enumerate(bounds):
+                    step((s, e), dev[i])  # (returns when the chunk's kernels are done: the status comes back with it)
+                    if th is not None:
+                        th.join()
+                    th = threading.Thread(target=drain, args=(i,))
+                    th.start()
+                th.join()
+
+            host_step()
+            barrier()
+            h0 = time.perf_counter()
+            for _ in range(args.gather_steps):
+                host_step()
+            barrier()
+            hdt = rdv.allreduce_max((time.perf_counter() - h0) / args.gather_steps)
+            host = {"value_with_host_gather": C * world / hdt, "ms_per_step_with_host_gather": hdt * 1e3,
+                    "host_gather": f"every rank's [T, {C}] shard to its process's host memory over its own PCIe link, {nchunk} cell chunks, "
+                                   "the copy of a chunk overlapping the next chunk's kernels",
+                    "host_GB_per_step_per_rank": 8.0 * T * C / 1e9}
+        except Exception as e:  # noqa: BLE001
+            host = {"value_with_host_gather": None, "host_gather_error": f"{type(e).__name__}: {e}"}
+        gather = dict(gather or {}, **host)
+
     # ---- parity spot check: part of the cpu_baseline leg (the oracle's result for the first cells is compared with the
     # engine's output for the same cells, outside the timed region) ----
     def check_parity(exp):
@@ -531,18 +576,35 @@ def main():
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     # HBM bytes per step from the committed rocprofv3 PMC passes of this exact workload (separate --pmc runs,
     # gfx950 FETCH_SIZE correction calibrated on a known byte count: profiles/pmc_traffic.json); null otherwise
-    traffic = None
+    traffic, traffic_source = None, None
     try:
+        import hashlib
+
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            for pt in json.load(f)["entries"]:
-                w = pt["workload"]
-                if w["config"] == config and w["cells"] == C and w["timesteps"] == T and w["kernel"] == "+".join(sorted(kern)):
+            doc = json.load(f)
+        csrc = os.path.join(ROOT, "scikit-downscale_amd", "csrc")
+        now = hashlib.sha256(b"".join(open(os.path.join(csrc, fn), "rb").read() for fn in sorted(os.listdir(csrc))
+                                      if fn.endswith((".hip", ".h")))).hexdigest()[:16]
+        src = doc.get("source", {})
+        traffic_source = {"file": "profiles/pmc_traffic.json", "head": src.get("head"), "generated": src.get("generated"),
+                          "kernel_sources_match": src.get("kernel_sources_sha16") == now, "entry": None}
+        for pt in doc["entries"]:
+            w = pt["workload"]
+            if w["config"] == config and w["cells"] == C and w["timesteps"] == T:
+                if w["kernel"] == "+".join(sorted(kern)):
                     traffic = pt["traffic_bytes_per_step"]
-    except Exception:  # noqa: BLE001
-        traffic = None
+                    traffic_source["entry"] = "matches this run's workload and kernel set"
+                else:
+                    traffic_source["entry"] = f"stale: measured for kernels {w['kernel']}, this run launches {'+'.join(sorted(kern))}"
+        if traffic_source["entry"] is None:
+            traffic_source["entry"] = "no PMC pass for this config / size"
+        if traffic is not None and not traffic_source["kernel_sources_match"]:
+            traffic_source["entry"] += "; kernel sources changed since the PMC pass (refresh with tools/dev/refresh_profiles.sh)"
+    except Exception as e:  # noqa: BLE001
+        traffic, traffic_source = None, {"file": "profiles/pmc_traffic.json", "entry": f"unreadable: {e}"}
     dominant = max(kern, key=lambda k: kern[k] * launches_per_step[k]) if kern else None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "kernel": "+".join(sorted(kern)), "dominant_kernel": dominant, "kernel_ms_per_step": kernel_ms,
+                "traffic": traffic, "traffic_source": traffic_source, "kernel": "+".join(sorted(kern)), "dominant_kernel": dominant, "kernel_ms_per_step": kernel_ms,
                 "algorithmic_bytes_per_step": alg_bytes, "algorithmic_bytes_per_cell": T * wl["bytes_per_step"],
                 "per_kernel_avg_ms": kern, "launches_per_step": launches_per_step}
     line = {

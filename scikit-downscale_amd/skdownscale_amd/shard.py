@@ -367,3 +367,78 @@ def cell_partition(n_cells: int, world: int):
 
 def local_cells(n_cells: int, world: int, rank: int):
     return cell_partition(n_cells, world)[rank]
+
+
+class ShardedPointWiseDownscaler:
+    """``PointWiseDownscaler`` over the GPUs of one node: every rank (one process per GPU, same script, same inputs) fits and
+    predicts a contiguous block of the grid's cells (``cell_partition`` of the flattened spatial dims) on its own engine, and
+    the predicted field is gathered to rank 0 (``comm.gather_field``: ``HostCommunicator`` for the host arrays this surface
+    returns).  Replaces the reference's ``map_blocks`` over dask workers (core.py:256-262, 300-336) for one node.
+
+    ``fit`` / ``predict`` / ``transform`` take what ``PointWiseDownscaler`` takes (GridArray, ndarray, xarray); ``predict`` returns
+    the full result on rank 0 and None on the other ranks."""
+
+    def __init__(self, model, dim="time", comm=None):
+        from .core import PointWiseDownscaler
+
+        self.comm = comm
+        self.rank = 0 if comm is None else comm.rank
+        self.world = 1 if comm is None else comm.world
+        self._dim = dim
+        self._inner = PointWiseDownscaler(model, dim)
+        self._layout = None
+
+    # -- the cells of this rank as a [time, (feature), cell] grid ---------------------------------------------------------
+    def _shard(self, X, feature_dim):
+        from .core import DEFAULT_FEATURE_DIM, GridArray, _to_grid
+
+        g, _ = _to_grid(X, feature_dim or DEFAULT_FEATURE_DIM)
+        lead = [d for d in g.dims if d in (self._dim, feature_dim or DEFAULT_FEATURE_DIM)]
+        spatial = [d for d in g.dims if d not in lead]
+        g = g.transpose(*lead, *spatial)
+        sp_shape = g.shape[len(lead):]
+        C = int(np.prod(sp_shape, dtype=np.int64)) if sp_shape else 1
+        s, e = cell_partition(C, self.world)[self.rank]
+        flat = np.asarray(g.values).reshape(g.shape[:len(lead)] + (C,))
+        coords = {k: v for k, v in g.coords.items() if k in lead}
+        local = GridArray(np.ascontiguousarray(flat[..., s:e]), tuple(lead) + ("cell",), coords)
+        return local, (tuple(spatial), tuple(sp_shape), C, {k: v for k, v in g.coords.items() if k in spatial})
+
+    def fit(self, X, *args, **kwargs):
+        fd = kwargs.get("feature_dim")
+        Xl, self._layout = self._shard(X, fd)
+        self._inner.fit(Xl, *[self._shard(a, fd)[0] for a in args], **kwargs)
+        return self
+
+    def _run(self, method, X, **kwargs):
+        from .core import GridArray, _to_grid
+
+        if self._layout is None:
+            raise ValueError("ShardedPointWiseDownscaler is not fitted: call fit() first")
+        fd = kwargs.get("feature_dim")
+        Xl, (spatial, sp_shape, C, sp_coords) = self._shard(X, fd)
+        res, _ = _to_grid(getattr(self._inner, method)(Xl, **kwargs), fd or "variable")
+        res = res.transpose(*[d for d in res.dims if d != "cell"], "cell")
+        lead_dims, lead_shape = res.dims[:-1], res.shape[:-1]
+        rows = int(np.prod(lead_shape, dtype=np.int64))
+        local = np.ascontiguousarray(np.asarray(res.values, dtype=np.float64).reshape(rows, res.shape[-1]))
+        cells = np.array([e - s for s, e in cell_partition(C, self.world)], dtype=np.int64)
+        if self.comm is None or self.world == 1:
+            full = local
+        else:
+            views = self.comm.gather_field(local, cells, 0)
+            if self.rank != 0:
+                return None
+            full = np.concatenate(views, axis=1)  # per-rank blocks side by side = the flattened cell axis
+        coords = {k: v for k, v in res.coords.items() if k in lead_dims}
+        coords.update(sp_coords)
+        return GridArray(full.reshape(tuple(lead_shape) + tuple(sp_shape)), tuple(lead_dims) + tuple(spatial), coords)
+
+    def predict(self, X, **kwargs):
+        return self._run("predict", X, **kwargs)
+
+    def transform(self, X, **kwargs):
+        return self._run("transform", X, **kwargs)
+
+    def inverse_transform(self, X, **kwargs):
+        return self._run("inverse_transform", X, **kwargs)

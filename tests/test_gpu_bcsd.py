@@ -681,3 +681,27 @@ def test_chunked_grids_and_attributes_on_the_engine():
     ar = PointWiseDownscaler(AnalogRegression(n_analogs=20))
     ar.fit(Xr, yr)
     assert (ar.get_attr("k_", "int64").values == 20).all()
+
+
+def test_sharded_pointwise_downscaler_single_rank_matches_the_plain_one():
+    """ShardedPointWiseDownscaler (skdownscale_amd/shard.py) with one rank on the GPU: same fields as PointWiseDownscaler
+    for the batched BcsdTemperature (the N > 1 layout logic runs on CPU in tests/test_host.py)."""
+    from skdownscale_amd import BcsdTemperature, PointWiseDownscaler
+    from skdownscale_amd.core import GridArray
+    from skdownscale_amd.shard import ShardedPointWiseDownscaler
+
+    rng = np.random.default_rng(3)
+    T, shape = 1461, (4, 6)
+    index = pd.date_range("1984-01-01", periods=T)
+    mk = lambda a: GridArray(a, ("time", "y", "x"), {"time": index})  # noqa: E731
+    X, y = mk(15 + 8 * rng.standard_normal((T,) + shape)), mk(13 + 9 * rng.standard_normal((T,) + shape))
+    X.values[0, 2, 3] = np.nan
+    plain = PointWiseDownscaler(BcsdTemperature())
+    plain.fit(X, y)
+    exp = plain.predict(X)
+    sh = ShardedPointWiseDownscaler(BcsdTemperature()).fit(X, y)
+    got = sh.predict(X)
+    assert got.dims == exp.dims and got.shape == exp.shape
+    assert np.array_equal(np.isnan(got.values), np.isnan(exp.values))
+    ok = ~np.isnan(exp.values)
+    assert np.array_equal(got.values[ok], exp.values[ok])

@@ -204,6 +204,52 @@ def test_product_gather_layout_three_ranks_on_cpu(tmp_path):
     assert "PRODUCT_GATHER_OK" in res.stdout
 
 
+SHARDED_PW_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path[:0] = [os.path.join(r"{root}", "scikit-downscale_amd")]
+from sklearn.linear_model import LinearRegression
+from skdownscale_amd import GridArray, PointWiseDownscaler
+from skdownscale_amd.shard import HostCommunicator, Rendezvous, ShardedPointWiseDownscaler
+rdv = Rendezvous.from_env()
+comm = HostCommunicator(rdv)
+rng = np.random.default_rng(5)          # same inputs on every rank (SPMD)
+X = GridArray(rng.standard_normal((40, 2, 3, 5)), ("time", "variable", "y", "x"), {{"y": np.arange(3.0), "x": np.arange(5.0)}})
+y = GridArray(rng.standard_normal((40, 3, 5)), ("time", "y", "x"))
+X.values[0, :, 1, 2] = np.nan            # a masked cell (core.py:35-37)
+m = ShardedPointWiseDownscaler(LinearRegression(), comm=comm)   # 15 cells over 3 ranks; an sklearn estimator: the per-cell loop
+m.fit(X, y)
+out = m.predict(X)
+if comm.rank == 0:
+    ref = PointWiseDownscaler(LinearRegression())
+    ref.fit(X, y)
+    exp = ref.predict(X)
+    assert out.dims == exp.dims and out.shape == exp.shape, (out.dims, exp.dims)
+    assert np.array_equal(np.isnan(out.values), np.isnan(exp.values)) and np.isnan(out.values[:, 1, 2]).all()
+    ok = ~np.isnan(exp.values)
+    assert np.array_equal(out.values[ok], exp.values[ok]), "sharded PointWiseDownscaler differs from the unsharded one"
+    assert np.array_equal(out.coords["x"], np.arange(5.0))
+    print("SHARDED_PW_OK")
+else:
+    assert out is None
+rdv.barrier()
+rdv.close()
+'''
+
+
+def test_sharded_pointwise_downscaler_three_ranks_on_cpu(tmp_path):
+    """The sharded drop-in surface (cells of the grid -> cell_partition -> per-rank PointWiseDownscaler -> gather to rank 0)
+    with three processes on CPU: an sklearn estimator takes PointWiseDownscaler's per-cell loop, so no GPU is needed; on a
+    GPU node the same class runs the batched estimators, one engine per rank."""
+    script = tmp_path / "worker.py"
+    script.write_text(SHARDED_PW_WORKER.format(root=ROOT))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+                          "--master-port", "29653", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "SHARDED_PW_OK" in res.stdout
+
+
 def test_padded_doy_grouper_matches_the_reference():
     """groupers.py:19-89 through g12_padded_doy.npz (row positions of all 366 groups and their means, from the real
     reference), plus the assertion of the reference's own test_paddeddoygrouper (test_pointwise_models.py:302-312)."""

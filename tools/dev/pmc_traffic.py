@@ -55,7 +55,23 @@ def main():
             "ratio": total / roof["algorithmic_bytes_per_step"],
             "per_kernel": detail,
         })
+    import hashlib
+    import subprocess
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    lib = os.path.join(root, "scikit-downscale_amd", "lib", "libsd_downscale.so")
+    try:
+        head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:  # noqa: BLE001
+        head = None
+    head = os.environ.get("SD_PROFILE_HEAD", head)  # (the GPU box has no .git: refresh_profiles.sh passes the HEAD along)
     doc = {
+        "source": {"generated": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "head": head, "dir": src,
+                   "library_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None,
+                   "kernel_sources_sha16": hashlib.sha256(b"".join(open(os.path.join(root, "scikit-downscale_amd", "csrc", f), "rb").read()
+                                                                   for f in sorted(os.listdir(os.path.join(root, "scikit-downscale_amd", "csrc")))
+                                                                   if f.endswith((".hip", ".h")))).hexdigest()[:16]},
         "_comment": "HBM traffic per timed step from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py "
                     "--config N --steps 2 --warmup 1 --no-cpu-baseline` (profiles/r02/pmc_fetch_cN.csv, pmc_write_cN.csv; counter unit KiB, "
                     "mean over the dispatches of a kernel symbol x launches per step).  gfx950: FETCH_SIZE x 2 (128-byte requests tallied at 64 "

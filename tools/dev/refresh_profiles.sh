@@ -4,7 +4,10 @@ set -u
 O=gpurun_out/r; mkdir -p $O
 export TMPDIR=/tmp
 R=$PWD
-PARTS=${PARTS:-bench stats pmc sq extra torchrun tests}
+# Order matters: `pmc` needs a bench line per config for the kernel names / launches per step (it makes a short one itself when
+# there is none), writes profiles/pmc_traffic.json, and the `bench` lines made afterwards in the same job carry that figure
+# with `traffic_source.kernel_sources_match: true`.
+PARTS=${PARTS:-pmc bench stats sq extra torchrun tests}
 CONFIGS=${CONFIGS:-2 3 4}
 for part in $PARTS; do
 case $part in
@@ -26,6 +29,7 @@ stats)
   ;;
 pmc)
   for c in $CONFIGS; do
+    [ -f $O/bench_config$c.json ] || timeout 300 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err
     cells=""
     for ctr in FETCH_SIZE WRITE_SIZE; do
       n=$(echo $ctr | tr A-Z a-z | sed 's/_size//')
@@ -34,6 +38,8 @@ pmc)
       rm -rf $O/pmc
     done
   done
+  python tools/dev/pmc_traffic.py $O $O/pmc_traffic.json 2>&1 | tail -4
+  cp $O/pmc_traffic.json profiles/pmc_traffic.json   # (on the GPU box: read by the bench lines of this job; copied back by refresh_all.sh)
   ;;
 sq)
   for c in $CONFIGS; do
@@ -67,7 +73,6 @@ tests)
   ;;
 esac
 done
-python tools/dev/pmc_traffic.py $O $O/pmc_traffic.json 2>&1 | tail -4
 for c in 2 3 4; do [ -f $O/bench_config$c.json ] && python - $O/bench_config$c.json <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
