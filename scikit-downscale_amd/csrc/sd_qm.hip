@@ -263,15 +263,24 @@ __global__ void __launch_bounds__(1024) qm_map_kernel(int model, int mode, int n
                 double p;
                 if (x < x_min) {
                     if (ext_lo) {  // bracket (synthetic node, first value); below the synthetic node: left = -inf (quantile.py:245)
-                        const double slope = (pp_at(0, dn) - kSyntheticMin) / (x_min - vx_lo);
-                        p = x < vx_lo ? -__builtin_inf() : slope * (x - vx_lo) + kSyntheticMin;
+                        // (tied end points give a level tail line: vx_lo == x_min, every x < x_min is "below the node")
+                        if (x < vx_lo || !(x_min > vx_lo)) {
+                            p = -__builtin_inf();
+                        } else {
+                            const double slope = (pp_at(0, dn) - kSyntheticMin) / (x_min - vx_lo);
+                            p = slope * (x - vx_lo) + kSyntheticMin;
+                        }
                     } else {
                         p = pp_at(0, dn);
                     }
                 } else if (x >= x_max) {
                     if (ext_hi && x > x_max) {
-                        const double slope = (kSyntheticMax - pp_at(n - 1, dn)) / (vx_hi - x_max);
-                        p = x > vx_hi ? __builtin_inf() : slope * (x - x_max) + pp_at(n - 1, dn);
+                        if (x > vx_hi || !(vx_hi > x_max)) {
+                            p = __builtin_inf();
+                        } else {
+                            const double slope = (kSyntheticMax - pp_at(n - 1, dn)) / (vx_hi - x_max);
+                            p = slope * (x - x_max) + pp_at(n - 1, dn);
+                        }
                     } else {
                         p = pp_at(n - 1, dn);
                     }
