@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SD_VERSION 101  /* bump on every change of an exported signature: the Python loader refuses other versions */
+#define SD_VERSION 102  /* bump on every change of an exported signature: the Python loader refuses other versions */
 
 /* return codes */
 #define SD_OK 0
@@ -108,6 +108,11 @@ int sd_dev_alloc(sd_ctx* ctx, size_t bytes, void** dptr);
 int sd_dev_free(sd_ctx* ctx, void* dptr);
 int sd_memcpy_h2d(sd_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int sd_memcpy_d2h(sd_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* float32 transport: a float32 grid crosses PCIe as float32 and is widened / narrowed on the device (exact
+ * widening, round-to-nearest narrowing: what the reference's NumPy promotion / result cast do on the host, core.py:119).
+ * n elements; src and dst device pointers, queued on the context's stream. */
+int sd_convert_f32_to_f64_dev(sd_ctx* ctx, const float* src_dev, int64_t n, double* dst_dev);
+int sd_convert_f64_to_f32_dev(sd_ctx* ctx, const double* src_dev, int64_t n, float* dst_dev);
 int sd_memcpy_d2d(sd_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 
 /* ---- timing: HIP events on the context's stream ---------------------------------------------- */

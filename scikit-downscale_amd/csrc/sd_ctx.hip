@@ -253,6 +253,53 @@ int sd_memcpy_d2h(sd_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return SD_OK;
 }
 
+namespace {
+// float32 <-> float64 over n elements: 4 per thread through 16-byte loads / stores where the element count allows
+__global__ void __launch_bounds__(256) widen_kernel(const float* __restrict__ src, int64_t n, double* __restrict__ dst) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        *reinterpret_cast<double2*>(dst + i) = make_double2((double)v.x, (double)v.y);
+        *reinterpret_cast<double2*>(dst + i + 2) = make_double2((double)v.z, (double)v.w);
+    } else {
+        for (int64_t j = i; j < n; ++j) dst[j] = (double)src[j];
+    }
+}
+__global__ void __launch_bounds__(256) narrow_kernel(const double* __restrict__ src, int64_t n, float* __restrict__ dst) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const double2 a = *reinterpret_cast<const double2*>(src + i), b = *reinterpret_cast<const double2*>(src + i + 2);
+        *reinterpret_cast<float4*>(dst + i) = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+    } else {
+        for (int64_t j = i; j < n; ++j) dst[j] = (float)src[j];
+    }
+}
+}  // namespace
+
+int sd_convert_f32_to_f64_dev(sd_ctx* ctx, const float* src_dev, int64_t n, double* dst_dev) {
+    SD_CHECK_ARG(ctx && src_dev && dst_dev && n >= 0, "sd_convert_f32_to_f64_dev: bad argument");
+    SD_CHECK_ARG((reinterpret_cast<uintptr_t>(src_dev) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst_dev) & 15) == 0,
+                 "sd_convert_f32_to_f64_dev: 16-byte aligned device pointers expected");
+    if (n == 0) return SD_OK;
+    SD_HIP(hipSetDevice(ctx->device));
+    const int64_t nb = (n + 1023) / 1024;
+    SD_CHECK_ARG(nb < ((int64_t)1 << 31), "sd_convert_f32_to_f64_dev: too many elements for one launch");
+    SD_LAUNCH(ctx, "widen_kernel", widen_kernel, dim3((unsigned)nb), dim3(256), 0, src_dev, n, dst_dev);
+    return SD_OK;
+}
+
+int sd_convert_f64_to_f32_dev(sd_ctx* ctx, const double* src_dev, int64_t n, float* dst_dev) {
+    SD_CHECK_ARG(ctx && src_dev && dst_dev && n >= 0, "sd_convert_f64_to_f32_dev: bad argument");
+    SD_CHECK_ARG((reinterpret_cast<uintptr_t>(src_dev) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst_dev) & 15) == 0,
+                 "sd_convert_f64_to_f32_dev: 16-byte aligned device pointers expected");
+    if (n == 0) return SD_OK;
+    SD_HIP(hipSetDevice(ctx->device));
+    const int64_t nb = (n + 1023) / 1024;
+    SD_CHECK_ARG(nb < ((int64_t)1 << 31), "sd_convert_f64_to_f32_dev: too many elements for one launch");
+    SD_LAUNCH(ctx, "narrow_kernel", narrow_kernel, dim3((unsigned)nb), dim3(256), 0, src_dev, n, dst_dev);
+    return SD_OK;
+}
+
 int sd_memcpy_d2d(sd_ctx* ctx, void* dst, const void* src, size_t bytes) {
     SD_CHECK_ARG(ctx && dst && src, "sd_memcpy_d2d: NULL argument");
     SD_HIP(hipSetDevice(ctx->device));

@@ -44,6 +44,8 @@ SIGNATURES = {
     "sd_memcpy_h2d": [_p, _p, _p, C.c_size_t],
     "sd_memcpy_d2h": [_p, _p, _p, C.c_size_t],
     "sd_memcpy_d2d": [_p, _p, _p, C.c_size_t],
+    "sd_convert_f32_to_f64_dev": [_p, _p, _i64, _p],
+    "sd_convert_f64_to_f32_dev": [_p, _p, _i64, _p],
     "sd_timer_start": [_p],
     "sd_timer_stop": [_p, C.POINTER(C.c_float)],
     "sd_prof_enable": [_p, _int],
@@ -104,7 +106,7 @@ SIGNATURES = {
 }
 
 _libs = {}
-ABI_VERSION = 101  # include/sd_downscale.h: SD_VERSION
+ABI_VERSION = 102  # include/sd_downscale.h: SD_VERSION
 
 
 class EngineError(RuntimeError):

@@ -116,7 +116,7 @@ class BcsdGridModel:
         self.status_ = self.state.status()
         return self
 
-    def predict(self, Xp, index_p, out=None):
+    def predict(self, Xp, index_p, out=None, out_dtype=None):
         if self.state is None:
             raise NotFittedError("This BCSD grid model is not fitted yet.")
         if self.daily and self.return_anoms:
@@ -130,7 +130,7 @@ class BcsdGridModel:
         if self.kind == _lib.BCSD_TAS and (self.daily or self.trend_grouper is not self.grouper):
             tkeys, gid_t = np.unique(group_keys(index_p, self.trend_grouper), return_inverse=True)
             return self.ctx.bcsd_predict_trend(self.state, Xp, gid_p, gid_t.astype(np.int32), len(tkeys), out=out)
-        return self.ctx.bcsd_predict(self.state, Xp, gid_p, out=out)
+        return self.ctx.bcsd_predict(self.state, Xp, gid_p, out=out, out_dtype=out_dtype)
 
     def export(self):
         e = self.state.export()

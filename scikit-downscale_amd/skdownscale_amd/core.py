@@ -460,7 +460,10 @@ class PointWiseDownscaler:
                 msg = "BCSD only supports up to 4 features, found {}" if m._kind == _lib.BCSD_TAS else "BCSD only supports 1 feature, found {}"
                 raise ValueError(msg.format(F))
             gm = self._bcsd_proto._new_grid()
-            gm.fit(Xv[:, 0, :], yv, index)
+            if Xg.dtype == np.float32 and yg.dtype == np.float32:  # float32 grids cross PCIe as float32 (widened in HBM, exact)
+                gm.fit(np.ascontiguousarray(Xg.values).reshape(T, C), np.ascontiguousarray(yg.values).reshape(T, C), index)
+            else:
+                gm.fit(Xv[:, 0, :], yv, index)
             self._raise_for_status(gm.status_, Xv[:, 0, :], yv)
         elif kind == "qm":
             if F != 1:
@@ -559,7 +562,10 @@ class PointWiseDownscaler:
         mdl = self._models
         coords = {k: v for k, v in Xg.coords.items() if k != feature_dim}
         if mdl.kind == "bcsd":
-            out, status = mdl.grid_model.predict(Xv[:, 0, :], index)
+            if Xg.dtype == np.float32 and F == 1:  # in and out as float32, widened / narrowed on the device
+                out, status = mdl.grid_model.predict(np.ascontiguousarray(Xg.values).reshape(T, C), index, out_dtype=np.float32)
+            else:
+                out, status = mdl.grid_model.predict(Xv[:, 0, :], index)
             self._raise_for_status(status, Xv[:, 0, :], Xv[:, 0, :])
             vals = out.reshape((T,) + tuple(spatial_shape)).astype(Xg.dtype, copy=False)
             res = GridArray(vals, (self._dim,) + spatial_dims, coords)

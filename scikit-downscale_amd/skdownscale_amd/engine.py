@@ -231,6 +231,34 @@ class Context:
         a = np.ascontiguousarray(a, dtype=dtype)
         return DeviceArray(self, a.shape, dtype).copy_from_host(a)
 
+    # ---- float32 transport: a float32 host field crosses PCIe as float32 and is widened on the device (exact), a result
+    # wanted as float32 is narrowed there (round to nearest, what ``.astype(np.float32)`` does on the host) ----
+    @staticmethod
+    def _is_f32_host(a):
+        return isinstance(a, np.ndarray) and a.dtype == np.float32
+
+    def widen_to_device(self, a32):
+        """float32 host array -> float64 DeviceArray of the same shape (half the host-to-device bytes of an upcast on the host)"""
+        a32 = np.ascontiguousarray(a32, dtype=np.float32)
+        d32 = DeviceArray(self, a32.shape, np.float32).copy_from_host(a32)
+        d64 = DeviceArray(self, a32.shape, np.float64)
+        check(self.lib.sd_convert_f32_to_f64_dev(self.handle, d32.vptr, a32.size, d64.vptr))
+        self.synchronize()
+        d32.free()
+        return d64
+
+    def narrow_to_host(self, d64, out=None):
+        """float64 DeviceArray (contiguous) -> float32 host array: narrowed on the device, half the device-to-host bytes"""
+        if d64.ld != d64.shape[-1]:
+            raise ValueError("narrow_to_host needs a contiguous DeviceArray")
+        n = int(np.prod(d64.shape, dtype=np.int64))
+        d32 = DeviceArray(self, d64.shape, np.float32)
+        check(self.lib.sd_convert_f64_to_f32_dev(self.handle, d64.vptr, n, d32.vptr))
+        res = np.empty(d64.shape, dtype=np.float32) if out is None else out
+        check(self.lib.sd_memcpy_d2h(self.handle, ptr(res), d32.vptr, res.nbytes))
+        d32.free()
+        return res
+
     def wrap(self, dptr, shape, dtype=np.float64):
         """View foreign device memory (e.g. a torch tensor's data_ptr()) without owning it."""
         return DeviceArray(self, shape, dtype, dptr=int(dptr), owner=False)
@@ -273,6 +301,9 @@ class Context:
         """X, y: numpy [T,C] (host path) or DeviceArray [T,C] (resident path); X may be None for PR.  ``detrend``:
         qm_kwargs={'detrend': True} (quantile.py:95-98,128-145)."""
         return_anoms = self._bcsd_options(return_anoms, detrend)
+        if self._is_f32_host(y) and (X is None or self._is_f32_host(X)) and y.ndim == 2 and y.size % 4 == 0:
+            y = self.widen_to_device(y)  # float32 grids: 4 bytes per sample over PCIe, widened in HBM
+            X = None if X is None else self.widen_to_device(X)
         y = self._field2("y", y)
         X = self._field2("X", X, *y.shape)
         if X is not None and isinstance(X, DeviceArray) != isinstance(y, DeviceArray):
@@ -344,8 +375,15 @@ class Context:
                                                  ptr(status)))
         return out, status
 
-    def bcsd_predict(self, state, Xp, gid_p, out=None):
+    def bcsd_predict(self, state, Xp, gid_p, out=None, out_dtype=None):
+        """``out_dtype=np.float32`` with a float32 host ``Xp``: the field goes in and the result comes back as float32
+        (widened / narrowed on the device); everything else as before (float64 results)."""
         info = state.info()
+        if self._is_f32_host(Xp) and Xp.ndim == 2 and Xp.size % 4 == 0 and out is None:
+            d_out, status = self.bcsd_predict(state, self.widen_to_device(Xp), gid_p)
+            if out_dtype is not None and np.dtype(out_dtype) == np.float32:
+                return self.narrow_to_host(d_out), status
+            return d_out.to_host(), status
         Xp = self._field2("X", Xp, None, info["C"])
         gid_p = self._group_ids("group_id", gid_p, Xp.shape[0], info["G"])
         Cc = info["C"]

@@ -705,3 +705,34 @@ def test_sharded_pointwise_downscaler_single_rank_matches_the_plain_one():
     assert np.array_equal(np.isnan(got.values), np.isnan(exp.values))
     ok = ~np.isnan(exp.values)
     assert np.array_equal(got.values[ok], exp.values[ok])
+
+
+def test_float32_fields_cross_pcie_as_float32():
+    """float32 host grids take the float32 transport (widened on the device: exact; a float32 result is narrowed there: the
+    rounding of ``.astype(np.float32)``): bit-identical to upcasting on the host, for the engine call and for
+    PointWiseDownscaler, and the conversion entry points themselves round-trip."""
+    from skdownscale_amd import BcsdTemperature, GridArray, PointWiseDownscaler
+    from skdownscale_amd.engine import default_context
+
+    ctx = default_context()
+    rng = np.random.default_rng(11)
+    T, C = 1461, 8
+    index = pd.date_range("1990-01-01", periods=T)
+    gid = month_gid(index)
+    X32 = (12 + 7 * rng.standard_normal((T, C))).astype(np.float32)
+    y32 = (10 + 5 * rng.standard_normal((T, C))).astype(np.float32)
+    d = ctx.widen_to_device(X32)
+    assert d.dtype == np.float64 and np.array_equal(d.to_host(), X32.astype(np.float64))
+    assert np.array_equal(ctx.narrow_to_host(ctx.to_device(X32.astype(np.float64) * 1.000000123)), (X32.astype(np.float64) * 1.000000123).astype(np.float32))
+    st64 = ctx.bcsd_fit(0, X32.astype(np.float64), y32.astype(np.float64), gid, 12, True)
+    exp, _ = ctx.bcsd_predict(st64, X32.astype(np.float64), gid)
+    st32 = ctx.bcsd_fit(0, X32, y32, gid, 12, True)
+    out, status = ctx.bcsd_predict(st32, X32, gid)
+    assert out.dtype == np.float64 and (status == 0).all() and np.array_equal(out, exp)
+    out32, _ = ctx.bcsd_predict(st32, X32, gid, out_dtype=np.float32)
+    assert out32.dtype == np.float32 and np.array_equal(out32, exp.astype(np.float32))
+    mk = lambda a: GridArray(a.reshape(T, 2, 4), ("time", "y", "x"), {"time": index})  # noqa: E731
+    pw = PointWiseDownscaler(BcsdTemperature())
+    pw.fit(mk(X32), mk(y32))
+    res = pw.predict(mk(X32))
+    assert res.values.dtype == np.float32 and np.array_equal(res.values.reshape(T, C), exp.astype(np.float32))
