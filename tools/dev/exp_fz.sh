@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B and ablation sweep of the fused BcsdTemperature kernel (run through gpurun; log -> gpurun_out/exp_fz.log)
+# A/B against the previous library (lib/libsd_downscale_prev.so, if present) and phase ablations of the fused BcsdTemperature
+# kernel (development library, SD_FZ_ABLATE); run through gpurun; log -> gpurun_out/exp_fz.log
 set -u
 O=gpurun_out; mkdir -p $O
 L=$PWD/scikit-downscale_amd/lib
@@ -23,13 +24,11 @@ if [ "${TESTS:-1}" = 1 ]; then
   timeout 900 python -m pytest tests/test_gpu_bcsd.py tests/test_gpu_detrend.py -x -q -m gpu 2>&1 | tail -3 | tee -a $LOG
 fi
 for rep in 1 2; do
-  one prev SD_DOWNSCALE_LIB=$L/libsd_downscale_prev.so
+  [ -f $L/libsd_downscale_prev.so ] && one prev SD_DOWNSCALE_LIB=$L/libsd_downscale_prev.so
   one new SD_DOWNSCALE_LIB=$L/libsd_downscale.so
 done
 D=SD_DOWNSCALE_LIB=$L/libsd_downscale_dev.so
 one dev $D
-for nt in 1 2 4 3 7 8 23; do one "dev NT=$nt" $D SD_FZ_NT=$nt; done
-one "dev SHIFT=2(regs/scratch)" $D SD_FZ_SHIFT=2
 one "dev SLAB" $D SD_FZ_SLAB=1
 for a in 8 4 12 32 64 1 2 3 16 127; do one "dev ABLATE=$a" $D SD_FZ_ABLATE=$a; done
 one "dev RS_SPLIT=0" $D SD_RS_SPLIT=0
