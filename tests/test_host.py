@@ -522,3 +522,22 @@ def test_tcp_rendezvous_three_ranks(tmp_path):
     outs = [p.communicate(timeout=120) for p in procs]
     for p, (out, err) in zip(procs, outs):
         assert p.returncode == 0 and out.startswith("ok"), (out, err)
+
+
+def test_bench_cpu_legs_run_for_every_config():
+    """bench.py's CPU side (per-config port, NumPy on one core and on one process per core, oracle result for the parity check)
+    on a short series: every leg reports a positive rate, the checker receives the oracle's field for the first cells."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for kind, ndim in (("bcsd_tas", 2), ("bcsd_pr", 2), ("analog", 3)):
+        seen = {}
+        port, numpy_1, numpy_n, parity, c_port = bench.cpu_baseline(kind, 731, 0, 4096, 0.4, check=lambda exp: seen.setdefault("shape", exp.shape) and "ok")
+        assert parity == "ok" and len(seen["shape"]) == ndim and seen["shape"][0] == 731
+        for leg in (port, numpy_1, numpy_n):
+            assert leg is not None and leg["value"] > 0 and leg["cores"] >= 1 and leg["unit"] == "cells/s"
+        assert numpy_n["cores"] >= numpy_1["cores"]
+        if kind != "analog":
+            assert c_port is not None and "sd_oracle.c" in c_port["sample"]
