@@ -31,6 +31,7 @@
 #include "sd_internal.h"
 #include "sd_lsq.h"
 #include "sd_sortnet.h"
+#include "sd_wave.h"
 
 namespace {
 
@@ -176,6 +177,158 @@ __global__ void __launch_bounds__(1024) analog_sort_kernel(const double* __restr
 constexpr long long kTagMask = 0x3fff;      // 14 bits: series of up to 16 384 samples
 constexpr unsigned kTagPadHi = 0x7fe00000u;  // upper word of the pad keys (>= 8.98e307: beyond any data the fast path accepts)
 
+// ---- fit, F == 1, tile-shaped first stage ------------------------------------------------------------------------------
+// analog_tile_sort_kernel<K>: one 512-thread workgroup = 8 adjacent cells x one chunk of 64 * K consecutive time steps, read as
+// 64-byte row fragments of the time-major fields (the geometry of the BCSD kernels, sd_wave.h).  It does what the two staging
+// transposes of X and y did (the cell-major copies the state keeps, with the mask / finite bookkeeping of
+// analog_transpose_kernel) and, while the tile is on chip, sorts every cell's chunk of tagged keys with the wave sort: the
+// sorted runs of 64 * K keys go to a scratch field and analog_sort2_kernel only has to merge them (rounds 6 ..), which is less
+// than half of its work (measured: 9.8 instead of 23.1 ms per 100 000 cells with the register sort and rounds 0 .. 5 skipped).
+// Keys are those of analog_sort2_kernel<K, true>: (x with -0.0 -> +0.0, non-finite -> 0) with the training index in the 14 low
+// mantissa bits; slots past the series are pads (kTagPadHi, index).  A cell that holds a value in the pad range is reported in
+// odd_flags (it takes the exact two-sort kernel, like in the single-kernel path).
+template <int K>
+__global__ void __launch_bounds__(sdw::kThreads, 4) analog_tile_sort_kernel(const double* __restrict__ X, const double* __restrict__ y,
+                                                                            int64_t ld, int64_t T, int64_t C, int nchunks,
+                                                                            double* __restrict__ Xc, double* __restrict__ yc,
+                                                                            double* __restrict__ runs, int64_t runs_stride,
+                                                                            int32_t* status, int32_t* odd_flags) {
+    using namespace sdw;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int CHUNK = kWave * K;
+    constexpr int NR = (CHUNK + kRowsPerPass - 1) / kRowsPerPass;  // rows a thread loads of one tile
+    constexpr int RS = CHUNK + 2 + ((4 - (CHUNK + 2) % 4) + 2) % 4;  // row stride: >= CHUNK + 1 slots, RS % 4 == 2 (see sd_bcsd_rs_row_stride)
+    double* const tile = reinterpret_cast<double*>(smem_raw) + kHeadDoubles;  // (no row at LDS address 0: sd_wave.h keeps "address - 8" positions)
+    // workgroup -> (tile, chunk): XCD-aware like xcd_tile_of_block (tile-fastest inside an XCD)
+    const int64_t ntiles = (C + kW - 1) / kW;
+    int64_t tile_id;
+    int q;
+    xcd_tile_of_block(blockIdx.x, ntiles, &tile_id, &q);
+    if (tile_id >= ntiles || q >= nchunks) return;
+    const int64_t c0 = tile_id * kW;
+    const int64_t r0 = (int64_t)q * CHUNK;
+    const int nq = (int)(T - r0 < CHUNK ? T - r0 : CHUNK);  // valid rows of this chunk (> 0)
+    const int tid = tid_now();
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave;
+    const int cp = tid & 3, rr = tid >> 2;
+    const int64_t cpair = c0 + 2 * cp;
+    const bool vec = (ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && cpair + 1 < C;
+    // ---- both tiles are requested at once ----
+    double x0[NR], x1[NR], y0[NR], y1[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int r = rr + k * kRowsPerPass;
+        const int64_t row = r0 + (r < nq ? r : 0);
+        const double* px = X + row * ld + cpair;
+        if (vec) {
+            const double2 v = *reinterpret_cast<const double2*>(px);
+            x0[k] = v.x;
+            x1[k] = v.y;
+        } else {
+            x0[k] = cpair < C ? px[0] : 0.0;
+            x1[k] = cpair + 1 < C ? px[1] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int r = rr + k * kRowsPerPass;
+        const int64_t row = r0 + (r < nq ? r : 0);
+        const double* py = y + row * ld + cpair;
+        if (vec) {
+            const double2 v = *reinterpret_cast<const double2*>(py);
+            y0[k] = v.x;
+            y1[k] = v.y;
+        } else {
+            y0[k] = cpair < C ? py[0] : 0.0;
+            y1[k] = cpair + 1 < C ? py[1] : 0.0;
+        }
+    }
+    // ---- X tile -> rows; mask (core.py:35-37: first sample of X is NaN) and finite bookkeeping ----
+    {
+        double* d0 = tile + (2 * cp) * RS;
+        double* d1 = d0 + RS;
+        int bits0 = 0, bits1 = 0;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = rr + k * kRowsPerPass;
+            if (r < nq) {
+                if (r0 + r == 0) {
+                    bits0 |= x0[k] != x0[k] ? SDI_MASKED : 0;
+                    bits1 |= x1[k] != x1[k] ? SDI_MASKED : 0;
+                }
+                bits0 |= sd_finite(x0[k]) ? 0 : SDI_NONFINITE;
+                bits1 |= sd_finite(x1[k]) ? 0 : SDI_NONFINITE;
+                bits0 |= sd_finite(y0[k]) ? 0 : SDI_NONFINITE;
+                bits1 |= sd_finite(y1[k]) ? 0 : SDI_NONFINITE;
+                d0[r] = x0[k];
+                d1[r] = x1[k];
+            }
+        }
+        if (bits0 && cpair < C) atomicOr(&status[cpair], bits0);
+        if (bits1 && cpair + 1 < C) atomicOr(&status[cpair + 1], bits1);
+    }
+    __syncthreads();
+    const int64_t c = c0 + wave;
+    const bool cell_ok = c < C;
+    double* const row = tile + wave * RS;
+    {
+        // cell-major copy of the chunk (coalesced: the wave writes 512 consecutive bytes per step)
+        if (cell_ok) {
+            double* dst = Xc + c * T + r0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = lane + i * kWave;
+                if (j < nq) dst[j] = row[j];
+            }
+        }
+        // tagged keys of the K consecutive samples this lane owns
+        double v[K];
+        bool odd = false;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int jl = K * lane + i;  // (lane stride K is odd: conflict-free)
+            const int64_t j = r0 + jl;    // training index
+            double xv = row[jl < nq ? jl : 0];
+            xv = sd_finite(xv) ? xv : 0.0;
+            const long long b = __double_as_longlong(xv + 0.0);  // -0.0 -> +0.0: they tie as values
+            odd |= jl < nq && (unsigned)((b >> 32) & 0x7fffffff) >= kTagPadHi;
+            const long long key = jl < nq ? ((b & ~(long long)kTagMask) | (long long)j) : (((long long)kTagPadHi << 32) | (long long)j);
+            v[i] = __longlong_as_double(key);
+        }
+        if (odd && cell_ok) atomicOr(&odd_flags[c], 1);
+        wave_fence();
+        sort_segment<K>(v, row, CHUNK, lane);  // every slot of the chunk is an element: pads sort behind the data
+        if (cell_ok) {
+            double* dst = runs + c * runs_stride + r0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) dst[lane + i * kWave] = row[lane + i * kWave];
+        }
+    }
+    __syncthreads();
+    // ---- y tile -> rows -> cell-major copy ----
+    {
+        double* d0 = tile + (2 * cp) * RS;
+        double* d1 = d0 + RS;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = rr + k * kRowsPerPass;
+            if (r < nq) {
+                d0[r] = y0[k];
+                d1[r] = y1[k];
+            }
+        }
+    }
+    __syncthreads();
+    if (cell_ok) {
+        double* dst = yc + c * T + r0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int j = lane + i * kWave;
+            if (j < nq) dst[j] = row[j];
+        }
+    }
+}
+
 // TAGGED = true: the index-tag pass (below); cells it cannot serve are appended to `worklist` and the TAGGED = false
 // instance (two sorts, any data) walks that list afterwards.  TAGGED = false with worklist == nullptr: every cell.
 template <int K, bool TAGGED>
@@ -184,10 +337,14 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
                                                             int64_t T, int64_t C, double* __restrict__ xs,
                                                             int32_t* __restrict__ xi, double* __restrict__ yx,
                                                             double* __restrict__ pq_all, double* __restrict__ ybar_all,
-                                                            int32_t* worklist, int32_t* work_count) {
+                                                            int32_t* worklist, int32_t* work_count,
+                                                            const double* __restrict__ runs, int np_runs,
+                                                            const int32_t* __restrict__ odd_flags) {
+    // runs != nullptr (TAGGED only): the keys arrive as sorted runs of 64 * K slots, np_runs slots per cell
+    // (analog_tile_sort_kernel): only the merge rounds 6 .. are left
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
-    const int np = (n + K - 1) / K * K;
+    const int np = (TAGGED && runs != nullptr) ? np_runs : (n + K - 1) / K * K;
     double* buf = reinterpret_cast<double*>(smem_raw);     // np + 1 doubles
     int* xch = reinterpret_cast<int*>(buf + np + 1);        // nthr + 1 ints (also 3 x 16 doubles of reduction scratch)
     double* red = reinterpret_cast<double*>(xch);
@@ -211,7 +368,7 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
             }
         };
         __syncthreads();
-        load_x();
+        if (!(TAGGED && runs != nullptr)) load_x();
         __syncthreads();
         if constexpr (TAGGED) {
             // ---- fast path: the training index rides through the sort in the 14 low mantissa bits of the key.  The sorted
@@ -220,18 +377,36 @@ __global__ void __launch_bounds__(1024) analog_sort2_kernel(const double* __rest
             // magnitudes reach the pad range take the two-sort path below).  The tags of the sorted keys are xi, and xs / yx
             // are x / y gathered through them from LDS: 2 x K random LDS reads per thread instead of the 14 x K of the
             // first-position search.
-            double t[K];
             bool odd = false;
+            if (runs != nullptr) {
+                const double* rc = runs + c * (int64_t)np_runs;
+                double kv[K + 1];
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const int j = K * tid + i;
-                const long long b = __double_as_longlong(buf[j < np ? j : np] + 0.0);  // (lane stride K is odd: conflict-free); -0.0 -> +0.0: they tie as values
-                odd |= j < n && (unsigned)((b >> 32) & 0x7fffffff) >= kTagPadHi;
-                const long long key = j < n ? ((b & ~(long long)kTagMask) | (long long)j) : (((long long)kTagPadHi << 32) | (long long)j);
-                t[i] = __longlong_as_double(key);
+                for (int t2 = 0; t2 <= K; ++t2) {
+                    const int i = tid + t2 * nthr;
+                    kv[t2] = i < np ? rc[i] : inf;
+                }
+#pragma unroll
+                for (int t2 = 0; t2 <= K; ++t2) {
+                    const int i = tid + t2 * nthr;
+                    if (i <= np) buf[i] = kv[t2];
+                }
+                odd = odd_flags[c] != 0;
+                __syncthreads();
+                sdsort::block_merge_rounds<K>(buf, np, xch, tid, nthr, 6);
+            } else {
+                double t[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const int j = K * tid + i;
+                    const long long b = __double_as_longlong(buf[j < np ? j : np] + 0.0);  // (lane stride K is odd: conflict-free); -0.0 -> +0.0: they tie as values
+                    odd |= j < n && (unsigned)((b >> 32) & 0x7fffffff) >= kTagPadHi;
+                    const long long key = j < n ? ((b & ~(long long)kTagMask) | (long long)j) : (((long long)kTagPadHi << 32) | (long long)j);
+                    t[i] = __longlong_as_double(key);
+                }
+                __syncthreads();
+                sdsort::block_merge_sort<K>(t, buf, np, xch, tid, nthr);
             }
-            __syncthreads();
-            sdsort::block_merge_sort<K>(t, buf, np, xch, tid, nthr);
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const int j = K * tid + i;
@@ -453,11 +628,16 @@ struct Sort2Args {
     double* xs;
     int32_t* xi;
     double *yx, *pq, *ybar;
+    // presorted runs of 64 * K tagged keys per cell from analog_tile_sort_kernel (np_runs slots per cell), or null
+    const double* runs = nullptr;
+    int np_runs = 0;
+    const int32_t* odd_flags = nullptr;
 };
 
 template <int K>
 int launch_sort2(sd_ctx* ctx, const Sort2Args& a) {
-    const int np = (int)((a.T + K - 1) / K * K);
+    int np = (int)((a.T + K - 1) / K * K);
+    if (a.runs != nullptr && a.np_runs > np) np = a.np_runs;
     const size_t lds = sizeof(double) * (size_t)(np + 1) + sizeof(int) * 1025;
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort2_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
@@ -475,12 +655,55 @@ int launch_sort2(sd_ctx* ctx, const Sort2Args& a) {
         worklist = work_count + 1;
         SD_HIP(hipMemsetAsync(work_count, 0, sizeof(int32_t), ctx->stream));
         SD_LAUNCH(ctx, "analog_sort2_kernel", (analog_sort2_kernel<K, true>), dim3(nb), dim3(1024), lds, a.X, a.x_stride, a.keys_only, a.y,
-                  a.T, a.C, a.xs, a.xi, a.yx, a.pq, a.ybar, worklist, work_count);
+                  a.T, a.C, a.xs, a.xi, a.yx, a.pq, a.ybar, worklist, work_count, tagged ? a.runs : nullptr, a.np_runs, a.odd_flags);
     }
     SD_LAUNCH(ctx, "analog_sort2_exact_kernel", (analog_sort2_kernel<K, false>), dim3(tagged ? std::min(nb, 256) : nb), dim3(1024), lds, a.X,
-              a.x_stride, a.keys_only, a.y, a.T, a.C, a.xs, a.xi, a.yx, a.pq, a.ybar, worklist, work_count);
+              a.x_stride, a.keys_only, a.y, a.T, a.C, a.xs, a.xi, a.yx, a.pq, a.ybar, worklist, work_count, (const double*)nullptr, 0,
+              (const int32_t*)nullptr);
     if (tagged) SD_HIP(hipStreamSynchronize(ctx->stream));  // the list goes back to the block cache
+#ifdef SD_DEV
+    if (tagged && sd_dev_env("SD_ANALOG_COUNT")) {
+        int32_t h = 0;
+        SD_HIP(hipMemcpy(&h, work_count, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "analog sort: %d of %lld cells took the exact kernel (presorted runs: %d)\n", h, (long long)a.C, a.runs != nullptr);
+    }
+#endif
     return SD_OK;
+}
+
+// The tile-shaped first stage of the F == 1 fit (analog_tile_sort_kernel): writes the cell-major copies Xc / yc, the mask / finite
+// status bits and the sorted runs.  Instantiated for the widths of the 40-year daily series and its neighbours.
+bool tile_sort_applies(int K, int64_t T, int64_t C, size_t lds_max) {
+    if (K != 13 && K != 15 && K != 17) return false;
+    const int64_t chunk = 64 * K, nchunks = (T + chunk - 1) / chunk;
+    if (T > kTagMask + 1 || C >= ((int64_t)1 << 31) || nchunks > 16) return false;
+    if (sizeof(double) * (size_t)(nchunks * chunk + 1) + sizeof(int) * 1025 > lds_max) return false;
+    return sd_dev_env("SD_ANALOG_NOTILE") == nullptr && sd_dev_env("SD_ANALOG_NOTAGS") == nullptr;
+}
+
+template <int K>
+int launch_tile_sort_k(sd_ctx* ctx, const double* X, const double* y, int64_t ld, int64_t T, int64_t C, double* Xc, double* yc, double* runs,
+                       int64_t runs_stride, int32_t* status, int32_t* odd_flags) {
+    constexpr int CHUNK = 64 * K;
+    constexpr int RS = CHUNK + 2 + ((4 - (CHUNK + 2) % 4) + 2) % 4;
+    const int nchunks = (int)((T + CHUNK - 1) / CHUNK);
+    const size_t lds = sizeof(double) * ((size_t)sdw::kW * RS + sdw::kHeadDoubles);
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_tile_sort_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t ntiles = (C + sdw::kW - 1) / sdw::kW, tx = (ntiles + 7) / 8;
+    const int64_t nblocks = 8 * tx * nchunks;
+    SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "analog fit: grid too large");
+    SD_LAUNCH(ctx, "analog_tile_sort_kernel", analog_tile_sort_kernel<K>, dim3((unsigned)nblocks), dim3(sdw::kThreads), lds, X, y, ld, T, C, nchunks,
+              Xc, yc, runs, runs_stride, status, odd_flags);
+    return SD_OK;
+}
+int launch_tile_sort(sd_ctx* ctx, int K, const double* X, const double* y, int64_t ld, int64_t T, int64_t C, double* Xc, double* yc, double* runs,
+                     int64_t runs_stride, int32_t* status, int32_t* odd_flags) {
+    switch (K) {
+        case 13: return launch_tile_sort_k<13>(ctx, X, y, ld, T, C, Xc, yc, runs, runs_stride, status, odd_flags);
+        case 15: return launch_tile_sort_k<15>(ctx, X, y, ld, T, C, Xc, yc, runs, runs_stride, status, odd_flags);
+        case 17: return launch_tile_sort_k<17>(ctx, X, y, ld, T, C, Xc, yc, runs, runs_stride, status, odd_flags);
+    }
+    return sd_set_error(SD_ERR_INVALID, "analog tile sort: width %d not instantiated", K);
 }
 
 int launch_sort2_width(sd_ctx* ctx, int K, const Sort2Args& a) {
@@ -2681,13 +2904,35 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
         SD_HIP(sd_pool_malloc(ctx, (void**)&st->y, sizeof(double) * (size_t)T * C));
         SD_HIP(sd_pool_malloc(ctx, (void**)&st->status, sizeof(int32_t) * C));
         SD_HIP(hipMemsetAsync(st->status, 0, sizeof(int32_t) * C, ctx->stream));
-        dim3 grid((unsigned)((C + 31) / 32), (unsigned)((T + 31) / 32));
-        for (int f = 0; f < F; ++f)
-            SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, grid, dim3(256), 0, X_dev, ld, T, F, f, C,
-                      st->X, st->status, 1);
-        SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, grid, dim3(256), 0, y_dev, ld, T, 1, 0, C,
-                  st->y, st->status, 0);
         const size_t lds = (size_t)T * (sizeof(double) + sizeof(uint16_t));
+        const bool f1_sorted = F == 1 && T <= 65535 && (lds <= ctx->lds_max || sort2_width(T, ctx->lds_max) != 0) &&
+                               sizeof(double) * (size_t)(T + 1) <= ctx->lds_max;
+        const int K2t = (f1_sorted && !sd_dev_env("SD_ANALOG_SORT1")) ? sort2_width(T, ctx->lds_max) : 0;
+        bool tiled = K2t != 0 && tile_sort_applies(K2t, T, C, ctx->lds_max);
+        sd_scratch runs_buf, odd_buf;
+        int np_runs = 0;
+        if (tiled) {
+            const int64_t chunk = 64 * K2t;
+            np_runs = (int)(((T + chunk - 1) / chunk) * chunk);
+            if (runs_buf.alloc(ctx, sizeof(double) * (size_t)np_runs * (size_t)C) != hipSuccess) {  // no room for the runs: the two-transpose path
+                (void)hipGetLastError();
+                tiled = false;
+            }
+        }
+        if (tiled) {
+            // F == 1: one tile-shaped kernel makes the cell-major copies and the sorted runs of 64 * K keys (csrc: analog_tile_sort_kernel)
+            SD_HIP(odd_buf.alloc(ctx, sizeof(int32_t) * (size_t)C));
+            SD_HIP(hipMemsetAsync(odd_buf.p, 0, sizeof(int32_t) * (size_t)C, ctx->stream));
+            SD_TRY(launch_tile_sort(ctx, K2t, X_dev, y_dev, ld, T, C, st->X, st->y, runs_buf.as<double>(), np_runs, st->status,
+                                    odd_buf.as<int32_t>()));
+        } else {
+            dim3 grid((unsigned)((C + 31) / 32), (unsigned)((T + 31) / 32));
+            for (int f = 0; f < F; ++f)
+                SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, grid, dim3(256), 0, X_dev, ld, T, F, f, C,
+                          st->X, st->status, 1);
+            SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, grid, dim3(256), 0, y_dev, ld, T, 1, 0, C,
+                      st->y, st->status, 0);
+        }
         if (F == 1 && T <= 65535 && (lds <= ctx->lds_max || sort2_width(T, ctx->lds_max) != 0) &&
             sizeof(double) * (size_t)(T + 1) <= ctx->lds_max) {
             // sorted view for the 1-D fast path: values, original indices, and y in the same order
@@ -2701,7 +2946,12 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
             if (K2 != 0) {
                 // (no prefix sums yet: the BASELINE path -- analog_f1_mean3_kernel -- builds its own on chip; the kernels
                 // that read them from memory get them from ensure_prefix_sums on their first call)
-                const Sort2Args a{st->X, T, 0, st->y, T, C, st->xs, st->xi, st->yx, nullptr, st->ybar};
+                Sort2Args a{st->X, T, 0, st->y, T, C, st->xs, st->xi, st->yx, nullptr, st->ybar};
+                if (tiled && K2 == K2t) {
+                    a.runs = runs_buf.as<double>();
+                    a.np_runs = np_runs;
+                    a.odd_flags = odd_buf.as<int32_t>();
+                }
                 SD_TRY(launch_sort2_width(ctx, K2, a));
             } else {
                 SD_HIP(sd_pool_malloc(ctx, (void**)&st->pq, sizeof(double) * 2 * (size_t)(T + 1) * C));

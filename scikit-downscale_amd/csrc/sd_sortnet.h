@@ -108,18 +108,13 @@ __device__ __forceinline__ void group_sync(bool within_wave) {
     }
 }
 
+// the merge rounds from round `first` on: buf holds sorted runs of K << first slots (first = 0: the threads' own runs; first = 6:
+// runs of 64 * K produced elsewhere, e.g. by the wave sorts of analog_tile_sort_kernel)
 template <int K>
-__device__ __forceinline__ void block_merge_sort(double (&v)[K], double* buf, int np, int* xch, int tid, int nthr) {
+__device__ __forceinline__ void block_merge_rounds(double* buf, int np, int* xch, int tid, int nthr, int first) {
     constexpr MergeNet<K> net{};
-    sort_registers<K>(v);
-    if (K * tid < np) {
-        double* dst = buf + K * tid;
-#pragma unroll
-        for (int i = 0; i < K; ++i) dst[i] = v[i];
-    }
-    group_sync(true);  // round 0 reads only the two runs of a lane pair
 #pragma unroll 1
-    for (int r = 0; (K << r) < np; ++r) {
+    for (int r = first; (K << r) < np; ++r) {
         const int L = K << r;
         const bool in_wave = (2 << r) <= 64;      // this round's merge groups do not cross a wave
         const bool next_in_wave = (4 << r) <= 64;  // ... nor do the next round's
@@ -175,6 +170,18 @@ __device__ __forceinline__ void block_merge_sort(double (&v)[K], double* buf, in
         group_sync(next_in_wave);
     }
     __syncthreads();
+}
+
+template <int K>
+__device__ __forceinline__ void block_merge_sort(double (&v)[K], double* buf, int np, int* xch, int tid, int nthr) {
+    sort_registers<K>(v);
+    if (K * tid < np) {
+        double* dst = buf + K * tid;
+#pragma unroll
+        for (int i = 0; i < K; ++i) dst[i] = v[i];
+    }
+    group_sync(true);  // round 0 reads only the two runs of a lane pair
+    block_merge_rounds<K>(buf, np, xch, tid, nthr, 0);
 }
 
 }  // namespace sdsort

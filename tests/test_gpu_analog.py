@@ -418,3 +418,38 @@ def test_analog_regression_thresh_surface():
         AnalogRegression(n_analogs=10, thresh=1e9).fit(X[:, :, 0], y[:, 0]).predict(Xq[:5, :, 0])
     with pytest.raises(NotImplementedError, match="metric"):
         AnalogRegression(kdtree_kwargs={"metric": "manhattan"}).fit(X[:, :, 0], y[:, 0])
+
+
+@pytest.mark.parametrize("T", [14600, 16384, 13400])
+def test_tile_shaped_fit_stage_is_bit_identical(ctx, dev_ctx, monkeypatch, T):
+    """F = 1 fit of a long series: the tile-shaped first stage (analog_tile_sort_kernel: cell-major copies + sorted runs of 64 K
+    tagged keys, then only the merge rounds 6 .. in analog_sort2_kernel) leaves the same fitted state as the two staging
+    transposes + the full per-cell sort (SD_ANALOG_NOTILE of the development library): predictions, statistics, neighbour
+    indices and distances of every kind agree bit for bit -- ragged last tile, a masked cell, a cell with a non-finite sample,
+    cells with tied / signed-zero values (exact two-sort kernel) included -- and match the oracle's brute force."""
+    rng = np.random.default_rng(T)
+    C, Tq, k = 19, 700, 30
+    X = rng.standard_normal((T, 1, C))
+    y = 2.0 * X[:, 0, :] + rng.standard_normal((T, C))
+    X[0, 0, 4] = np.nan                      # masked cell (core.py:35-37)
+    X[T // 2, 0, 9] = np.inf                 # a non-finite sample: the cell is reported, its outputs are NaN
+    X[:, 0, 12] = np.round(X[:, 0, 12] * 8) / 8   # ties (and both signed zeros): the exact two-sort kernel
+    X[5, 0, 12], X[6, 0, 12] = 0.0, -0.0
+    Xq = 1.1 * rng.standard_normal((Tq, 1, C))
+    monkeypatch.delenv("SD_ANALOG_NOTILE", raising=False)
+    st = ctx.analog_fit(X, y)
+    monkeypatch.setenv("SD_ANALOG_NOTILE", "1")
+    st0 = dev_ctx.analog_fit(X, y)
+    monkeypatch.delenv("SD_ANALOG_NOTILE")
+    for kind in (0, 2, 3):  # best, weight, mean
+        a, sa = ctx.analog_predict(st, Xq, k, kind)
+        b, sb = dev_ctx.analog_predict(st0, Xq, k, kind)
+        assert sa.tolist() == sb.tolist() and sa[4] == 1 and sa[9] == 2
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]), kind
+    a, sa, ia, da = ctx.analog_predict(st, Xq, k, 3, want_neighbors=True)
+    b, sb, ib, db = dev_ctx.analog_predict(st0, Xq, k, 3, want_neighbors=True)
+    live = [c for c in range(C) if c not in (4, 9)]
+    assert np.array_equal(ia[:, :, live], ib[:, :, live]) and np.array_equal(da[:, :, live], db[:, :, live])
+    for c in (0, 12, 18):
+        d, i = ao.knn(X[:, :, c], Xq[:, :, c], k)
+        assert np.array_equal(ia[:, :, c], i) and np.array_equal(da[:, :, c], d)
