@@ -494,12 +494,11 @@ def main():
         gather = {"value_with_gather": None, "error": f"no RCCL communicator: {comm_error}"}
 
     # ---- N > 1: the other sink -- every rank copies its own shard to host memory over its own PCIe link (N links in
-    # parallel instead of N - 1 xGMI links into one GPU); cell chunks, a copy thread drains chunk i while chunk i + 1 computes ----
+    # parallel instead of N - 1 xGMI links into one GPU); cell chunks through two alternating host buffers ----
     if world > 1 and wl["kind"] != "analog" and args.gather_steps > 0:
         host = None
         try:
             import ctypes as Cc
-            import threading
 
             from skdownscale_amd.shard import cell_partition
 
@@ -514,14 +513,9 @@ def main():
                 ctx.lib.sd_memcpy_d2h(ctx.handle, hostbuf[i % 2].ctypes.data_as(Cc.c_void_p), dev[i].vptr, n)
 
             def host_step():
-                th = None
                 for i, (s, e) in enumerate(bounds):
                     step((s, e), dev[i])  # (returns when the chunk's kernels are done: the status comes back with it)
-                    if th is not None:
-                        th.join()
-                    th = threading.Thread(target=drain, args=(i,))
-                    th.start()
-                th.join()
+                    drain(i)              # calls on one context are serialised: no copy thread (the copy is 10 x the compute anyway)
 
             host_step()
             barrier()
@@ -532,7 +526,7 @@ def main():
             hdt = rdv.allreduce_max((time.perf_counter() - h0) / args.gather_steps)
             host = {"value_with_host_gather": C * world / hdt, "ms_per_step_with_host_gather": hdt * 1e3,
                     "host_gather": f"every rank's [T, {C}] shard to its process's host memory over its own PCIe link, {nchunk} cell chunks, "
-                                   "the copy of a chunk overlapping the next chunk's kernels",
+                                   "compute and copy of a chunk back to back (one context: serialised calls)",
                     "host_GB_per_step_per_rank": 8.0 * T * C / 1e9}
         except Exception as e:  # noqa: BLE001
             host = {"value_with_host_gather": None, "host_gather_error": f"{type(e).__name__}: {e}"}
