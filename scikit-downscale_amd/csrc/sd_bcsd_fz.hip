@@ -130,6 +130,9 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
     const int np = (m + K - 1) / K * K;
     unsigned pos2[NR];  // two 16-bit tags (8 * time position) per register
     bool redo = false;
+    // the y_obs tile: K <= 19 requests it right behind the sort of u (its latency then covers the tag bookkeeping and the
+    // workgroup's vote: -2.4 % on those launches); at K = 21 the 44 registers in flight there cost more in spills than they hide
+    TileRegs<NR> yt;
     {
         SD_LANE();
         double* const slab = slab0 + lane;
@@ -156,6 +159,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
         }
         wave_fence();
         sort_segment<K, true>(u, row, m, lane, !(abl & 1));  // u[] <- the sorted values of the positions this lane owns
+        if (K <= 19 && !p->from_state && n > 0 && !(abl & 32)) tile_issue<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, yt);
         // ---- ranks off the tags; near-tie detection ----------------------------------------------------
         const bool owner = K * lane < np;  // this lane owns sorted positions K*lane .. K*lane + K - 1
         long long key[K];  // upper 48 bits
@@ -190,7 +194,8 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fz_kernel(const Params) {
     if (!p->from_state) {
         if (n > 0) {
             SD_LANE();
-            if (!(abl & 32)) load_tile<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, tile, RS, p->status_fit);
+            if (K > 19 && !(abl & 32)) tile_issue<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, yt);
+            if (!(abl & 32)) tile_commit<NR>(yt, n, c0, p->C, tile, RS, p->status_fit);
             __syncthreads();
             double v[K];
             load_blocked<K>(row, n, lane, 0.0, v);
