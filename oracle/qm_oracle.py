@@ -192,3 +192,29 @@ def cunnane_inverse(cdf, P, extrapolate="both", n_endpoints=10):
         s = slice(-n_endpoints, None)
         out[upper] = ols_predict(pp[s], vals[s], P[upper])
     return out
+
+
+# ---- TrendAwareQuantileMappingRegressor (quantile.py:639-716) ------------------------------------------
+
+def _line(v):
+    """least-squares line of a series over its sample index (trend.py:49-52): slope, intercept"""
+    n = len(v)
+    t = np.arange(n, dtype=np.float64)
+    tb, vb = t.mean(), v.mean()
+    slope = float(((t - tb) * (v - vb)).sum() / ((t - tb) ** 2).sum()) if n > 1 else 0.0
+    return slope, float(vb - slope * tb)
+
+
+def trend_aware_predict(model, X, y, Xp, extrapolate=None, n_endpoints=10, kind="difference"):
+    """One cell: fit on (X, y), predict Xp.  X and y lose their lines (quantile.py:676-680), the regressor maps the detrended
+    series (682, 700-703), the centred line of Xp and the change of the mean come back (707-715)."""
+    X, y, Xp = (np.asarray(a, dtype=np.float64).reshape(-1) for a in (X, y, Xp))
+    sx, ix = _line(X)
+    sy, iy = _line(y)
+    st = qm_fit(X - (np.arange(len(X)) * sx + ix), y - (np.arange(len(y)) * sy + iy), extrapolate, n_endpoints)
+    sp, ip = _line(Xp)
+    line = np.arange(len(Xp)) * sp + ip
+    xd = Xp - line
+    y_hat = qmr_predict(st, xd, extrapolate, n_endpoints) if model == "qmr" else ecm_predict(st, xd, kind, extrapolate, n_endpoints)
+    delta = (Xp.mean() - X.mean()) + y.mean()
+    return y_hat + (line - line.mean()) + delta
