@@ -463,6 +463,7 @@ def main():
     # over xGMI overlaps the next chunk's kernels) ----
     gather = None
     if comm is not None and wl["kind"] != "analog" and args.gather_steps > 0:
+        chunk_out, root_bufs = [], []
         try:
             from skdownscale_amd.shard import cell_partition
 
@@ -490,6 +491,14 @@ def main():
                       "gathered_GB_per_step": 8.0 * T * C * (world - 1) / 1e9}
         except Exception as e:  # noqa: BLE001  (never lose the throughput line over the second measurement)
             gather = {"value_with_gather": None, "error": str(e)}
+        finally:  # rank 0 holds world x the shard here (117 GB at N = 8): give it back before the next leg allocates
+            try:
+                ctx.synchronize()
+                for b in root_bufs + chunk_out:
+                    if b is not None:
+                        b.free()
+            except Exception:  # noqa: BLE001
+                pass
     elif world > 1 and comm is None:
         gather = {"value_with_gather": None, "error": f"no RCCL communicator: {comm_error}"}
 
