@@ -301,7 +301,7 @@ class Context:
         """X, y: numpy [T,C] (host path) or DeviceArray [T,C] (resident path); X may be None for PR.  ``detrend``:
         qm_kwargs={'detrend': True} (quantile.py:95-98,128-145)."""
         return_anoms = self._bcsd_options(return_anoms, detrend)
-        if self._is_f32_host(y) and (X is None or self._is_f32_host(X)) and y.ndim == 2 and y.size % 4 == 0:
+        if self._is_f32_host(y) and (X is None or self._is_f32_host(X)) and y.ndim == 2 and y.size > 0:
             y = self.widen_to_device(y)  # float32 grids: 4 bytes per sample over PCIe, widened in HBM
             X = None if X is None else self.widen_to_device(X)
         y = self._field2("y", y)
@@ -379,11 +379,17 @@ class Context:
         """``out_dtype=np.float32`` with a float32 host ``Xp``: the field goes in and the result comes back as float32
         (widened / narrowed on the device); everything else as before (float64 results)."""
         info = state.info()
-        if self._is_f32_host(Xp) and Xp.ndim == 2 and Xp.size % 4 == 0 and out is None:
+        want32 = out_dtype is not None and np.dtype(out_dtype) == np.float32
+        if out_dtype is not None and not want32 and np.dtype(out_dtype) != np.float64:
+            raise ValueError("bcsd_predict: out_dtype must be float64 or float32")
+        if self._is_f32_host(Xp) and Xp.ndim == 2 and Xp.size > 0 and out is None:
             d_out, status = self.bcsd_predict(state, self.widen_to_device(Xp), gid_p)
-            if out_dtype is not None and np.dtype(out_dtype) == np.float32:
-                return self.narrow_to_host(d_out), status
-            return d_out.to_host(), status
+            return (self.narrow_to_host(d_out) if want32 else d_out.to_host()), status
+        if want32:  # (float64 or resident input: the result is narrowed where it is)
+            if out is not None:
+                raise ValueError("bcsd_predict: out_dtype=float32 does not combine with a float64 `out` buffer")
+            res, status = self.bcsd_predict(state, Xp, gid_p)
+            return (self.narrow_to_host(res) if isinstance(res, DeviceArray) else res.astype(np.float32)), status
         Xp = self._field2("X", Xp, None, info["C"])
         gid_p = self._group_ids("group_id", gid_p, Xp.shape[0], info["G"])
         Cc = info["C"]

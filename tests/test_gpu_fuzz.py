@@ -14,3 +14,15 @@ def test_random_configurations(seed):
     import fuzz_gpu
 
     fuzz_gpu.main(45, seed)
+
+
+def test_random_configurations_of_the_round3_paths():
+    """tools/dev/fuzz_r3.py: tile-shaped analog fit stage vs the two-transpose path (bit for bit) and the oracle, detrended
+    mapping of 2 113 .. 19 456 sample segments, TrendAwareQuantileMappingRegressor, float32 transport."""
+    import warnings
+
+    import fuzz_r3
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)  # (the oracle's squared distances overflow for the 1e154-scaled cells)
+        assert fuzz_r3.main(120.0, 7000, None, 80) == 0
