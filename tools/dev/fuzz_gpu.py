@@ -199,7 +199,17 @@ def main(n_cases=40, seed=0):
             except ValueError:
                 print(f"case {it}: analogreg_thresh one-class query (skipped)", flush=True)
                 continue
-            assert_close(out[:, [0, 2]], exp[:, [0, 2]], what=f"case {it} analogreg thresh F={F} T={T} k={k}")
+            # a query with <= F + 1 exceeding analogs is under-determined: the reference's lstsq cut-off (eps * max(n, F) * s_max)
+            # sits at the rounding level of the centred rows, its answer flips between the minimum-norm solution (what the
+            # engine returns) and noise (seed 131: 2 exceeding analogs, second singular value 7.1e-17 vs cut-off 3.1e-17) -- unpinned
+            pinned = np.ones((Tq, C), dtype=bool)
+            for c in range(C):
+                _, ii = ao.knn(X[:, :, c], Xq[:, :, c], k)
+                pinned[:, c] = (y[ii, c] > thresh).sum(axis=1) >= F + 2
+            got, want = out[:, [0, 2]], exp[:, [0, 2]]
+            sel = np.broadcast_to(pinned[:, None, :], got.shape)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), f"case {it} analogreg thresh NaN pattern"
+            assert_close(got[sel], want[sel], scale=float(np.nanstd(want)), what=f"case {it} analogreg thresh F={F} T={T} k={k}")
             assert np.abs(out[:, 1] - exp[:, 1]).max() < 1e-6, f"case {it} analogreg thresh probability F={F} T={T} k={k}"
         elif what == "qm_modes":
             # QuantileMappingReressor / EquidistantCdfMatcher with synthetic end points, samples inside the fitted range
