@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""Randomised sweep of the grid driver (development aid, run on the GPU box): PointWiseDownscaler around a random estimator on a
+random grid -- 1 or 2 spatial dims, with / without a feature dim, time leading or not, float64 / float32, random masked cells,
+whole or in random spatial blocks (LazyGridArray results) -- against the oracles' per-cell loops (core.py:69-143 restated:
+masked cells NaN, output dims (time, [variable,] *spatial)).
+
+usage: fuzz_pointwise.py [seconds] [first seed] [max cases]
+"""
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+import pandas as pd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "scikit-downscale_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import analog_oracle as ao  # noqa: E402
+import bcsd_oracle as bo  # noqa: E402
+from _cases import assert_close  # noqa: E402
+from skdownscale_amd import (AnalogRegression, BcsdPrecipitation, BcsdTemperature, GridArray, PointWiseDownscaler,  # noqa: E402
+                             PureAnalog)
+
+KINDS = {"best_analog": ao.KIND_BEST, "mean_analogs": ao.KIND_MEAN, "weight_analogs": ao.KIND_WEIGHT}
+
+
+def one_case(rng):
+    what = str(rng.choice(["tas", "pr", "analog", "analogreg"]))
+    nsp = int(rng.integers(1, 3))
+    sp_shape = tuple(int(rng.integers(1, 6)) for _ in range(nsp))
+    sp_dims = ("y", "x")[:nsp] if nsp == 2 else ("point",)
+    C = int(np.prod(sp_shape))
+    bcsd = what in ("tas", "pr")
+    T = int(rng.integers(400, 2500)) if bcsd else int(rng.integers(60, 1200))
+    Tp = int(rng.integers(40, 2500)) if bcsd else int(rng.integers(1, 300))
+    F = 1 if bcsd else int(rng.choice([1, 1, 2, 3]))
+    with_feature = bool(F > 1 or rng.random() < 0.5)
+    f32 = bool(bcsd and rng.random() < 0.3)
+    index = pd.date_range(pd.Timestamp("1975-01-01") + pd.Timedelta(days=int(rng.integers(0, 4000))), periods=T)
+    index_p = pd.date_range(pd.Timestamp("1985-01-01") + pd.Timedelta(days=int(rng.integers(0, 4000))), periods=Tp)
+    X = 10 + 3 * rng.standard_normal((T, F, C))
+    y = 0.5 * X.sum(axis=1) + 2 * rng.standard_normal((T, C)) + 20
+    Xp = 10.5 + 3.2 * rng.standard_normal((Tp, F, C))
+    if what == "pr":
+        X, y, Xp = np.abs(X - 10) * (rng.random(X.shape) > 0.4), np.abs(y - 25) + 0.1, np.abs(Xp - 10) * (rng.random(Xp.shape) > 0.4)
+    if f32:
+        X, y, Xp = (a.astype(np.float32) for a in (X, y, Xp))
+    masked = rng.random(C) < (0.25 if C > 1 else 0.0)
+    if masked.all():
+        masked[int(rng.integers(0, C))] = False
+    for a in (X, Xp):
+        a[:, :, masked] = np.nan
+    y[:, masked] = np.nan
+    lead_time = bool(rng.random() < 0.8)
+
+    def grid(a, idx, feature):
+        """a: [T, F, C] or [T, C] -> GridArray with the case's dims"""
+        a = a.reshape(a.shape[:-1] + sp_shape)
+        dims = ("time",) + (("variable",) if feature else ()) + sp_dims
+        coords = {"time": idx}
+        for d, n in zip(sp_dims, sp_shape):
+            coords[d] = np.arange(n) * 0.5
+        g = GridArray(a, dims, coords)
+        if not lead_time:  # a spatial dim first: the driver moves time to the front (core.py:427-440)
+            order = (sp_dims[0], "time") + tuple(d for d in dims if d not in (sp_dims[0], "time"))
+            g = g.transpose(*order)
+        return g
+
+    Xg = grid(X if with_feature else X[:, 0], index, with_feature)
+    yg = grid(y, index, False)
+    Xpg = grid(Xp if with_feature else Xp[:, 0], index_p, with_feature)
+    blocks = None
+    if rng.random() < 0.4 and C > 1:
+        blocks = {d: int(rng.integers(1, n + 1)) for d, n in zip(sp_dims, sp_shape)}
+        Xg, yg, Xpg = Xg.chunk(blocks), yg.chunk(blocks), Xpg.chunk(blocks)
+    live = np.flatnonzero(~masked)
+    X64, y64, Xp64 = (np.asarray(a, dtype=np.float64) for a in (X, y, Xp))
+    if bcsd:
+        ra = bool(rng.integers(0, 2))
+        model = (BcsdTemperature if what == "tas" else BcsdPrecipitation)(return_anoms=ra)
+        gid, gid_p = (np.asarray(index.month) - 1).astype(np.int32), (np.asarray(index_p.month) - 1).astype(np.int32)
+        e, est = bo.pointwise_fit_predict(bo.TAS if what == "tas" else bo.PR, X64[:, 0, live], y64[:, live], Xp64[:, 0, live], gid, gid_p,
+                                          G=12, return_anoms=ra)
+        assert (np.asarray(est) == 0).all()
+        exp = np.full((Tp, C), np.nan)
+        exp[:, live] = e
+        desc = f"{what} return_anoms={ra}"
+    else:
+        k = int(rng.integers(1, min(T, 40)))
+        thresh = None if rng.random() < 0.6 else float(np.median(y64[:, live]))
+        if what == "analog":
+            kind = str(rng.choice(list(KINDS)))
+            model = PureAnalog(n_analogs=k, kind=kind, thresh=thresh)
+            exp = np.full((Tp, 3, C), np.nan)
+            for c in live:
+                exp[:, :, c] = ao.pure_analog_predict(X64[:, :, c], y64[:, c], Xp64[:, :, c], k, KINDS[kind], thresh)[0]
+            desc = f"PureAnalog {kind} k={k} thresh={thresh}"
+        else:
+            k = max(k, F + 2)  # (k <= F + 1: under-determined, unpinned in the reference)
+            model = AnalogRegression(n_analogs=k)
+            exp = np.full((Tp, 3, C), np.nan)
+            for c in live:
+                exp[:, :, c] = ao.analog_regression_predict(X64[:, :, c], y64[:, c], Xp64[:, :, c], k)[0]
+            desc = f"AnalogRegression k={k}"
+    what_s = (f"{desc} T={T} Tp={Tp} F={F} feature_dim={with_feature} spatial={dict(zip(sp_dims, sp_shape))} f32={f32} "
+              f"masked={int(masked.sum())} time_first={lead_time} blocks={blocks}")
+    pw = PointWiseDownscaler(model)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pw.fit(Xg, yg)
+        res = pw.predict(Xpg)
+    want_dims = ("time",) + (() if bcsd else ("variable",)) + sp_dims
+    assert tuple(res.dims) == want_dims, (what_s, res.dims)
+    vals = np.asarray(res.values)
+    assert vals.shape == ((Tp,) + (() if bcsd else (3,)) + sp_shape), (what_s, vals.shape)
+    assert vals.dtype == (np.float32 if f32 else np.float64), (what_s, vals.dtype)
+    got = vals.reshape(exp.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(exp)), what_s + ": NaN pattern"
+    if f32:
+        np.testing.assert_allclose(got, exp.astype(np.float32), rtol=3e-6, atol=3e-6 * float(np.nanstd(exp)), err_msg=what_s)
+    else:
+        assert_close(got, exp, scale=float(np.nanstd(exp)), what=what_s)
+    return what_s
+
+
+def main(seconds=120.0, seed0=100, max_cases=None):
+    t0, n, seed = time.time(), 0, seed0
+    while time.time() - t0 < seconds and (max_cases is None or n < max_cases):
+        try:
+            what = one_case(np.random.default_rng(seed))
+        except AssertionError as e:
+            print(f"FAILED seed={seed}: {str(e)[:3000]}", flush=True)
+            return 1
+        print(f"ok seed={seed} {what}", flush=True)
+        n += 1
+        seed += 1
+    print(f"fuzz_pointwise: {n} cases in {time.time() - t0:.0f} s, seeds {seed0}..{seed - 1}: all ok", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 100,
+                  int(sys.argv[3]) if len(sys.argv) > 3 else None))
