@@ -18,15 +18,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [os.path.join(ROOT, "scikit-downscale_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import analog_oracle as ao  # noqa: E402
 import bcsd_oracle as bo  # noqa: E402
+import qm_oracle as qo  # noqa: E402
 from _cases import assert_close  # noqa: E402
-from skdownscale_amd import (AnalogRegression, BcsdPrecipitation, BcsdTemperature, GridArray, PointWiseDownscaler,  # noqa: E402
-                             PureAnalog)
+from skdownscale_amd import (AnalogRegression, BcsdPrecipitation, BcsdTemperature, EquidistantCdfMatcher, GridArray,  # noqa: E402
+                             PointWiseDownscaler, PureAnalog, QuantileMappingReressor)
 
 KINDS = {"best_analog": ao.KIND_BEST, "mean_analogs": ao.KIND_MEAN, "weight_analogs": ao.KIND_WEIGHT}
 
 
-def one_case(rng):
-    what = str(rng.choice(["tas", "pr", "analog", "analogreg"]))
+def one_case(rng, kinds=("tas", "pr", "analog", "analogreg", "qmr", "ecm")):
+    what = str(rng.choice(kinds))
     nsp = int(rng.integers(1, 3))
     sp_shape = tuple(int(rng.integers(1, 6)) for _ in range(nsp))
     sp_dims = ("y", "x")[:nsp] if nsp == 2 else ("point",)
@@ -34,7 +35,8 @@ def one_case(rng):
     bcsd = what in ("tas", "pr")
     T = int(rng.integers(400, 2500)) if bcsd else int(rng.integers(60, 1200))
     Tp = int(rng.integers(40, 2500)) if bcsd else int(rng.integers(1, 300))
-    F = 1 if bcsd else int(rng.choice([1, 1, 2, 3]))
+    qm = what in ("qmr", "ecm")
+    F = 1 if bcsd or qm else int(rng.choice([1, 1, 2, 3]))
     with_feature = bool(F > 1 or rng.random() < 0.5)
     f32 = bool(bcsd and rng.random() < 0.3)
     index = pd.date_range(pd.Timestamp("1975-01-01") + pd.Timedelta(days=int(rng.integers(0, 4000))), periods=T)
@@ -86,6 +88,11 @@ def one_case(rng):
         exp = np.full((Tp, C), np.nan)
         exp[:, live] = e
         desc = f"{what} return_anoms={ra}"
+    elif qm:
+        ex = [None, "1to1"][int(rng.integers(0, 2))]  # (min / max / both: +-1e20 node noise beyond the fitted range)
+        model = QuantileMappingReressor(extrapolate=ex) if what == "qmr" else EquidistantCdfMatcher(extrapolate=ex)
+        exp = qo.pointwise_qm(what, X64[:, 0], y64, Xp64[:, 0], ex)
+        desc = f"{what} extrapolate={ex}"
     else:
         k = int(rng.integers(1, min(T, 40)))
         thresh = None if rng.random() < 0.6 else float(np.median(y64[:, live]))
@@ -110,10 +117,11 @@ def one_case(rng):
         warnings.simplefilter("ignore")
         pw.fit(Xg, yg)
         res = pw.predict(Xpg)
-    want_dims = ("time",) + (() if bcsd else ("variable",)) + sp_dims
+    one = bcsd or qm
+    want_dims = ("time",) + (() if one else ("variable",)) + sp_dims
     assert tuple(res.dims) == want_dims, (what_s, res.dims)
     vals = np.asarray(res.values)
-    assert vals.shape == ((Tp,) + (() if bcsd else (3,)) + sp_shape), (what_s, vals.shape)
+    assert vals.shape == ((Tp,) + (() if one else (3,)) + sp_shape), (what_s, vals.shape)
     assert vals.dtype == (np.float32 if f32 else np.float64), (what_s, vals.dtype)
     got = vals.reshape(exp.shape)
     assert np.array_equal(np.isnan(got), np.isnan(exp)), what_s + ": NaN pattern"
