@@ -1,0 +1,150 @@
+#!/usr/bin/env python
+"""Randomised sweep of the oracles against the LIVE reference (build container only: needs /root/reference; CPU).
+
+The GPU sweeps (fuzz_gpu.py, fuzz_r3.py, fuzz_pointwise.py) hold the engine to the oracles; this one holds the oracles to the
+reference on fresh random inputs -- random calendars, lengths, options -- beyond the fixed cases of
+tests/test_oracle_vs_reference.py.
+
+usage: fuzz_oracle_vs_reference.py [seconds] [first seed]
+"""
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+import pandas as pd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "scikit-downscale_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import analog_oracle as ao  # noqa: E402
+import bcsd_oracle as bo  # noqa: E402
+import qm_oracle as qo  # noqa: E402
+import ref_shim  # noqa: E402
+from _cases import assert_close  # noqa: E402
+
+KINDS = {"best_analog": ao.KIND_BEST, "weight_analogs": ao.KIND_WEIGHT, "mean_analogs": ao.KIND_MEAN}
+
+
+def frame(a, index):
+    return pd.DataFrame(np.asarray(a).reshape(len(index), -1), index=index)
+
+
+def start(rng, lo="1960-01-01", span=15000):
+    return pd.Timestamp(lo) + pd.Timedelta(days=int(rng.integers(0, span)))
+
+
+def case_bcsd(ref, rng):
+    kind = int(rng.integers(0, 2))
+    T, Tp = int(rng.integers(400, 3200)), int(rng.integers(60, 3600))
+    index, index_p = pd.date_range(start(rng), periods=T), pd.date_range(start(rng), periods=Tp)
+    ra = bool(rng.integers(0, 2))
+    detrend = bool(rng.random() < 0.3)
+    # a detrended group of 3 samples has residuals (c, -2c, c): samples 0 and 2 tie in exact arithmetic and the reference's own
+    # ranks are decided by the rounding of its lstsq line (seed 295: 3 June days; outputs 2.86 / 14.28 vs 8.78 / 8.35) -- unpinned
+    if detrend and min(np.bincount(np.asarray(index_p.month))[np.unique(index_p.month)].min(), np.bincount(np.asarray(index.month))[np.unique(index.month)].min()) < 4:
+        detrend = False
+    if kind == 0:
+        X, y, Xp = (12 + 7 * rng.standard_normal(n) + 8 * np.sin(np.arange(n) * 2 * np.pi / 365.25) for n in (T, T, Tp))
+        cls = ref.BcsdTemperature
+    else:
+        X, y, Xp = (rng.gamma(0.8, 4.0, n) * (rng.random(n) > rng.uniform(0.1, 0.7)) for n in (T, T, Tp))
+        y = y + 0.05
+        cls = ref.BcsdPrecipitation
+    if detrend:
+        X, y, Xp = (a + float(rng.normal(0, 1e-3)) * np.arange(len(a)) for a in (X, y, Xp))
+        if kind == 1:
+            X, y, Xp = np.abs(X), np.abs(y) + 0.05, np.abs(Xp)
+    kw = dict(return_anoms=ra)
+    if detrend:
+        kw["qm_kwargs"] = {"detrend": True}
+    exp = cls(**kw).fit(frame(X, index), frame(y, index)).predict(frame(Xp, index_p)).values[:, 0]
+    out, status = bo.pointwise_fit_predict(kind, X[:, None], y[:, None], Xp[:, None], bo.month_group_id(index), bo.month_group_id(index_p),
+                                           return_anoms=ra, detrend=detrend)
+    what = f"bcsd kind={kind} T={T} Tp={Tp} return_anoms={ra} detrend={detrend} {index[0].date()} {index_p[0].date()}"
+    assert status[0] == 0, what
+    assert_close(out[:, 0], exp, what=what)
+    return what
+
+
+def case_analog(ref, rng):
+    F = int(rng.integers(1, 5))
+    T, Tq = int(rng.integers(50, 1500)), int(rng.integers(1, 80))
+    k = int(rng.integers(1, min(T, 50)))
+    X, Xq = rng.standard_normal((T, F)) * rng.choice([1.0, 10.0, 0.1], F), rng.standard_normal((Tq, F))
+    y = X.sum(axis=1) + 0.5 * rng.standard_normal(T)
+    kind = str(rng.choice(list(KINDS)))
+    thresh = None if rng.random() < 0.5 else float(np.quantile(y, rng.uniform(0.1, 0.6)))
+    if kind == "weight_analogs" and thresh is None and Tq == 1:
+        # the reference squeezes the [1, k] analog array and fails (gard.py:327: AxisError) -- the engine answers; not reproduced
+        Xq, Tq = np.vstack([Xq, Xq * 0.5]), 2
+    exp = ref.PureAnalog(n_analogs=k, kind=kind, thresh=thresh).fit(X, y).predict(Xq)
+    out, _, _ = ao.pure_analog_predict(X, y, Xq, k, KINDS[kind], thresh)
+    what = f"PureAnalog {kind} F={F} T={T} Tq={Tq} k={k} thresh={thresh}"
+    assert_close(out, exp, what=what)
+    if k >= F + 2:
+        exp = ref.AnalogRegression(n_analogs=k).fit(X, y).predict(Xq)
+        assert_close(ao.analog_regression_predict(X, y, Xq, k)[0], exp, what="AnalogRegression " + what)
+    return what
+
+
+def case_qm(ref, rng):
+    T, Tp = int(rng.integers(21, 2500)), int(rng.integers(1, 2500))
+    ex = [None, "1to1", "min", "max", "both"][int(rng.integers(0, 5))]
+    X, y = 10 + 3 * rng.standard_normal(T), 12 + 4 * rng.standard_normal(T)
+    inside = ex in ("min", "max", "both") or rng.random() < 0.5  # (beyond the range those modes carry the +-1e20 node noise: DESIGN 2)
+    Xp = X.min() + (X.max() - X.min()) * rng.random(Tp) if inside else 10.3 + 3.5 * rng.standard_normal(Tp)
+    Q = ref.quantile
+    what = f"qm T={T} Tp={Tp} extrapolate={ex} inside={inside}"
+    exp = Q.QuantileMappingReressor(extrapolate=ex).fit(X.reshape(-1, 1), y).predict(Xp.reshape(-1, 1))
+    assert_close(qo.qmr_predict(qo.qm_fit(X, y, ex), Xp, ex), exp, what="QMR " + what)
+    for kind in ("difference", "ratio"):
+        exp = Q.EquidistantCdfMatcher(kind=kind, extrapolate=ex).fit(X.reshape(-1, 1), y).predict(Xp.reshape(-1, 1))
+        assert_close(qo.ecm_predict(qo.qm_fit(X, y, ex), Xp, kind, ex), exp, what=f"ECM {kind} " + what)
+    return what
+
+
+def case_trend(ref, rng):
+    T, Tp = int(rng.integers(60, 2500)), int(rng.integers(30, 2500))
+    model = str(rng.choice(["qmr", "ecm"]))
+    index, index_p = pd.date_range(start(rng), periods=T), pd.date_range(start(rng), periods=Tp)
+    X = 10 + 3 * rng.standard_normal(T) + float(rng.normal(0, 3e-3)) * np.arange(T)
+    y = 8 + 4 * rng.standard_normal(T) + float(rng.normal(0, 3e-3)) * np.arange(T)
+    Xp = 11 + 3 * rng.standard_normal(Tp) + float(rng.normal(0, 3e-3)) * np.arange(Tp)
+    inner = ref.quantile.QuantileMappingReressor() if model == "qmr" else ref.quantile.EquidistantCdfMatcher()
+    m = ref.quantile.TrendAwareQuantileMappingRegressor(inner).fit(frame(X, index), frame(y, index))
+    exp = np.asarray(m.predict(frame(Xp, index_p))).reshape(-1)
+    what = f"trend-aware {model} T={T} Tp={Tp}"
+    assert_close(qo.trend_aware_predict(model, X, y, Xp), exp, what=what)
+    return what
+
+
+CASES = {"bcsd": case_bcsd, "analog": case_analog, "qm": case_qm, "trend": case_trend}
+
+
+def main(seconds=300.0, seed0=0):
+    if not ref_shim.available():
+        sys.exit("the reference tree is not here (this sweep runs in the build container only)")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = ref_shim.load()
+    t0, seed, n = time.time(), seed0, {k: 0 for k in CASES}
+    while time.time() - t0 < seconds:
+        rng = np.random.default_rng(seed)
+        name = str(rng.choice(list(CASES)))
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                what = CASES[name](ref, rng)
+        except AssertionError as e:
+            print(f"FAILED seed={seed} {name}: {str(e)[:1500]}", flush=True)
+            return 1
+        n[name] += 1
+        print(f"ok seed={seed} {what}", flush=True)
+        seed += 1
+    print(f"fuzz_oracle_vs_reference: {n} cases in {time.time() - t0:.0f} s, seeds {seed0}..{seed - 1}: all ok", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(float(sys.argv[1]) if len(sys.argv) > 1 else 300.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0))
