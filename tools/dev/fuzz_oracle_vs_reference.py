@@ -5,7 +5,7 @@ The GPU sweeps (fuzz_gpu.py, fuzz_r3.py, fuzz_pointwise.py) hold the engine to t
 reference on fresh random inputs -- random calendars, lengths, options -- beyond the fixed cases of
 tests/test_oracle_vs_reference.py.
 
-usage: fuzz_oracle_vs_reference.py [seconds] [first seed]
+usage: fuzz_oracle_vs_reference.py [seconds] [first seed] [case,case,...]
 """
 import os
 import sys
@@ -119,10 +119,94 @@ def case_trend(ref, rng):
     return what
 
 
-CASES = {"bcsd": case_bcsd, "analog": case_analog, "qm": case_qm, "trend": case_trend}
+def case_cunnane(ref, rng):
+    n, Tp = int(rng.integers(2, 4000)), int(rng.integers(1, 1500))
+    ex = [None, "min", "max", "both", "1to1"][int(rng.integers(0, 5))]
+    ne = int(rng.integers(2, 15))
+    x = np.round(5 + 2 * rng.standard_normal(n), int(rng.choice([1, 3, 12])))
+    xn = x.min() + (x.max() - x.min()) * rng.random(Tp)  # (beyond an extended tail the reference's transform raises: N2)
+    P = rng.uniform(-0.1, 1.1, Tp)
+    what = f"cunnane n={n} Tp={Tp} extrapolate={ex} n_endpoints={ne}"
+    t = ref.quantile.CunnaneTransformer(extrapolate=ex, n_endpoints=ne).fit(x.reshape(-1, 1))
+    cdf = qo.cunnane_fit(x)
+    assert np.array_equal(np.asarray(t.cdf_.vals).ravel(), cdf[1]) and np.array_equal(np.asarray(t.cdf_.pp).ravel(), cdf[0]), what
+    fwd = np.asarray(t.transform(xn.reshape(-1, 1))).ravel()
+    assert_close(qo.cunnane_transform(cdf, xn, ex), fwd, rtol=1e-12, what="forward " + what)
+    inv = np.asarray(t.inverse_transform(P.reshape(-1, 1))).ravel()
+    assert_close(qo.cunnane_inverse(cdf, P, ex, ne), inv, rtol=1e-8, what="inverse " + what)
+    return what
 
 
-def main(seconds=300.0, seed0=0):
+def case_regression(ref, rng):
+    F = int(rng.integers(1, 6))
+    T, Tq = int(rng.integers(F + 3, 3000)), int(rng.integers(1, 400))
+    X, Xq = rng.standard_normal((T, F)) * rng.choice([1.0, 100.0, 0.01], F), rng.standard_normal((Tq, F))
+    y = X @ rng.standard_normal(F) + rng.standard_normal(T)
+    what = f"PureRegression F={F} T={T} Tq={Tq}"
+    exp = ref.gard.PureRegression().fit(X, y).predict(Xq)
+    assert_close(ao.pure_regression(X, y, Xq)[0], np.asarray(exp), what=what)
+    thresh = float(np.quantile(y, rng.uniform(0.2, 0.7)))
+    if (y > thresh).sum() >= F + 2:
+        tight = dict(tol=1e-12, max_iter=100000)
+        m = ref.gard.PureRegression(thresh=thresh, logistic_kwargs=tight).fit(X, y)
+        exp = np.asarray(m.predict(Xq))
+        out = ao.pure_regression_thresh(X, y, Xq, thresh)[0]
+        assert_close(out[:, [0, 2]], exp[:, [0, 2]], what=what + f" thresh={thresh}")
+        # probabilities: on features of scales 0.01 .. 100 lbfgs (even at tol=1e-12) stops short of the optimum -- seed 50031: its
+        # objective 1408.14646988 vs 1408.14646983 for the oracle's Newton iteration, probabilities 1.8e-4 apart.  So: the oracle's
+        # point must be at least as good a minimiser of sklearn's objective, and the probabilities agree to the solver's accuracy.
+        exc = (y > thresh).astype(np.float64)
+
+        def objective(w, b):
+            z = X @ w + b
+            return 0.5 * w @ w + np.sum(np.logaddexp(0.0, z) - exc * z)
+
+        w, b = ao.logistic_fit(X, exc.astype(bool))
+        lm = m.logistic_model_
+        assert objective(w, b) <= objective(lm.coef_[0], lm.intercept_[0]) * (1 + 1e-12), what + " logistic objective"
+        assert np.abs(out[:, 1] - exp[:, 1]).max() < 2e-3, what + " probability"
+    return what
+
+
+def case_analogreg_thresh(ref, rng):
+    F = int(rng.integers(1, 4))
+    T, Tq = int(rng.integers(150, 1500)), int(rng.integers(1, 25))
+    k = int(rng.integers(24, 64))
+    X, Xq = rng.standard_normal((T, F)), rng.standard_normal((Tq, F))
+    y = 0.3 * X.sum(axis=1) + rng.standard_normal(T)
+    thresh = float(np.quantile(y, rng.uniform(0.3, 0.6)))
+    what = f"AnalogRegression(thresh) F={F} T={T} Tq={Tq} k={k}"
+    _, inds = ao.knn(X, Xq, k)
+    nexc = (y[inds] > thresh).sum(axis=1)
+    keep = (nexc >= F + 2) & (nexc < k)  # (<= F + 1 exceeding analogs: unpinned; all exceeding: no logistic fit; none: the reference raises)
+    if not keep.any() or (nexc == 0).any():
+        return None
+    tight = dict(tol=1e-12, max_iter=100000)
+    exp = np.asarray(ref.AnalogRegression(n_analogs=k, thresh=thresh, logistic_kwargs=tight).fit(X, y).predict(Xq))
+    out = ao.analog_regression_thresh_predict(X, y, Xq, k, thresh)[0]
+    assert_close(out[keep][:, [0, 2]], exp[keep][:, [0, 2]], what=what)
+    assert np.abs(out[keep, 1] - exp[keep, 1]).max() < 1e-6, what + " probability"
+    return what
+
+
+def case_nasanex(ref, rng):
+    index = pd.date_range(start(rng, "1970-01-01", 8000), periods=int(rng.integers(3 * 366, 6 * 366)))
+    index_p = pd.date_range(index[0] + pd.Timedelta(days=int(rng.integers(0, 700))), periods=int(rng.integers(40, 3 * 366)))
+    X, y, Xp = (12 + 7 * rng.standard_normal(n) for n in (len(index), len(index), len(index_p)))
+    what = f"daily_nasa-nex {index[0].date()} +{len(index)} -> {index_p[0].date()} +{len(index_p)}"
+    m = ref.BcsdTemperature(time_grouper="daily_nasa-nex", return_anoms=False).fit(frame(X, index), frame(y, index))
+    exp = m.predict(frame(Xp, index_p)).values[:, 0]
+    st, _ = bo.bcsd_fit_cell(bo.TAS, X, y, None, table=bo.padded_doy_table(index), return_anoms=False)
+    out, _ = bo.bcsd_predict_trend_cell(st, Xp, np.asarray(index_p.day) - 1, np.asarray(index_p.month) - 1, return_anoms=False)
+    assert_close(out, exp, what=what)
+    return what
+
+
+CASES = {"bcsd": case_bcsd, "analog": case_analog, "qm": case_qm, "trend": case_trend, "cunnane": case_cunnane,
+         "regression": case_regression, "analogreg_thresh": case_analogreg_thresh, "nasanex": case_nasanex}
+
+
+def main(seconds=300.0, seed0=0, only=None):
     if not ref_shim.available():
         sys.exit("the reference tree is not here (this sweep runs in the build container only)")
     with warnings.catch_warnings():
@@ -131,7 +215,7 @@ def main(seconds=300.0, seed0=0):
     t0, seed, n = time.time(), seed0, {k: 0 for k in CASES}
     while time.time() - t0 < seconds:
         rng = np.random.default_rng(seed)
-        name = str(rng.choice(list(CASES)))
+        name = str(rng.choice(list(CASES if only is None else only)))
         try:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
@@ -139,12 +223,14 @@ def main(seconds=300.0, seed0=0):
         except AssertionError as e:
             print(f"FAILED seed={seed} {name}: {str(e)[:1500]}", flush=True)
             return 1
-        n[name] += 1
-        print(f"ok seed={seed} {what}", flush=True)
+        if what is not None:
+            n[name] += 1
+            print(f"ok seed={seed} {what}", flush=True)
         seed += 1
     print(f"fuzz_oracle_vs_reference: {n} cases in {time.time() - t0:.0f} s, seeds {seed0}..{seed - 1}: all ok", flush=True)
     return 0
 
 
 if __name__ == "__main__":
-    sys.exit(main(float(sys.argv[1]) if len(sys.argv) > 1 else 300.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0))
+    sys.exit(main(float(sys.argv[1]) if len(sys.argv) > 1 else 300.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+                  sys.argv[3].split(",") if len(sys.argv) > 3 else None))
