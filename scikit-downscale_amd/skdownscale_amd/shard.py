@@ -255,7 +255,20 @@ class Communicator(_GatherLayout):
             return buf.raw
 
         if rendezvous is not None:
-            return cls(ctx, rank, world, rendezvous.broadcast(make_id() if rank == 0 else None))
+            if rank == 0:
+                try:
+                    uid = make_id()
+                except Exception:
+                    rendezvous.broadcast(b"")  # (the other ranks are waiting for it: let them fail too instead of hanging)
+                    raise
+                rendezvous.broadcast(uid)
+            else:
+                uid = rendezvous.broadcast(None)
+                if len(uid) != ID_BYTES:
+                    from ._lib import EngineError
+
+                    raise EngineError("rank 0 could not create the RCCL unique id")
+            return cls(ctx, rank, world, uid)
         return cls(ctx, rank, world, exchange_unique_id(rank, world, make_id, timeout=timeout))
 
     def close(self):
