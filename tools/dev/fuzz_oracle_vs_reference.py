@@ -206,14 +206,14 @@ CASES = {"bcsd": case_bcsd, "analog": case_analog, "qm": case_qm, "trend": case_
          "regression": case_regression, "analogreg_thresh": case_analogreg_thresh, "nasanex": case_nasanex}
 
 
-def main(seconds=300.0, seed0=0, only=None):
+def main(seconds=300.0, seed0=0, only=None, max_cases=None):
     if not ref_shim.available():
         sys.exit("the reference tree is not here (this sweep runs in the build container only)")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         ref = ref_shim.load()
     t0, seed, n = time.time(), seed0, {k: 0 for k in CASES}
-    while time.time() - t0 < seconds:
+    while time.time() - t0 < seconds and (max_cases is None or sum(n.values()) < max_cases):
         rng = np.random.default_rng(seed)
         name = str(rng.choice(list(CASES if only is None else only)))
         try:
