@@ -510,7 +510,9 @@ int carve_workspace(sd_ctx* ctx, int nmax, int64_t C, int G, bool fused, bool wa
 int run_predict_kernels(sd_ctx* ctx, sdrs::Params& p, bool fused, int nmax_all, const std::vector<int>& glen) {
     if (fused) {
         if (const char* e = sd_dev_env("SD_FZ_ABLATE")) p.dev_flags = atoi(e);
-        SD_TRY(sd_bcsd_fz_launch(ctx, p, nmax_all, glen.data()));
+        const char* fx = sd_dev_env("SD_BCSD_FX");  // "0": the round-3 fused kernel (f64 merge sort through LDS), A/B measurements
+        if (sd_bcsd_fx_supported(nmax_all) && !(fx && fx[0] == '0')) SD_TRY(sd_bcsd_fx_launch(ctx, p, nmax_all, glen.data()));
+        else SD_TRY(sd_bcsd_fz_launch(ctx, p, nmax_all, glen.data()));
         p.use_worklist = 1;
         p.shift = nullptr;
     }

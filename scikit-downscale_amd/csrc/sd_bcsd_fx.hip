@@ -1,0 +1,518 @@
+// BcsdTemperature fit + predict of one (cell, month) segment in ONE workgroup pass -- the headline kernel, round 4.
+//
+// Same decomposition as sd_bcsd_rs.hip (one 64-lane wave per segment, 8 adjacent cells per 512-thread workgroup, K
+// consecutive samples per lane, two workgroups per CU) and the same reference semantics as the fused kernel it replaces
+// (bcsd.py:197-269, quantile.py:81-147, 438-545), but neither sort touches LDS memory any more:
+//
+//   keys     a sample becomes a 32-bit key: 21 bits of q = floor((v - lo) * QD / (hi - lo)) (lo, hi = extremes of the segment;
+//            monotone in v) above the 11-bit LDS slot of the sample.  Pads get keys above every data key.
+//   sort     sdws::wave_sort: a bitonic network over 64 lane-blocks held in registers (DPP / ds_swizzle partner fetch +
+//            v_med3_u32, compile-time comparator networks inside a lane).  It orders by (q, slot), which differs from the
+//            true order only inside runs of equal q (1.3 pairs per 1 240-sample segment).
+//   fix-up   neighbours with equal q are compared by their float64 values, which sit in the wave's LDS row by slot, and
+//            swap tags when inverted (wave-uniform branches; a second pass only when three or more samples share a q).
+//            Exactly tied predict samples (np.interp wants the largest rank among ties, quantile.py:488) send the
+//            (tile, group) to the RANK / APPLY work list as before.
+//   x side   x_hist rows streamed and reduced to x_climo (bcsd.py:222); the x_fut tile transposed into the LDS rows; the
+//            9-sample rolling mean gives the shift (bcsd.py:247-253), which now STAYS IN REGISTERS until the end (the sort
+//            needs 20 key registers instead of 42 + 84 for values and merge windows): no second read of the x_fut tile, no
+//            second rolling mean, no scratch.  The shifted series u = x - shift (bcsd.py:256) replaces x in the row.
+//   y side   y_obs tile transposed into the same rows, y_climo (bcsd.py:223), keys, sort, fix-up; the lane owning sorted
+//            positions r reads the r-th smallest observations from the row by tag (np.sort, quantile.py:462).
+//   map      rank r -> fitted inverse CDF (quantile.py:523-545): identity for equal fit / predict group lengths, else the
+//            per-rank (index, weight) table with 10-point OLS tails; the value is scattered to the time slot named by the
+//            tag of the rank-r predict sample, every lane reads back its K consecutive samples, adds the shift
+//            (bcsd.py:263), removes y_climo (bcsd.py:266-267) and the tile goes out transposed.
+//
+// LDS row layout: sample j of the segment sits in slot 4 + j + j / (K * P), P = 64 / gcd(2K, 64): every K*P samples one
+// slot is skipped, so that the lanes' blocks of K doubles start on distinct bank pairs (K = 20 is even: stride 40 words
+// would otherwise put lanes l and l + 8 on the same banks).  Slots 0..3 and the four slots behind the segment hold zeros
+// for the rolling window.
+// HBM traffic: 3 reads + 1 write per sample.
+#include "sd_bcsd_rs.h"
+#include "sd_wave.h"
+#include "sd_wsort.h"
+
+namespace sdfx {
+
+using namespace sdw;
+using sdrs::Params;
+
+typedef const Params __attribute__((address_space(4)))* ParamsPtr;
+
+constexpr int kFront = 4;
+constexpr unsigned kTagBits = 11, kTagMask = 2047u;
+constexpr unsigned kQD = (1u << 21) - 2048u;  // data keys use q <= kQD; pads q = kQD + 1 + slot
+
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+
+template <int K>
+struct Lay {
+    static constexpr int P = 64 / cgcd(2 * K, 64);
+    static constexpr int KP = K * P;
+    __device__ __host__ static int slot(int j) { return kFront + j + j / KP; }  // j >= 0
+    __device__ static int own(int lane) { return kFront + K * lane + lane / P; }  // slot of sample K * lane
+};
+
+// slots a row needs: a partly filled lane reads its whole block and the rolling window behind it, so the row reaches
+// sample K * ceil(len / K) + 3 of the longest group; one spare slot takes the stores of positions past the segment
+template <int K>
+int row_slots(int nmax) {
+    int need = Lay<K>::slot((nmax + K - 1) / K * K + 3) + 2;
+    while (need % 4 != 2) ++need;  // cell rows land 8 or 24 banks apart: conflict-free transposing stores
+    return need;
+}
+
+__device__ __forceinline__ unsigned lds_u32(unsigned a) { return *reinterpret_cast<__attribute__((address_space(3))) unsigned*>((uintptr_t)a); }
+
+// ---- tile movement with the swizzled row layout ---------------------------------------------------------------
+template <int RPT, int K>
+__device__ __forceinline__ void tile_commit_sw(const TileRegs<RPT>& t, int nrows, int64_t c0, int64_t C, double* tile, int RS,
+                                               int32_t* status, int* bad_cell) {
+    const int tid = tid_now();
+    const int cp = tid & 3, rr = tid >> 2;
+    const int64_t c = c0 + 2 * cp;
+    double* d0 = tile + (2 * cp) * RS;
+    double* d1 = d0 + RS;
+    bool bad0 = false, bad1 = false;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = rr + k * kRowsPerPass;
+        if (r < nrows) {
+            bad0 |= !finite64(t.v0[k]);
+            bad1 |= !finite64(t.v1[k]);
+            const int s = Lay<K>::slot(r);
+            d0[s] = t.v0[k];
+            d1[s] = t.v1[k];
+        }
+    }
+    if (bad0 && c < C) atomicOr(&status[c], SDI_NONFINITE);
+    if (bad1 && c + 1 < C) atomicOr(&status[c + 1], SDI_NONFINITE);
+    if (bad_cell != nullptr) {
+        if (bad0) bad_cell[2 * cp] = 1;
+        if (bad1) bad_cell[2 * cp + 1] = 1;
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void store_tile_sw(double* __restrict__ dst, int64_t ld, const int32_t* __restrict__ ord, int nrows,
+                                              int64_t c0, int64_t C, bool vec_ok, const double* tile, int RS) {
+    const int tid = tid_now();
+    const int cp = tid & 3, rr = tid >> 2;
+    const int64_t c = c0 + 2 * cp;
+    const double* s0 = tile + (2 * cp) * RS;
+    const double* s1 = s0 + RS;
+    const bool full = vec_ok && c + 1 < C;
+#pragma unroll 4
+    for (int r = rr; r < nrows; r += kRowsPerPass) {
+        double* p = row_of(dst + c, ord[r], ld);
+        const int s = Lay<K>::slot(r);
+        if (full) {
+            *reinterpret_cast<double2*>(p) = make_double2(s0[s], s1[s]);
+        } else {
+            if (c < C) p[0] = s0[s];
+            if (c + 1 < C) p[1] = s1[s];
+        }
+    }
+}
+
+// ---- wave reductions --------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = vmin(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = vmax(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+// ---- keys ---------------------------------------------------------------------------------------------------------
+// v[i] = sample K * lane + i of the segment (any value where that position is past m); key = (q << 11) | slot
+template <int K>
+__device__ __forceinline__ void make_keys(const double (&v)[K], int m, int lane, unsigned (&key)[K]) {
+    const int j0 = K * lane;
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const bool in = j0 + i < m;
+        lo = vmin(lo, in ? v[i] : lo);
+        hi = vmax(hi, in ? v[i] : hi);
+    }
+    lo = wave_min_f64(lo);
+    hi = wave_max_f64(hi);
+    const double sc = (double)kQD / (hi - lo);  // +inf when every sample is equal: all keys tie, the fix-up sorts it out
+    const double off = -lo * sc;
+    const unsigned tag0 = (unsigned)Lay<K>::own(lane);
+    const unsigned pad0 = ((kQD + 1u + tag0) << kTagBits) | tag0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        unsigned q = (unsigned)__builtin_fma(v[i], sc, off);  // v_cvt_u32_f64: truncates, saturates, NaN -> 0
+        q = q < kQD ? q : kQD;
+        const unsigned dk = (q << kTagBits) | (tag0 + (unsigned)i);
+        const unsigned pk = pad0 + (unsigned)i * ((1u << kTagBits) + 1u);
+        key[i] = j0 + i < m ? dk : pk;
+    }
+}
+
+// ---- exact order inside runs of equal q -------------------------------------------------------------------------------
+// k[] = the lane's K sorted keys (lane l owns sorted positions K*l ..).  Neighbouring keys with equal q are compared by
+// the float64 values behind their tags (rowb + 8 * slot) and exchange tags when inverted.  Returns true if two of the
+// compared values are equal (an exact tie) or the passes did not converge.
+template <int K>
+__device__ __forceinline__ bool fix_equal_q(unsigned (&k)[K], unsigned rowb, int lane) {
+    constexpr unsigned kQ = 1u << kTagBits;
+    bool tie = false;
+#pragma unroll 1
+    for (int pass = 0; pass < 6; ++pass) {
+        bool swapped = false;
+        // the pair (last key of lane l, first key of lane l + 1) first, on both lanes' values as the pass finds them
+        const unsigned knext = lane < 63 ? (unsigned)__shfl_down((int)k[0], 1, kWave) : 0xffffffffu;
+        const bool eqx = (k[K - 1] ^ knext) < kQ;
+        const unsigned long long bx = __ballot(eqx);
+        if (bx != 0ull) {  // wave-uniform, rare
+            const double va = lds_f64(rowb + 8u * (k[K - 1] & kTagMask));
+            const double vb = lds_f64(rowb + 8u * (knext & kTagMask));
+            const bool sw = eqx && va > vb;
+            tie |= eqx && va == vb;
+            const unsigned d = sw ? (k[K - 1] ^ knext) : 0u;  // equal q: the xor exchanges the tags
+            k[K - 1] ^= d;
+            const unsigned din = (unsigned)__shfl_up((int)d, 1, kWave);
+            if (lane > 0) k[0] ^= din;
+            swapped |= sw;
+        }
+        // pairs inside the lane, in ascending order
+        unsigned long long prev = 0ull, b0 = 0ull, multi = 0ull;
+#pragma unroll
+        for (int i = 0; i + 1 < K; ++i) {
+            const bool eq = (k[i] ^ k[i + 1]) < kQ;
+            const unsigned long long b = __ballot(eq);
+            multi |= b & prev;
+            if (i == 0) b0 = b;
+            prev = b;
+            if (b != 0ull) {
+                const double va = lds_f64(rowb + 8u * (k[i] & kTagMask));
+                const double vb = lds_f64(rowb + 8u * (k[i + 1] & kTagMask));
+                const bool sw = eq && va > vb;
+                tie |= eq && va == vb;
+                const unsigned d = sw ? (k[i] ^ k[i + 1]) : 0u;
+                k[i] ^= d;
+                k[i + 1] ^= d;
+                swapped |= sw;
+            }
+        }
+        // a key in two equal-q pairs (a run of three or more) may need another pass
+        multi |= (bx & prev) | ((bx << 1) & b0);
+        if (multi == 0ull || !__any(swapped)) return __any(tie);
+    }
+    return true;
+}
+
+template <int K, bool IDENT, bool YE>
+__global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();  // Params is the only kernel argument
+    constexpr int NR = K / 2;  // rows per thread of a tile (64 K rows, 128 per pass)
+    constexpr int CH = K >= 14 ? K / 2 : K;
+    static_assert(K % 2 == 0 && K % CH == 0, "even K");
+    using L = Lay<K>;
+#ifdef SD_DEV
+    const int abl = p->dev_flags;  // SD_FZ_ABLATE: 1 no sort of u, 2 no sort of y, 4 no x_hist, 8 no fix-ups, 16 no store, 32 no y load,
+                                   // 64 no x_fut load, 128 no rolling mean (timing only: results are wrong)
+#else
+    constexpr int abl = 0;
+#endif
+    double* const scratch = reinterpret_cast<double*>(smem_raw);  // 64 doubles (column-sum exchange)
+    double* const rcp = scratch + 64;                             // 16 doubles: correctly rounded 1/c, c = 1..9
+    int* const bad_cell = reinterpret_cast<int*>(rcp + 16);       // 8 ints: cell of the tile saw a non-finite sample
+    int* const redo_flag = bad_cell + kW;                         // 8 ints: the wave's segment must go to the work list
+    double* const tile = scratch + kHeadDoubles;
+    const int RS = p->RS;
+    fill_rcp_table(rcp);
+    if (threadIdx.x >= 32 && threadIdx.x < 32 + kW) bad_cell[threadIdx.x - 32] = 0;
+
+#ifdef SD_DEV
+    if ((abl >> 12) != 0 && blockIdx.x < 512u) {
+        // SD_FZ_ABLATE bits 12.. = T: the first generation of workgroups starts spread over ~T microseconds
+        const unsigned h = (blockIdx.x * 2654435761u) >> 20;  // 12 bits
+        const unsigned nn = (h * (unsigned)(abl >> 12)) >> 12;  // 0 .. T-1 "microseconds"
+        for (unsigned i = 0; i < 2u * nn; ++i) __builtin_amdgcn_s_sleep(19);  // ~1216 clocks ~ 0.5 us
+    }
+#endif
+    int64_t tile_id;
+    int g;
+    xcd_tile_of_block(blockIdx.x, p->ntiles, &tile_id, &g);
+    if (p->gmask != 0ull) g = nth_set_bit(p->gmask, g);
+    if (tile_id >= p->ntiles || g < 0 || g >= p->G) return;
+
+    const int64_t c0 = tile_id * kW;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_now() / kWave);
+#define SD_LANE() const int lane = tid_now() % kWave
+    const int64_t c = c0 + wave;
+    const bool cell_ok = c < p->C;
+    double* const row = tile + wave * RS;
+    const unsigned rowb = lds_addr(row);
+    const int64_t seg = c * p->G + g;
+    const int begf = p->off_f[g];
+    const int n = p->off_f[g + 1] - begf;
+    const int begp = p->off_p[g];
+    const int m = p->off_p[g + 1] - begp;
+    if (m == 0) return;
+    const bool vec_f = (p->ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->y) & 15) == 0) &&
+                       (p->X == nullptr || (reinterpret_cast<uintptr_t>(p->X) & 15) == 0);
+    const bool vec_p = (p->ld_p % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->Xp) & 15) == 0);
+    const bool cell_live = cell_ok && p->status_fit[cell_ok ? c : 0] == 0;
+    const unsigned spare = rowb + 8u * (unsigned)(RS - 1);  // slot that takes the stores of positions past the segment
+    __syncthreads();  // bad_cell zeroed before the commits below may set it
+
+    // ---- x climatology (bcsd.py:222) + the x_fut tile ---------------------------------------------------
+    double xc = 0.0;
+    {
+        SD_LANE();
+        TileRegs<NR> xf;
+        if (p->from_state) {
+            if (cell_ok) xc = p->x_climo[seg];
+            tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
+        } else if (n > 0 && !(abl & 4)) {
+            TileRegs<NR> xh;
+            tile_issue<NR>(p->X, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, xh);
+            if (!(abl & 64)) tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
+            xc = tile_reduce_mean<NR>(xh, n, c0, p->C, scratch, p->status_fit, wave, lane, bad_cell);
+        } else if (!(abl & 64)) {
+            tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
+        }
+        if (!(abl & 64)) tile_commit_sw<NR, K>(xf, m, c0, p->C, tile, RS, p->status_p, bad_cell);
+        if (lane < kFront) {
+            row[lane] = 0.0;
+            row[L::slot(m + lane)] = 0.0;
+        }
+    }
+    __syncthreads();
+
+    // ---- shift (kept), shifted series -> row, keys -> sort ------------------------------------------------
+    double shift[K];
+    unsigned ku[K];  // sorted keys of the shifted series: tag = time slot of the sample with that rank
+    bool redo = false;
+    TileRegs<NR> yt;  // the y_obs tile, requested before the sort of u: its latency hides behind the sort
+    constexpr bool y_early = YE;
+    {
+        SD_LANE();
+        const bool has = K * lane < m;  // the lane's block starts inside the segment
+        const int bl = has ? lane : 0;  // lanes past the segment read lane 0's block (values unused)
+        const double* ob = row + L::own(bl);
+        const double* pb = row + (kFront + K * bl + (bl > 0 ? (bl - 1) / L::P : 0));  // pb[-k] = sample K*bl - k
+        const double* nb = row + (kFront + K * (bl + 1) + (bl + 1) / L::P);              // nb[k]  = sample K*(bl+1) + k
+        double u[K];
+#pragma unroll
+        for (int cbeg = 0; cbeg < K; cbeg += CH) {
+            double w[CH + 8];
+#pragma unroll
+            for (int t = 0; t < CH + 8; ++t) {
+                const int idx = cbeg - 4 + t;  // sample K*bl + idx
+                w[t] = idx < 0 ? pb[idx] : idx >= K ? nb[idx - K] : ob[idx];
+            }
+#pragma unroll
+            for (int ii = 0; ii < CH; ++ii) {
+                double s = 0.0;
+#pragma unroll
+                for (int d = 0; d < 9; ++d) s += w[ii + d];
+                const int j = K * lane + cbeg + ii;
+                const int lo = j - 4 > 0 ? j - 4 : 0;
+                const int hi = j + 5 < m ? j + 5 : m;
+                const int cnt = hi - lo > 1 ? (hi - lo < 10 ? hi - lo : 9) : 1;
+                const double cd = (double)cnt;
+                const double rc = rcp[cnt];
+                const double q = s * rc;
+                const double mean = __builtin_fma(__builtin_fma(-cd, q, s), rc, q);  // correctly rounded s / cnt
+                const double sh = mean - xc;                                           // bcsd.py:253
+                shift[cbeg + ii] = sh;
+                u[cbeg + ii] = (w[ii + 4] - sh) + 0.0;  // bcsd.py:256; -0.0 -> +0.0 (they tie in np.sort / np.interp)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wave_fence();  // every lane has read its window
+        {
+            const unsigned a0 = rowb + 8u * (unsigned)L::own(lane);
+#pragma unroll
+            for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < m ? a0 + 8u * (unsigned)i : spare, u[i]);
+        }
+        make_keys<K>(u, m, lane, ku);
+        wave_fence();
+        if (y_early && !p->from_state && n > 0 && !(abl & 32)) tile_issue<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, yt);
+        if (!(abl & 1)) sdws::wave_sort<K>(ku, lane, (m + K - 1) / K);
+        const bool tie = (abl & 8) ? false : fix_equal_q<K>(ku, rowb, lane);
+        redo = tie && cell_live && bad_cell[wave] == 0 && abl == 0;  // wave-uniform
+    }
+    // every wave is done with its row; a workgroup with an ambiguous segment leaves the (tile, group) to RANK / APPLY
+    // (not __syncthreads_or: its library reduction takes 256 bytes of static LDS, which costs the second workgroup per CU)
+    redo_flag[wave] = redo ? 1 : 0;
+    __syncthreads();
+    int any_redo = 0;
+#pragma unroll
+    for (int w = 0; w < kW; ++w) any_redo |= redo_flag[w];
+    if (any_redo) {
+        if (threadIdx.x == 0) {
+            const int slot = atomicAdd(p->work_count, 1);
+            if (slot < p->work_cap) p->worklist[slot] = tile_id * p->G + g;
+        }
+        return;
+    }
+
+    // ---- y: climatology + sorted observations -----------------------------------------------------------------
+    double yc = 0.0;
+    double t[K];  // IDENT: the sorted observations of the ranks this lane owns
+    if (!p->from_state) {
+        if (n > 0) {
+            SD_LANE();
+            if (!y_early && !(abl & 32)) tile_issue<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, yt);
+            if (!(abl & 32)) tile_commit_sw<NR, K>(yt, n, c0, p->C, tile, RS, p->status_fit, nullptr);
+            __syncthreads();
+            unsigned ky[K];
+            {
+                const int bl = K * lane < n ? lane : 0;
+                const double* ob = row + L::own(bl);
+                double v[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) v[i] = ob[i];
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < K; ++i) s += K * lane + i < n ? v[i] : 0.0;
+                yc = wave_sum(s) / (double)n;  // bcsd.py:223
+                make_keys<K>(v, n, lane, ky);
+            }
+            if (!(abl & 2)) sdws::wave_sort<K>(ky, lane, (n + K - 1) / K);
+            if (!(abl & 8)) (void)fix_equal_q<K>(ky, rowb, lane);  // tied observations are interchangeable
+#pragma unroll
+            for (int i = 0; i < K; ++i) t[i] = lds_f64(rowb + 8u * (K * lane + i < n ? (ky[i] & kTagMask) : (unsigned)(RS - 1)));
+            if (!IDENT) {
+                wave_fence();  // all reads by tag done: the row becomes the sorted segment, plain indexing
+#pragma unroll
+                for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < n ? rowb + 8u * (unsigned)(K * lane + i) : spare, t[i]);
+            }
+        }
+    } else {
+        SD_LANE();
+        if (cell_ok) {
+            yc = p->y_climo[seg];
+            const double* src = p->ys + c * p->Tf + begf;
+            for (int i = lane; i < n; i += kWave) row[i] = src[i];
+        }
+        wave_fence();
+        if (IDENT) {
+            const double* srow = row + (K * lane < n ? K * lane : 0);
+#pragma unroll
+            for (int i = 0; i < K; ++i) t[i] = srow[i];
+        }
+    }
+
+    // ---- map ranks through the fitted inverse CDF (quantile.py:523-545), scatter to time slots ------------------
+    {
+        SD_LANE();
+        if (!IDENT) {
+            wave_fence();
+            double slo = 0.0, ilo = 0.0, shi = 0.0, ihi = 0.0;
+            if (m > n && n > 0) {  // tails are reachable only when the predict segment is longer
+                const int e = n < 10 ? n : 10;
+                const double dn = pp_denom(n);
+                ols_line(row, 0, e, dn, &slo, &ilo);
+                ols_line(row, n - e, e, dn, &shi, &ihi);
+            }
+            const double nan = __longlong_as_double(0x7ff8000000000000ll);
+            const int r0 = K * lane < m ? K * lane : 0;
+            const int32_t* qi = p->qidx + begp + r0;
+            const double* qv = p->qval + begp + r0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const bool in = r0 + i < m;
+                const int idx = in ? qi[i] : -3;
+                const double w = in ? qv[i] : 0.0;
+                double v;
+                if (idx >= 0) {
+                    const double y0 = row[idx];
+                    const double y1 = row[idx + 1 < n ? idx + 1 : idx];
+                    v = w == 0.0 ? y0 : y0 + w * (y1 - y0);
+                } else if (idx == -1) {
+                    v = w * slo + ilo;
+                } else if (idx == -2) {
+                    v = w * shi + ihi;
+                } else {
+                    v = nan;
+                }
+                t[i] = v;
+                if ((i + 1) % CH == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        wave_fence();  // every lane has read what it needs of the row
+#pragma unroll
+        for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < m ? rowb + 8u * (ku[i] & kTagMask) : spare, t[i]);
+        wave_fence();
+        // ---- restore the climate-trend shift (bcsd.py:263-267), in place ---------------------------------------
+        const bool has = K * lane < m;
+        double* ob = row + L::own(has ? lane : 0);
+        double q[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) q[i] = ob[i];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            double res = shift[i] + q[i];         // bcsd.py:253,263
+            if (p->return_anoms) res = res - yc;  // bcsd.py:266-267
+            lds_store_f64(K * lane + i < m ? rowb + 8u * (unsigned)(L::own(lane) + i) : spare, res);
+        }
+    }
+    __syncthreads();
+    const bool vec_o = (p->ld_out % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->out) & 15) == 0);
+    if (!(abl & 16)) store_tile_sw<K>(p->out, p->ld_out, p->ord_p + begp, m, c0, p->C, vec_o, tile, RS);
+#undef SD_LANE
+}
+
+template <int K, bool IDENT, bool YE>
+int launch_kiy(sd_ctx* ctx, Params p, int nmax, const int* group_len) {
+    (void)group_len;
+    p.RS = row_slots<K>(nmax);
+    const size_t lds = ((size_t)kW * p.RS + kHeadDoubles) * sizeof(double);
+    if (lds > ctx->lds_max) return sd_set_error(SD_ERR_UNSUPPORTED, "segment of %d samples needs %zu bytes of LDS", nmax, lds);
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fx_kernel<K, IDENT, YE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    const int64_t tx = (p.ntiles + 7) / 8;
+    const int64_t nblocks = 8 * tx * (p.gmask ? __builtin_popcountll(p.gmask) : p.G);
+    SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "grid too large");
+    SD_LAUNCH(ctx, "bcsd_fx_kernel", (bcsd_fx_kernel<K, IDENT, YE>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
+    return SD_OK;
+}
+
+template <int K, bool IDENT>
+int launch_ki(sd_ctx* ctx, const Params& p, int nmax, const int* group_len) {
+#ifdef SD_DEV
+    if (p.dev_flags & 256) return launch_kiy<K, IDENT, true>(ctx, p, nmax, group_len);
+#endif
+    return launch_kiy<K, IDENT, false>(ctx, p, nmax, group_len);
+}
+
+template <int K>
+int launch_k(sd_ctx* ctx, const Params& p, int nmax, const int* gl) {
+    return p.identity ? launch_ki<K, true>(ctx, p, nmax, gl) : launch_ki<K, false>(ctx, p, nmax, gl);
+}
+
+int launch_width(sd_ctx* ctx, const Params& p, int nmax, const int* gl) {
+    if (nmax <= 64 * 4) return launch_k<4>(ctx, p, nmax, gl);
+    if (nmax <= 64 * 8) return launch_k<8>(ctx, p, nmax, gl);
+    if (nmax <= 64 * 12) return launch_k<12>(ctx, p, nmax, gl);
+    if (nmax <= 64 * 16) return launch_k<16>(ctx, p, nmax, gl);
+    if (nmax <= 64 * 20) return launch_k<20>(ctx, p, nmax, gl);
+    if (nmax <= 64 * 24) return launch_k<24>(ctx, p, nmax, gl);
+    return sd_set_error(SD_ERR_UNSUPPORTED, "segment of %d samples exceeds the fused register-sort path", nmax);
+}
+
+}  // namespace sdfx
+
+bool sd_bcsd_fx_supported(int nmax) { return nmax >= 1 && nmax <= 64 * 24; }
+
+// One launch per call: the K = 20 kernel serves every month of a daily series (1 130 .. 1 240 samples), a narrower
+// kernel only pays when the longest group allows it.
+int sd_bcsd_fx_launch(sd_ctx* ctx, const sdrs::Params& p, int nmax, const int* group_len) {
+    sdrs::Params q = p;
+    q.gmask = 0ull;
+    q.use_worklist = 0;
+    return sdfx::launch_width(ctx, q, nmax, group_len);
+}

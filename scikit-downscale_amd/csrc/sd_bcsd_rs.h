@@ -62,3 +62,6 @@ int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax, co
 // BcsdTemperature fused kernel (sd_bcsd_fz.hip): x side, y side, inverse CDF and shift of a segment in one workgroup
 // pass; segments it cannot serve are appended to p.worklist (the caller then runs RANK + APPLY with use_worklist).
 int sd_bcsd_fz_launch(sd_ctx* ctx, const sdrs::Params& p, int nmax, const int* group_len = nullptr);
+// round 4: the same contract on the register-resident 32-bit key sort of sd_wsort.h (sd_bcsd_fx.hip), segments <= 1 536
+bool sd_bcsd_fx_supported(int nmax);
+int sd_bcsd_fx_launch(sd_ctx* ctx, const sdrs::Params& p, int nmax, const int* group_len = nullptr);

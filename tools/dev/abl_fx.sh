@@ -1,0 +1,7 @@
+#!/bin/bash
+# ablation sweep of the fused kernel on the development library (SD_FZ_ABLATE bits, see csrc/sd_bcsd_fx.hip)
+export SD_DOWNSCALE_LIB=$PWD/scikit-downscale_amd/lib/libsd_downscale_dev.so
+for a in "$@"; do
+  SD_FZ_ABLATE=$a timeout 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.readline());print('abl=$a', round(d['roofline']['per_kernel_avg_ms']['bcsd_fx_kernel'],2),'ms')"
+done
