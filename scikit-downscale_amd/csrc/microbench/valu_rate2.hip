@@ -48,6 +48,26 @@ __global__ void __launch_bounds__(256) kern(unsigned* out, int iters) {
                 if (OP == 19) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
                 if (OP == 20) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
                 if (OP == 21) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 22) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(b) : "s20", "s21");
+                if (OP == 23) asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %1" : : "v"(a[i]), "v"(b) : "s20", "s21");
+                if (OP == 24) asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(b) : "s20", "s21");
+                if (OP == 25) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 26) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i]));
+                if (OP == 27) asm volatile("v_bfe_u32 %0, %0, 3, 11" : "+v"(a[i]));
+                if (OP == 28) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 29 && i < kCh / 2) asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(a[i]) : "v"(d[i]));
+                if (OP == 33 && i < kCh / 2) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(d[i]) : "v"(b), "v"(c) : "s20", "s21");
+                if (OP == 34 && i < kCh / 2) asm volatile("v_lshl_add_u64 %0, %0, 3, %1" : "+v"(d[i]) : "v"(bd));
+                if (OP == 35) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 36) asm volatile("v_lshl_or_b32 %0, %0, 11, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 37) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 38) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 39) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 40) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 41) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 42) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+                if (OP == 43) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+                if (OP == 44 && i < kCh / 2) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "v"(bd));
             }
             if (OP == 30) {  // the sort's cross stage pattern: 16 ds_swizzle then 16 med3
                 unsigned t[kCh];
@@ -98,6 +118,12 @@ int main() {
         {"v_mov_b32_dpp row_ror:8", kern<11>, 64}, {"v_max3_u32", kern<12>, 64}, {"v_min_u32_dpp", kern<13>, 64},
         {"v_pk_fma_f32", kern<14>, 32}, {"v_mov_b32", kern<15>, 64}, {"v_cmp_lt_u32", kern<16>, 64}, {"v_cndmask_b32", kern<17>, 64},
         {"v_pk_min_u16", kern<18>, 64}, {"v_min3_u32", kern<19>, 64}, {"v_and_or_b32", kern<20>, 64}, {"v_perm_b32", kern<21>, 64},
+        {"v_cndmask_b32_e64 sgpr mask", kern<22>, 64}, {"v_cmp_lt_u32_e64 -> sgpr", kern<23>, 64}, {"v_cmp_e64 + v_cndmask (pair)", kern<24>, 64},
+        {"v_and_b32", kern<25>, 64}, {"v_lshlrev_b32", kern<26>, 64}, {"v_bfe_u32", kern<27>, 64}, {"v_sub_u32", kern<28>, 64},
+        {"v_cvt_u32_f64", kern<29>, 32}, {"v_mad_u64_u32", kern<33>, 32}, {"v_lshl_add_u64", kern<34>, 32}, {"v_or_b32", kern<35>, 64},
+        {"v_lshl_or_b32", kern<36>, 64}, {"v_add3_u32", kern<37>, 64}, {"v_mul_f32", kern<38>, 64}, {"v_add_f32", kern<39>, 64},
+        {"v_max_f32", kern<40>, 64}, {"v_mul_lo_u32", kern<41>, 64}, {"v_cmp vcc + v_addc (pair)", kern<42>, 64},
+        {"v_mov_b32_dpp row_shr:1", kern<43>, 64}, {"v_mul_f64", kern<44>, 32},
         {"stage: 16 ds_swizzle + 16 med3 (32 instr)", kern<30>, 128}, {"stage: 16 mov_dpp + 16 med3 (32 instr)", kern<31>, 128},
         {"8 x (min_u32 + max_u32) on pairs", kern<32>, 64},
     };

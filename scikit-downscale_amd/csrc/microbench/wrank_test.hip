@@ -10,7 +10,7 @@
 #include <vector>
 
 #define SD_WRANK_STAMPS
-#include "../sd_wrank.h"
+#include "sd_wrank.h"
 
 constexpr int kWsBytes = sdwr::kHistBytes + 4 * (64 * 20 + sdwr::kMaxBin + 4);
 

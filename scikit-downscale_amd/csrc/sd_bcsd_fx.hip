@@ -131,17 +131,8 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 // ---- keys ---------------------------------------------------------------------------------------------------------
 // v[i] = sample K * lane + i of the segment (any value where that position is past m); key = (q << 11) | slot
 template <int K>
-__device__ __forceinline__ void make_keys(const double (&v)[K], int m, int lane, unsigned (&key)[K]) {
+__device__ __forceinline__ void keys_from_range(const double (&v)[K], int m, int lane, double lo, double hi, unsigned (&key)[K]) {
     const int j0 = K * lane;
-    double lo = __builtin_inf(), hi = -__builtin_inf();
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-        const bool in = j0 + i < m;
-        lo = vmin(lo, in ? v[i] : lo);
-        hi = vmax(hi, in ? v[i] : hi);
-    }
-    lo = wave_min_f64(lo);
-    hi = wave_max_f64(hi);
     const double sc = (double)kQD / (hi - lo);  // +inf when every sample is equal: all keys tie, the fix-up sorts it out
     const double off = -lo * sc;
     const unsigned tag0 = (unsigned)Lay<K>::own(lane);
@@ -154,6 +145,18 @@ __device__ __forceinline__ void make_keys(const double (&v)[K], int m, int lane,
         const unsigned pk = pad0 + (unsigned)i * ((1u << kTagBits) + 1u);
         key[i] = j0 + i < m ? dk : pk;
     }
+}
+template <int K>
+__device__ __forceinline__ void make_keys(const double (&v)[K], int m, int lane, unsigned (&key)[K]) {
+    const int j0 = K * lane;
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const bool in = j0 + i < m;
+        lo = vmin(lo, in ? v[i] : lo);
+        hi = vmax(hi, in ? v[i] : hi);
+    }
+    keys_from_range<K>(v, m, lane, wave_min_f64(lo), wave_max_f64(hi), key);
 }
 
 // ---- exact order inside runs of equal q -------------------------------------------------------------------------------
@@ -209,12 +212,12 @@ __device__ __forceinline__ bool fix_equal_q(unsigned (&k)[K], unsigned rowb, int
     return true;
 }
 
-template <int K, bool IDENT, bool YE>
+template <int K, bool IDENT>
 __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();  // Params is the only kernel argument
     constexpr int NR = K / 2;  // rows per thread of a tile (64 K rows, 128 per pass)
-    constexpr int CH = K >= 14 ? K / 2 : K;
+    constexpr int CH = K >= 20 ? K / 4 : K >= 14 ? K / 2 : K;  // samples per rolling-mean chunk (bounded register pressure)
     static_assert(K % 2 == 0 && K % CH == 0, "even K");
     using L = Lay<K>;
 #ifdef SD_DEV
@@ -294,8 +297,6 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
     double shift[K];
     unsigned ku[K];  // sorted keys of the shifted series: tag = time slot of the sample with that rank
     bool redo = false;
-    TileRegs<NR> yt;  // the y_obs tile, requested before the sort of u: its latency hides behind the sort
-    constexpr bool y_early = YE;
     {
         SD_LANE();
         const bool has = K * lane < m;  // the lane's block starts inside the segment
@@ -312,11 +313,15 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
                 const int idx = cbeg - 4 + t;  // sample K*bl + idx
                 w[t] = idx < 0 ? pb[idx] : idx >= K ? nb[idx - K] : ob[idx];
             }
+            // nine-sample window sums by shared partial sums (pairs, fours, eights): 4 additions per sample instead of 8
+            double p2[CH + 7], p4[CH + 5];
+#pragma unroll
+            for (int t = 0; t < CH + 7; ++t) p2[t] = w[t] + w[t + 1];
+#pragma unroll
+            for (int t = 0; t < CH + 5; ++t) p4[t] = p2[t] + p2[t + 2];
 #pragma unroll
             for (int ii = 0; ii < CH; ++ii) {
-                double s = 0.0;
-#pragma unroll
-                for (int d = 0; d < 9; ++d) s += w[ii + d];
+                const double s = (p4[ii] + p4[ii + 4]) + w[ii + 8];
                 const int j = K * lane + cbeg + ii;
                 const int lo = j - 4 > 0 ? j - 4 : 0;
                 const int hi = j + 5 < m ? j + 5 : m;
@@ -339,7 +344,6 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
         }
         make_keys<K>(u, m, lane, ku);
         wave_fence();
-        if (y_early && !p->from_state && n > 0 && !(abl & 32)) tile_issue<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, yt);
         if (!(abl & 1)) sdws::wave_sort<K>(ku, lane, (m + K - 1) / K);
         const bool tie = (abl & 8) ? false : fix_equal_q<K>(ku, rowb, lane);
         redo = tie && cell_live && bad_cell[wave] == 0 && abl == 0;  // wave-uniform
@@ -365,7 +369,10 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
     if (!p->from_state) {
         if (n > 0) {
             SD_LANE();
-            if (!y_early && !(abl & 32)) tile_issue<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, yt);
+            // (requesting this tile ahead of the sort of u, of its fix-up or of the vote keeps 40 registers in flight where the
+            // compiler has none to spare: 28 - 30 spilled registers, measured slower)
+            TileRegs<NR> yt;
+            if (!(abl & 32)) tile_issue<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, yt);
             if (!(abl & 32)) tile_commit_sw<NR, K>(yt, n, c0, p->C, tile, RS, p->status_fit, nullptr);
             __syncthreads();
             unsigned ky[K];
@@ -466,27 +473,19 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
 #undef SD_LANE
 }
 
-template <int K, bool IDENT, bool YE>
-int launch_kiy(sd_ctx* ctx, Params p, int nmax, const int* group_len) {
+template <int K, bool IDENT>
+int launch_ki(sd_ctx* ctx, Params p, int nmax, const int* group_len) {
     (void)group_len;
     p.RS = row_slots<K>(nmax);
     const size_t lds = ((size_t)kW * p.RS + kHeadDoubles) * sizeof(double);
     if (lds > ctx->lds_max) return sd_set_error(SD_ERR_UNSUPPORTED, "segment of %d samples needs %zu bytes of LDS", nmax, lds);
-    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fx_kernel<K, IDENT, YE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fx_kernel<K, IDENT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
     const int64_t tx = (p.ntiles + 7) / 8;
     const int64_t nblocks = 8 * tx * (p.gmask ? __builtin_popcountll(p.gmask) : p.G);
     SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "grid too large");
-    SD_LAUNCH(ctx, "bcsd_fx_kernel", (bcsd_fx_kernel<K, IDENT, YE>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
+    SD_LAUNCH(ctx, "bcsd_fx_kernel", (bcsd_fx_kernel<K, IDENT>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
     return SD_OK;
-}
-
-template <int K, bool IDENT>
-int launch_ki(sd_ctx* ctx, const Params& p, int nmax, const int* group_len) {
-#ifdef SD_DEV
-    if (p.dev_flags & 256) return launch_kiy<K, IDENT, true>(ctx, p, nmax, group_len);
-#endif
-    return launch_kiy<K, IDENT, false>(ctx, p, nmax, group_len);
 }
 
 template <int K>

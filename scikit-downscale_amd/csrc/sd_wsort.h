@@ -14,11 +14,10 @@
 //     v_med3_u32(own, partner, sel) with sel = 0 in the lanes that keep the minimum and 0xffffffff in those that keep
 //     the maximum: median(a, b, 0) = min(a, b), median(a, b, ~0) = max(a, b).  No lane-dependent sign conventions, no
 //     divergence; all keys stay in true ascending order.
-//   * the local merger sorts cyclic-bitonic sequences: even lengths are half-cleaned and split, an odd length (5 for
-//     K = 20) gets a full sorter.
+//   * the local merger sorts cyclic-bitonic sequences: even lengths are half-cleaned and split; the odd lengths 3 and 5
+//     (K = 12, 24; K = 20) end in 3-sorters (v_min3 / v_med3 / v_max3_u32), other odd lengths in a full sorter.
 //
-// K = 20: 101 + 6 * 56 comparators (2 instructions each) + 21 * 20 * 2 = ~1 700 full-rate 32-bit instructions per
-// 1 280 keys, against ~2 800 mostly double-rate instructions and 410 LDS instructions of the f64 merge sort of
+// K = 20: 202 + 6 * 80 + 21 * 20 * 2 = ~1 520 32-bit instructions per 1 280 keys, against ~2 800 mostly double-rate instructions and 410 LDS instructions of the f64 merge sort of
 // sd_wave.h.  tools/dev/nets.py checks the networks (0-1 principle), tools/dev/sim_wave_bitonic.py the lane scheme.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,12 +26,23 @@ namespace sdws {
 
 constexpr int kMaxCmp = 400;
 
+// a list of operations on registers: compare-exchange (a, b) -- min to a, max to b -- or, when c != kNone, a 3-sorter
+// (a, b, c) -- min to a, median to b, max to c: v_min3_u32, v_med3_u32, v_max3_u32, three instructions for what three
+// compare-exchanges (six instructions) do
+constexpr unsigned char kNone = 0xff;
 struct CmpList {
     int n = 0;
-    unsigned char a[kMaxCmp] = {}, b[kMaxCmp] = {};
+    unsigned char a[kMaxCmp] = {}, b[kMaxCmp] = {}, c[kMaxCmp] = {};
     constexpr void add(int lo, int hi) {
         a[n] = (unsigned char)lo;
         b[n] = (unsigned char)hi;
+        c[n] = kNone;
+        ++n;
+    }
+    constexpr void add3(int lo, int mid, int hi) {
+        a[n] = (unsigned char)lo;
+        b[n] = (unsigned char)mid;
+        c[n] = (unsigned char)hi;
         ++n;
     }
 };
@@ -80,6 +90,14 @@ struct BitonicNet {
                 sb[sp] = base;
                 sl[sp] = h;
                 ++sp;
+            } else if (len == 3) {
+                c.add3(base, base + 1, base + 2);
+            } else if (len == 5) {
+                // found by exhaustive search over the cyclic-bitonic 0-1 inputs (tools/dev/nets.py checks it): 10 instructions
+                c.add(base, base + 2);
+                c.add(base + 1, base + 3);
+                c.add3(base, base + 1, base + 4);
+                c.add3(base + 2, base + 3, base + 4);
             } else {
                 batcher_into(c, len, base);
             }
@@ -115,10 +133,53 @@ template <int K, typename Net>
 __device__ __forceinline__ void apply_net(unsigned (&k)[K], const Net& net) {
 #pragma unroll
     for (int c = 0; c < net.c.n; ++c) {
-        const unsigned lo = umin(k[net.c.a[c]], k[net.c.b[c]]);
-        const unsigned hi = umax(k[net.c.a[c]], k[net.c.b[c]]);
-        k[net.c.a[c]] = lo;
-        k[net.c.b[c]] = hi;
+        if (net.c.c[c] == kNone) {
+            const unsigned lo = umin(k[net.c.a[c]], k[net.c.b[c]]);
+            const unsigned hi = umax(k[net.c.a[c]], k[net.c.b[c]]);
+            k[net.c.a[c]] = lo;
+            k[net.c.b[c]] = hi;
+        } else {
+            // written out: the compiler re-associates min(min(x, z), y) to share min(x, y) with its v_med3 pattern and then
+            // emits five instructions instead of three
+            const unsigned x = k[net.c.a[c]], y = k[net.c.b[c]], z = k[net.c.c[c]];
+            unsigned lo, mid, hi;
+            asm("v_min3_u32 %0, %3, %4, %5\n\tv_med3_u32 %1, %3, %4, %5\n\tv_max3_u32 %2, %3, %4, %5"
+                : "=&v"(lo), "=&v"(mid), "=&v"(hi)
+                : "v"(x), "v"(y), "v"(z));
+            k[net.c.a[c]] = lo;
+            k[net.c.b[c]] = mid;
+            k[net.c.c[c]] = hi;
+        }
+    }
+}
+
+// Registers written by the inline assembly above may be read by a DPP move right away, and the compiler's hazard
+// recognizer does not look inside inline assembly (a VALU write needs two wait states before a DPP read of the same
+// register): every key passes through one "s_nop 1" after a network that uses 3-sorters.
+constexpr bool uses_sort3(const CmpList& c) {
+    for (int i = 0; i < c.n; ++i)
+        if (c.c[i] != kNone) return true;
+    return false;
+}
+template <int K>
+__device__ __forceinline__ void dpp_fence(unsigned (&k)[K]) {
+    if constexpr (!uses_sort3(BitonicNet<K>{}.c)) {
+        return;
+    } else if constexpr (K == 20) {
+        asm volatile("s_nop 1"
+                     : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "+v"(k[4]), "+v"(k[5]), "+v"(k[6]), "+v"(k[7]), "+v"(k[8]), "+v"(k[9]),
+                       "+v"(k[10]), "+v"(k[11]), "+v"(k[12]), "+v"(k[13]), "+v"(k[14]), "+v"(k[15]), "+v"(k[16]), "+v"(k[17]), "+v"(k[18]),
+                       "+v"(k[19]));
+    } else if constexpr (K == 12) {
+        asm volatile("s_nop 1"
+                     : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "+v"(k[4]), "+v"(k[5]), "+v"(k[6]), "+v"(k[7]), "+v"(k[8]), "+v"(k[9]),
+                       "+v"(k[10]), "+v"(k[11]));
+    } else {
+        static_assert(K == 24, "add the operand list for this K");
+        asm volatile("s_nop 1"
+                     : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "+v"(k[4]), "+v"(k[5]), "+v"(k[6]), "+v"(k[7]), "+v"(k[8]), "+v"(k[9]),
+                       "+v"(k[10]), "+v"(k[11]), "+v"(k[12]), "+v"(k[13]), "+v"(k[14]), "+v"(k[15]), "+v"(k[16]), "+v"(k[17]), "+v"(k[18]),
+                       "+v"(k[19]), "+v"(k[20]), "+v"(k[21]), "+v"(k[22]), "+v"(k[23]));
     }
 }
 
@@ -145,6 +206,7 @@ __device__ __forceinline__ void merge_level(unsigned (&k)[K], int lane, int addr
     if constexpr (M >= 4) cross_stage<K, 2, 1, false>(k, lane, addr63);
     if constexpr (M >= 2) cross_stage<K, 1, 0, false>(k, lane, addr63);
     apply_net<K>(k, bnet);
+    dpp_fence<K>(k);
 }
 
 // Sorts the wave's 64 * K keys; `lanes_used` (wave-uniform) = number of leading lanes that hold data: lanes beyond

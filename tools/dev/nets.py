@@ -100,7 +100,22 @@ def check_bitonic(K):
     return net, kept
 
 
+def check_bitonic5_sort3():
+    """the 10-instruction network of sd_wsort.h for cyclic-bitonic sequences of 5: two comparators + two 3-sorters"""
+    cols = cyclic_bitonic01(5)
+    def ce(a, b):
+        lo, hi = cols[a] & cols[b], cols[a] | cols[b]
+        cols[a], cols[b] = lo, hi
+    def s3(a, b, c):
+        n = cols[a].astype(int) + cols[b] + cols[c]
+        cols[a], cols[b], cols[c] = (n >= 3).astype(np.uint8), (n >= 2).astype(np.uint8), (n >= 1).astype(np.uint8)
+    ce(0, 2); ce(1, 3); s3(0, 1, 4); s3(2, 3, 4)
+    assert is_sorted01(cols)
+
+
 if __name__ == "__main__":
+    check_bitonic5_sort3()
+    print("bitonic-5 by two comparators + two 3-sorters: ok")
     for K in (3, 4, 5, 8, 10, 12, 16, 18, 20, 22, 24):
         s = sort_net(K) if K <= 22 else batcher(K)
         net, kept = check_bitonic(K)
