@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline, cpu_baseline_numpy and end_to_end")
     ap.add_argument("--check-cells", type=int, default=32, help="cells verified against the oracle outside the timed region")
+    ap.add_argument("--parity-only", action="store_true", help="CPU leg reduced to the parity check of the first cells (no CPU timing, no end_to_end)")
+    ap.add_argument("--no-secondary", action="store_true", help="default N=1 run: skip the short config 3 / config 4 runs appended as `secondary`")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)  # internal: one process of the N-process NumPy leg
     return ap.parse_args()
 
@@ -167,7 +169,7 @@ def _numpy_worker(job):
     return done, time.perf_counter() - t0
 
 
-def cpu_baseline(kind, T, seed, c_full, target_seconds, check=None):
+def cpu_baseline(kind, T, seed, c_full, target_seconds, check=None, parity_only=False):
     """CPU legs of one workload, on ONE socket of the GPU box, bounded samples, outside every timed region:
       port        BCSD: the plain-C restatement (oracle/sd_oracle.c, OpenMP, contiguous cell panels per thread), one thread per
                   physical core; PureAnalog: the reference's per-cell steps (sklearn KDTree + NumPy) on one process per physical core
@@ -198,6 +200,8 @@ def cpu_baseline(kind, T, seed, c_full, target_seconds, check=None):
             exp = (c_oracle.bcsd_fit_predict(0 if kind == "bcsd_tas" else 1, *chk_fields, gid, gid, nthreads=len(cores))[0]
                    if c_oracle.available() else numpy_cells(kind, chk_fields, gid, 0, n_chk))
         parity = check(exp) if check is not None else None
+        if parity_only:
+            return None, None, None, parity, None
         # ---- port ----
         if kind != "analog":
             import c_oracle
@@ -567,14 +571,15 @@ def main():
         try:
             step()  # `out` holds the full-grid result again
             ctx.synchronize()
-            baseline, numpy_1, numpy_n, parity, c_port = cpu_baseline(wl["kind"], T, args.seed, c_full, args.cpu_baseline_seconds, check_parity)
+            baseline, numpy_1, numpy_n, parity, c_port = cpu_baseline(wl["kind"], T, args.seed, c_full, args.cpu_baseline_seconds, check_parity,
+                                                                       parity_only=args.parity_only)
         except Exception as e:  # noqa: BLE001
             parity = f"not run: {type(e).__name__}: {e}"
         try:
             for d in list(fields.values()) + [out]:
                 d.free()
             ctx.release_cached()
-            if wl["kind"] == "bcsd_tas":
+            if wl["kind"] == "bcsd_tas" and not args.parity_only:
                 e2e = end_to_end(ctx, index, args.seed, c_full)
                 pw_e2e = pointwise_end_to_end(index, args.seed, c_full)
         except Exception as e:  # noqa: BLE001
@@ -641,6 +646,12 @@ def main():
     }
     if gather is not None:
         line.update(gather)
+    if world > 1:
+        line["scaling_claim"] = ("north_star's '>= 7x at 8 GPUs vs 1' is claimed on `value`: fit + predict of every rank's shard with the "
+                                 "predicted shards left resident on their GPUs (how a regridder or chunked writer consumes them); "
+                                 "`value_with_gather` (all shards into rank 0's HBM over xGMI, bound by the root's 7 links) and "
+                                 "`value_with_host_gather` (every rank to its own host memory over its own PCIe link) are reported beside "
+                                 "it and are NOT expected to reach 7x (DESIGN.md section 5)")
     if baseline is not None:  # rank 0 at N = 1 only
         line["cpu_baseline"] = baseline
     if numpy_1 is not None:
@@ -653,6 +664,23 @@ def main():
         line["end_to_end"] = e2e
     if pw_e2e is not None:
         line["pointwise_end_to_end"] = pw_e2e
+    # ---- the other single-GPU configurations of BASELINE.json, a few steps each, so that the driver's one run times them too:
+    # each in a process of its own (this one has released its fields), full size, parity of the first cells against the oracle
+    if world == 1 and config == 2 and not args.no_cpu_baseline and not args.parity_only and not args.no_secondary and not args.cells \
+            and args.times == 14_600:
+        secondary = {}
+        for c2, steps in ((3, 10), (4, 8)):
+            try:
+                o = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(c2), "--steps", str(steps), "--warmup", "2",
+                                    "--parity-only", "--seed", str(args.seed)], capture_output=True, text=True, timeout=600)
+                d = json.loads(o.stdout.strip().splitlines()[-1])
+                secondary[f"config{c2}"] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "steps": d["steps"],
+                                            "ms_per_step": d["ms_per_step"], "parity_check": d["parity_check"],
+                                            "roofline": {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel",
+                                                                                       "kernel_ms_per_step", "algorithmic_bytes_per_step")}}
+            except Exception as e:  # noqa: BLE001
+                secondary[f"config{c2}"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        line["secondary"] = secondary
     print(json.dumps(line), flush=True)
 
 

@@ -8,9 +8,10 @@ gather of the predicted field ``out[Tp, C_local]`` to the root.
 (``sd_comm_*``, csrc/sd_comm.hip) -- no PyTorch.  The ranks find each other through the launcher's environment
 (``RANK``, ``WORLD_SIZE``, ``MASTER_ADDR``, ``MASTER_PORT``: what ``python -m torch.distributed.run`` or any other
 launcher exports); rank 0 hands RCCL's 128-byte unique id to the others over a TCP socket.
-``HostCommunicator`` runs the same gather -- same layout code, same call -- on NumPy arrays over the rendezvous sockets:
-the sink of a sharded ``PointWiseDownscaler`` (whose results are host arrays anyway) and the way the layout logic is
-exercised with two processes on a machine without GPUs (tests/test_host.py).
+``ShardedPointWiseDownscaler`` is the drop-in surface on top of it: the ranks' results stay on their GPUs, travel to the
+root's GPU with one grouped ncclSend / ncclRecv, and cross PCIe once, on the root.  The layout logic (``_GatherLayout``) is
+transport independent; tests/_host_comm.py plugs a socket transport under it so that it runs with several processes on a
+machine without GPUs (tests/test_host.py) -- the package itself carries no host data plane.
 """
 from __future__ import annotations
 
@@ -159,32 +160,6 @@ class Rendezvous:
     def barrier(self):
         self.allreduce_max(0.0)
 
-    def gather_bytes(self, payload, into=None):
-        """every rank's ``payload`` (bytes-like) to rank 0: returns the list of per-rank buffers there (``into``: writable
-        per-rank memoryviews to receive into, avoiding copies), None elsewhere"""
-        if self.rank != 0:
-            view = memoryview(payload).cast("B")
-            self.root.sendall(self._struct.pack("<q", view.nbytes))
-            self.root.sendall(view)
-            return None
-        out = [None] * self.world
-        out[0] = memoryview(payload).cast("B") if into is None else into[0]
-        if into is not None:
-            into[0][:] = memoryview(payload).cast("B")
-        for r, conn in self.peers.items():
-            (n,) = self._struct.unpack("<q", self._recv(conn, 8))
-            buf = memoryview(bytearray(n)) if into is None else into[r]
-            if buf.nbytes != n:
-                raise ValueError(f"rank {r} sent {n} bytes, expected {buf.nbytes}")
-            got = 0
-            while got < n:
-                k = conn.recv_into(buf[got:], n - got)
-                if k == 0:
-                    raise ConnectionError("rendezvous peer closed the connection")
-                got += k
-            out[r] = buf
-        return out
-
     def close(self):
         for conn in list(self.peers.values()) + ([self.root] if self.root is not None else []):
             try:
@@ -319,54 +294,6 @@ class Communicator(_GatherLayout):
         check(self.ctx.lib.sd_comm_wait(self.handle))
 
 
-class HostCommunicator(_GatherLayout):
-    """The same gather for NumPy arrays, carried by the rendezvous sockets (root = rank 0 of the star)."""
-
-    def __init__(self, rendezvous):
-        self.rdv = rendezvous
-        self.rank, self.world = rendezvous.rank, rendezvous.world
-
-    def barrier(self):
-        self.rdv.barrier()
-
-    def allreduce_max(self, value):
-        return self.rdv.allreduce_max(value)
-
-    def _alloc(self, n):
-        return np.empty(int(n), dtype=np.float64)
-
-    @staticmethod
-    def _nbytes(buf):
-        return buf.nbytes
-
-    @staticmethod
-    def _view(buf, off, shape):
-        n = int(np.prod(shape, dtype=np.int64))
-        return buf.reshape(-1)[int(off):int(off) + n].reshape(shape)  # NumPy views keep their base alive
-
-    def _transport(self, local, T, cells, root_buffer, root, wait):
-        if root != 0:
-            raise ValueError("the socket transport gathers to rank 0 (the root of the rendezvous star)")
-        local = np.ascontiguousarray(local, dtype=np.float64)
-        if self.world == 1:
-            root_buffer.reshape(-1)[:local.size] = local.reshape(-1)
-            return
-        into = None
-        if self.rank == 0:
-            flat, into, off = memoryview(root_buffer.reshape(-1)).cast("B"), [], 0
-            for r in range(self.world):
-                n = T * int(cells[r]) * 8
-                into.append(flat[off:off + n])
-                off += n
-        self.rdv.gather_bytes(local, into)
-
-    def wait(self):
-        pass
-
-    def close(self):
-        pass
-
-
 def cell_partition(n_cells: int, world: int):
     """Contiguous blocks, sizes differ by at most one: list of (start, stop)."""
     base, rem = divmod(int(n_cells), int(world))
@@ -384,12 +311,18 @@ def local_cells(n_cells: int, world: int, rank: int):
 
 class ShardedPointWiseDownscaler:
     """``PointWiseDownscaler`` over the GPUs of one node: every rank (one process per GPU, same script, same inputs) fits and
-    predicts a contiguous block of the grid's cells (``cell_partition`` of the flattened spatial dims) on its own engine, and
-    the predicted field is gathered to rank 0 (``comm.gather_field``: ``HostCommunicator`` for the host arrays this surface
-    returns).  Replaces the reference's ``map_blocks`` over dask workers (core.py:256-262, 300-336) for one node.
+    predicts a contiguous block of the grid's cells (``cell_partition`` of the flattened spatial dims, in the spatial dim order
+    of the fitted ``X``) on its own engine, and the predicted field is gathered to rank 0 with ``comm.gather_field``.
+    Replaces the reference's ``map_blocks`` over dask workers (core.py:256-262, 300-336) for one node.
 
-    ``fit`` / ``predict`` / ``transform`` take what ``PointWiseDownscaler`` takes (GridArray, ndarray, xarray); ``predict`` returns
-    the full result on rank 0 and None on the other ranks."""
+    With a ``Communicator`` (RCCL) the gather runs GPU to GPU: BCSD predictions never leave the device before it (the
+    shard of ``X`` is uploaded, predicted and handed to the gather as a resident [T, C_r] field), results of the other
+    estimators are uploaded for it; rank 0 then downloads the gathered [rank][T][C_r] buffer once.
+
+    ``fit`` / ``predict`` / ``transform`` take what ``PointWiseDownscaler`` takes (GridArray, ndarray, xarray) and align their
+    arguments by dimension NAME like it does (core.py:86-93, 110-141): ``y`` at fit and ``X`` at predict may order their
+    spatial dims differently from the fitted ``X``.  ``predict`` returns the full result on rank 0 (dtype of the input, as
+    ``PointWiseDownscaler``) and None on the other ranks."""
 
     def __init__(self, model, dim="time", comm=None):
         from .core import PointWiseDownscaler
@@ -399,17 +332,27 @@ class ShardedPointWiseDownscaler:
         self.world = 1 if comm is None else comm.world
         self._dim = dim
         self._inner = PointWiseDownscaler(model, dim)
-        self._layout = None
+        self._layout = None  # (spatial dims, spatial shape, cells, spatial coords) of the fitted X
 
     # -- the cells of this rank as a [time, (feature), cell] grid ---------------------------------------------------------
-    def _shard(self, X, feature_dim):
+    def _shard(self, X, feature_dim, layout=None):
+        """``layout`` None: X defines the spatial dim order; else X is brought into the fitted order by dim name and must
+        have the fitted spatial shape."""
         from .core import DEFAULT_FEATURE_DIM, GridArray, _to_grid
 
-        g, _ = _to_grid(X, feature_dim or DEFAULT_FEATURE_DIM)
-        lead = [d for d in g.dims if d in (self._dim, feature_dim or DEFAULT_FEATURE_DIM)]
+        fd = feature_dim or DEFAULT_FEATURE_DIM
+        g, _ = _to_grid(X, fd)
+        lead = [d for d in g.dims if d in (self._dim, fd)]
         spatial = [d for d in g.dims if d not in lead]
+        if layout is not None:
+            want_dims, want_shape = layout[0], layout[1]
+            if set(spatial) != set(want_dims):
+                raise ValueError(f"spatial dims {tuple(spatial)} do not match the fitted grid's {tuple(want_dims)}")
+            spatial = list(want_dims)
         g = g.transpose(*lead, *spatial)
         sp_shape = g.shape[len(lead):]
+        if layout is not None and tuple(sp_shape) != tuple(layout[1]):
+            raise ValueError(f"spatial shape {tuple(sp_shape)} does not match the fitted grid {tuple(layout[1])}")
         C = int(np.prod(sp_shape, dtype=np.int64)) if sp_shape else 1
         s, e = cell_partition(C, self.world)[self.rank]
         flat = np.asarray(g.values).reshape(g.shape[:len(lead)] + (C,))
@@ -420,8 +363,30 @@ class ShardedPointWiseDownscaler:
     def fit(self, X, *args, **kwargs):
         fd = kwargs.get("feature_dim")
         Xl, self._layout = self._shard(X, fd)
-        self._inner.fit(Xl, *[self._shard(a, fd)[0] for a in args], **kwargs)
+        self._inner.fit(Xl, *[self._shard(a, fd, self._layout)[0] for a in args], **kwargs)
         return self
+
+    def _resident_bcsd(self, Xl, kwargs):
+        """BcsdTemperature / BcsdPrecipitation predict of this rank's shard with the result left on the GPU: (DeviceArray
+        [T, C_r], lead dims, lead shape, lead coords, dtype) or None when the fitted model is not a batched BCSD grid."""
+        from .core import DEFAULT_FEATURE_DIM, _time_index
+
+        mdl = getattr(self._inner, "_models", None)
+        if getattr(mdl, "kind", None) != "bcsd" or not hasattr(self.comm, "ctx"):
+            return None
+        fd = kwargs.get("feature_dim") or DEFAULT_FEATURE_DIM
+        Xg, _ = self._inner._to_feature_x(Xl, fd)
+        Xg = self._inner._align_to_fitted(Xg, fd)
+        T, F = Xg.shape[:2]
+        Cl = int(np.prod(Xg.shape[2:], dtype=np.int64))
+        if F != 1 or Cl == 0:
+            return None
+        Xv = np.ascontiguousarray(Xg.values, dtype=np.float64).reshape(T, Cl)
+        index = _time_index(Xg, self._dim)
+        out, status = mdl.grid_model.predict(self.comm.ctx.to_device(Xv), index)  # DeviceArray in -> DeviceArray out
+        self._inner._raise_for_status(status, Xv, Xv)
+        coords = {k: v for k, v in Xg.coords.items() if k == self._dim}
+        return out, (self._dim,), (T,), coords, Xg.dtype
 
     def _run(self, method, X, **kwargs):
         from .core import GridArray, _to_grid
@@ -429,23 +394,45 @@ class ShardedPointWiseDownscaler:
         if self._layout is None:
             raise ValueError("ShardedPointWiseDownscaler is not fitted: call fit() first")
         fd = kwargs.get("feature_dim")
-        Xl, (spatial, sp_shape, C, sp_coords) = self._shard(X, fd)
-        res, _ = _to_grid(getattr(self._inner, method)(Xl, **kwargs), fd or "variable")
-        res = res.transpose(*[d for d in res.dims if d != "cell"], "cell")
-        lead_dims, lead_shape = res.dims[:-1], res.shape[:-1]
-        rows = int(np.prod(lead_shape, dtype=np.int64))
-        local = np.ascontiguousarray(np.asarray(res.values, dtype=np.float64).reshape(rows, res.shape[-1]))
+        Xl, _ = self._shard(X, fd, self._layout)
+        spatial, sp_shape, C, sp_coords = self._layout
         cells = np.array([e - s for s, e in cell_partition(C, self.world)], dtype=np.int64)
+        on_gpu = self.comm is not None and hasattr(self.comm, "ctx")
+        resident = self._resident_bcsd(Xl, kwargs) if (method == "predict" and on_gpu and self.world > 1) else None
+        if resident is not None:
+            local, lead_dims, lead_shape, lead_coords, dtype = resident
+        else:
+            res, _ = _to_grid(getattr(self._inner, method)(Xl, **kwargs), fd or "variable")
+            res = res.transpose(*[d for d in res.dims if d != "cell"], "cell")
+            lead_dims, lead_shape, dtype = res.dims[:-1], res.shape[:-1], res.dtype
+            lead_coords = {k: v for k, v in res.coords.items() if k in lead_dims}
+            rows = int(np.prod(lead_shape, dtype=np.int64))
+            local = np.ascontiguousarray(np.asarray(res.values, dtype=np.float64).reshape(rows, res.shape[-1]))
         if self.comm is None or self.world == 1:
             full = local
         else:
+            if on_gpu and resident is None:
+                local = self.comm.ctx.to_device(local)  # (results of the other estimators are host arrays: up for the gather)
             views = self.comm.gather_field(local, cells, 0)
             if self.rank != 0:
                 return None
+            if on_gpu:
+                # one download of the root's [rank][T][C_r] buffer; the per-rank blocks are views of the host copy
+                rows = int(views[0].shape[0])
+                host = views[0].base.to_host().reshape(-1) if getattr(views[0], "base", None) is not None else None
+                if host is None:
+                    views = [v.to_host() for v in views]
+                else:
+                    blocks, off = [], 0
+                    for c in cells:
+                        blocks.append(host[off:off + rows * int(c)].reshape(rows, int(c)))
+                        off += rows * int(c)
+                    views = blocks
             full = np.concatenate(views, axis=1)  # per-rank blocks side by side = the flattened cell axis
-        coords = {k: v for k, v in res.coords.items() if k in lead_dims}
+        coords = dict(lead_coords)
         coords.update(sp_coords)
-        return GridArray(full.reshape(tuple(lead_shape) + tuple(sp_shape)), tuple(lead_dims) + tuple(spatial), coords)
+        full = np.asarray(full).reshape(tuple(lead_shape) + tuple(sp_shape)).astype(dtype, copy=False)
+        return GridArray(full, tuple(lead_dims) + tuple(spatial), coords)
 
     def predict(self, X, **kwargs):
         return self._run("predict", X, **kwargs)

@@ -361,6 +361,38 @@ def test_large_grid_is_consistent(ctx):
     out.free()
 
 
+def test_full_size_grid_is_consistent(ctx):
+    """BASELINE config 4 size (PureAnalog k = 30, F = 1, 100 000 cells x 14 600 steps, fit + predict) through the block
+    property: identical 8 192-cell blocks reproduce block 0 bit for bit (any chunk of the fit's tile sort, any workgroup of
+    the window search); the first cells match the oracle's brute-force neighbours."""
+    from skdownscale_amd import synth
+
+    T, C, B, k = 14600, 100_000, 8192, 30
+    fields = {}
+    for name, stream, kw in (("X", 20, {}), ("y", 20, dict(amp=2.0, stream2=21, amp2=1.0)), ("Xq", 22, {})):
+        d = ctx.empty((T, C))
+        for c0 in range(0, C, B):
+            ctx.synth_fill(d.cells(c0, min(C, c0 + B)), synth.GAUSS, 9, stream, c_offset=0, c_full=B, **kw)
+        fields[name] = d
+    st = ctx.analog_fit(ctx.wrap(fields["X"].ptr, (T, 1, C)), fields["y"])
+    out, status = ctx.analog_predict(st, ctx.wrap(fields["Xq"].ptr, (T, 1, C)), k, 3)
+    assert (status == 0).all()
+    rows = np.unique(np.linspace(0, T - 1, 24).astype(np.int64))
+    got = np.stack([ctx.wrap(out.ptr + int(t) * 3 * C * 8, (3, C)).to_host() for t in rows])  # [rows, 3, C]
+    for c0 in range(B, C, B):
+        c1 = min(C, c0 + B)
+        assert np.array_equal(got[:, :, c0:c1], got[:, :, :c1 - c0]), f"block at cell {c0} differs from block 0"
+    n = 2
+    Xh = fields["X"].cells(0, n).to_host()[:, None, :]
+    yh = fields["y"].cells(0, n).to_host()
+    Xqh = fields["Xq"].cells(0, n).to_host()[rows][:, None, :]
+    assert_close(got[:, :, :n], ao.pointwise_analog(Xh, yh, Xqh, k, ao.KIND_MEAN), what="full-size grid vs oracle")
+    st.close()
+    for d in fields.values():
+        d.free()
+    out.free()
+
+
 PROB_TIGHT = 1e-6    # exceedance probability vs the reference's objective solved tightly (logistic_kwargs tol=1e-12)
 PROB_DEFAULT = 1e-3  # ... vs the reference's default LogisticRegression: its L-BFGS stops at tol=1e-4, within ~2e-4 of the optimum
 

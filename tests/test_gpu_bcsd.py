@@ -598,6 +598,44 @@ def test_full_size_grid_is_consistent(ctx):
     out.free()
 
 
+def test_full_size_precipitation_grid_is_consistent(ctx):
+    """BASELINE config 3 size (BcsdPrecipitation, 250 000 cells x 14 600 steps, zero-inflated) through the same
+    size-independent property: identical 8 192-cell blocks must reproduce block 0 bit for bit wherever they land; the
+    first cells of block 0 are checked against the C oracle (bcsd.py:115-185: ratio anomalies, ties among the dry days)."""
+    import c_oracle
+    from skdownscale_amd import synth
+
+    if not c_oracle.available():
+        pytest.skip("C oracle not built")
+    T, C, B = 14600, 250_000, 8192
+    gid = month_gid(synth.daily_calendar(T))
+    fields = {}
+    for name in ("X_hist", "y_obs", "X_fut"):
+        p = synth.PR_FIELDS[name]
+        d = ctx.empty((T, C))
+        for c0 in range(0, C, B):
+            ctx.synth_fill(d.cells(c0, min(C, c0 + B)), synth.PRECIP, 7, p["stream"], c_offset=0, c_full=B, amp=p["amp"], p_dry=p["p_dry"])
+        fields[name] = d
+    out, status = ctx.bcsd_fit_predict(1, fields["X_hist"], fields["y_obs"], gid, 12, fields["X_fut"], gid)
+    assert (status == 0).all()
+    rows = np.unique(np.linspace(0, T - 1, 48).astype(np.int64))
+    got = np.empty((len(rows), C))
+    for i, t in enumerate(rows):
+        got[i] = ctx.wrap(out.ptr + int(t) * C * 8, (1, C)).to_host()[0]
+    for c0 in range(B, C, B):
+        c1 = min(C, c0 + B)
+        assert np.array_equal(got[:, c0:c1], got[:, :c1 - c0]), f"block at cell {c0} differs from block 0"
+    n = 16
+    cells = np.arange(n)
+    Xh, yh, Xf = (synth.pr_field(name, 7, T, cells, B) for name in ("X_hist", "y_obs", "X_fut"))
+    assert 0.3 < float((Xf == 0).mean()) < 0.7, "the generator is expected to leave about half the days dry"
+    exp, _ = c_oracle.bcsd_fit_predict(1, Xh, yh, Xf, gid, gid)
+    assert_close(got[:, :n], exp[rows], scale=float(np.std(exp)), what="full-size precipitation block 0 vs C oracle")
+    for d in fields.values():
+        d.free()
+    out.free()
+
+
 @pytest.mark.parametrize("kind", [0, 1])
 @pytest.mark.parametrize("G,T,Tp,C", [(1, 14600, 14600, 3), (1, 2113, 2500, 2), (4, 14600, 9000, 3), (1, 19456, 19456, 1),
                                      (2, 6000, 30000, 2), (1, 14600, 1000, 2)])

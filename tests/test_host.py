@@ -138,12 +138,13 @@ def test_sharded_gather_world_size_2_gloo(tmp_path):
 PRODUCT_WORKER = r'''
 import os, sys
 import numpy as np
-sys.path[:0] = [os.path.join(r"{root}", "scikit-downscale_amd"), os.path.join(r"{root}", "oracle")]
+sys.path[:0] = [os.path.join(r"{root}", "scikit-downscale_amd"), os.path.join(r"{root}", "oracle"), os.path.join(r"{root}", "tests")]
 import bcsd_oracle as bo
 from skdownscale_amd import synth
-from skdownscale_amd.shard import HostCommunicator, Rendezvous, cell_partition
+from skdownscale_amd.shard import Rendezvous, cell_partition
+from _host_comm import HostCommunicator
 rdv = Rendezvous.from_env()                   # RANK / WORLD_SIZE / MASTER_* from the launcher, like bench.py
-comm = HostCommunicator(rdv)                  # the product's gather call, bytes carried by sockets instead of RCCL
+comm = HostCommunicator(rdv)                  # the product's gather layout over a test transport (tests/_host_comm.py)
 rank, world = comm.rank, comm.world
 C, T = 11, 400
 index = synth.daily_calendar(T)
@@ -193,8 +194,8 @@ rdv.close()
 
 def test_product_gather_layout_three_ranks_on_cpu(tmp_path):
     """The layout logic of the product gather (cell_partition -> [rank][T][C_r] root buffer -> per-rank views -> equality with
-    the unsharded result) with three processes on CPU: ``HostCommunicator`` is ``Communicator`` with the RCCL call replaced
-    by a socket copy behind the same ``gather_field`` (same shared layout code, skdownscale_amd/shard.py:_GatherLayout)."""
+    the unsharded result) with three processes on CPU: tests/_host_comm.py puts a socket copy where ``Communicator`` calls RCCL,
+    behind the same ``gather_field`` (same shared layout code, skdownscale_amd/shard.py:_GatherLayout)."""
     script = tmp_path / "worker.py"
     script.write_text(PRODUCT_WORKER.format(root=ROOT))
     env = dict(os.environ, OMP_NUM_THREADS="1")
@@ -207,10 +208,11 @@ def test_product_gather_layout_three_ranks_on_cpu(tmp_path):
 SHARDED_PW_WORKER = r'''
 import os, sys
 import numpy as np
-sys.path[:0] = [os.path.join(r"{root}", "scikit-downscale_amd")]
+sys.path[:0] = [os.path.join(r"{root}", "scikit-downscale_amd"), os.path.join(r"{root}", "tests")]
 from sklearn.linear_model import LinearRegression
 from skdownscale_amd import GridArray, PointWiseDownscaler
-from skdownscale_amd.shard import HostCommunicator, Rendezvous, ShardedPointWiseDownscaler
+from skdownscale_amd.shard import Rendezvous, ShardedPointWiseDownscaler
+from _host_comm import HostCommunicator
 rdv = Rendezvous.from_env()
 comm = HostCommunicator(rdv)
 rng = np.random.default_rng(5)          # same inputs on every rank (SPMD)
@@ -218,8 +220,13 @@ X = GridArray(rng.standard_normal((40, 2, 3, 5)), ("time", "variable", "y", "x")
 y = GridArray(rng.standard_normal((40, 3, 5)), ("time", "y", "x"))
 X.values[0, :, 1, 2] = np.nan            # a masked cell (core.py:35-37)
 m = ShardedPointWiseDownscaler(LinearRegression(), comm=comm)   # 15 cells over 3 ranks; an sklearn estimator: the per-cell loop
-m.fit(X, y)
-out = m.predict(X)
+m.fit(X, y.transpose("time", "x", "y"))  # y in another spatial dim order: aligned by name (core.py:86-93)
+out = m.predict(X.transpose("time", "variable", "x", "y"))      # and so is X at predict (core.py:110-141)
+try:
+    m.predict(GridArray(X.values[:, :, :2], X.dims, {{"y": np.arange(2.0), "x": np.arange(5.0)}}))
+    raise SystemExit("a grid of another shape was accepted")
+except ValueError:
+    pass
 if comm.rank == 0:
     ref = PointWiseDownscaler(LinearRegression())
     ref.fit(X, y)
@@ -229,9 +236,20 @@ if comm.rank == 0:
     ok = ~np.isnan(exp.values)
     assert np.array_equal(out.values[ok], exp.values[ok]), "sharded PointWiseDownscaler differs from the unsharded one"
     assert np.array_equal(out.coords["x"], np.arange(5.0))
-    print("SHARDED_PW_OK")
 else:
     assert out is None
+# float32 grids come back as float32 (PointWiseDownscaler returns the input dtype); 2 cells over 3 ranks: one rank owns none
+X32 = GridArray(X.values[:, :, :1, :2].astype(np.float32), X.dims, {{"y": np.arange(1.0), "x": np.arange(2.0)}})
+y32 = GridArray(y.values[:, :1, :2].astype(np.float32), y.dims)
+m2 = ShardedPointWiseDownscaler(LinearRegression(), comm=comm)
+m2.fit(X32, y32)
+out2 = m2.predict(X32)
+if comm.rank == 0:
+    ref2 = PointWiseDownscaler(LinearRegression())
+    ref2.fit(X32, y32)
+    exp2 = ref2.predict(X32)
+    assert out2.dtype == exp2.dtype == np.float32 and np.array_equal(out2.values, exp2.values)
+    print("SHARDED_PW_OK")
 rdv.barrier()
 rdv.close()
 '''
