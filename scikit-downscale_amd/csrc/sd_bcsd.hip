@@ -467,7 +467,12 @@ bool use_fz_path(int kind, int nmax, bool detrend) {
     const char* e = sd_dev_env("SD_BCSD_FUSED");  // "0": RANK + APPLY for every segment (A/B measurements)
     if (e && e[0] == '0') return false;
     if (detrend) return false;  // QuantileMapper(detrend=True): RANK + APPLY carry the trend lines
-    return kind == SD_BCSD_TAS && sd_bcsd_fz_supported(nmax);
+    // BcsdPrecipitation: the fused kernel of sd_bcsd_fx.hip (zero class in the keys); SD_BCSD_FX=0 keeps it on RANK + APPLY
+    if (kind != SD_BCSD_TAS) {
+        const char* fx = sd_dev_env("SD_BCSD_FX");
+        return sd_bcsd_fx_supported(nmax) && !(fx && fx[0] == '0');
+    }
+    return sd_bcsd_fz_supported(nmax) || sd_bcsd_fx_supported(nmax);
 }
 
 // Hand-off / work-list workspace of one predict call, carved from the context workspace.
@@ -511,7 +516,7 @@ int run_predict_kernels(sd_ctx* ctx, sdrs::Params& p, bool fused, int nmax_all, 
     if (fused) {
         if (const char* e = sd_dev_env("SD_FZ_ABLATE")) p.dev_flags = atoi(e);
         const char* fx = sd_dev_env("SD_BCSD_FX");  // "0": the round-3 fused kernel (f64 merge sort through LDS), A/B measurements
-        if (sd_bcsd_fx_supported(nmax_all) && !(fx && fx[0] == '0')) SD_TRY(sd_bcsd_fx_launch(ctx, p, nmax_all, glen.data()));
+        if (sd_bcsd_fx_supported(nmax_all) && (p.kind != SD_BCSD_TAS || !(fx && fx[0] == '0'))) SD_TRY(sd_bcsd_fx_launch(ctx, p, nmax_all, glen.data()));
         else SD_TRY(sd_bcsd_fz_launch(ctx, p, nmax_all, glen.data()));
         p.use_worklist = 1;
         p.shift = nullptr;

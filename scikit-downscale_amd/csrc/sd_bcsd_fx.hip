@@ -130,24 +130,27 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 
 // ---- keys ---------------------------------------------------------------------------------------------------------
 // v[i] = sample K * lane + i of the segment (any value where that position is past m); key = (q << 11) | slot
-template <int K>
+// ZC (BcsdPrecipitation): exact zeros form class q = 0 of their own -- they are all tied, whatever order the sort leaves
+// them in -- and every other sample gets q >= 1 (lo must not be negative: the caller hands such segments back)
+template <int K, bool ZC>
 __device__ __forceinline__ void keys_from_range(const double (&v)[K], int m, int lane, double lo, double hi, unsigned (&key)[K]) {
     const int j0 = K * lane;
-    const double sc = (double)kQD / (hi - lo);  // +inf when every sample is equal: all keys tie, the fix-up sorts it out
-    const double off = -lo * sc;
+    const double sc = (double)(kQD - (ZC ? 1u : 0u)) / (hi - lo);  // +inf when every sample is equal: all keys tie, the fix-up sorts it out
+    const double off = -lo * sc + (ZC ? 1.0 : 0.0);
     const unsigned tag0 = (unsigned)Lay<K>::own(lane);
     const unsigned pad0 = ((kQD + 1u + tag0) << kTagBits) | tag0;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
         unsigned q = (unsigned)__builtin_fma(v[i], sc, off);  // v_cvt_u32_f64: truncates, saturates, NaN -> 0
         q = q < kQD ? q : kQD;
+        if (ZC) q = v[i] == 0.0 ? 0u : (q > 1u ? q : 1u);
         const unsigned dk = (q << kTagBits) | (tag0 + (unsigned)i);
         const unsigned pk = pad0 + (unsigned)i * ((1u << kTagBits) + 1u);
         key[i] = j0 + i < m ? dk : pk;
     }
 }
-template <int K>
-__device__ __forceinline__ void make_keys(const double (&v)[K], int m, int lane, unsigned (&key)[K]) {
+template <int K, bool ZC = false>
+__device__ __forceinline__ double make_keys(const double (&v)[K], int m, int lane, unsigned (&key)[K]) {
     const int j0 = K * lane;
     double lo = __builtin_inf(), hi = -__builtin_inf();
 #pragma unroll
@@ -156,23 +159,26 @@ __device__ __forceinline__ void make_keys(const double (&v)[K], int m, int lane,
         lo = vmin(lo, in ? v[i] : lo);
         hi = vmax(hi, in ? v[i] : hi);
     }
-    keys_from_range<K>(v, m, lane, wave_min_f64(lo), wave_max_f64(hi), key);
+    lo = wave_min_f64(lo);
+    keys_from_range<K, ZC>(v, m, lane, lo, wave_max_f64(hi), key);
+    return lo;
 }
 
 // ---- exact order inside runs of equal q -------------------------------------------------------------------------------
 // k[] = the lane's K sorted keys (lane l owns sorted positions K*l ..).  Neighbouring keys with equal q are compared by
-// the float64 values behind their tags (rowb + 8 * slot) and exchange tags when inverted.  Returns true if two of the
-// compared values are equal (an exact tie) or the passes did not converge.
-template <int K>
-__device__ __forceinline__ bool fix_equal_q(unsigned (&k)[K], unsigned rowb, int lane) {
-    constexpr unsigned kQ = 1u << kTagBits;
+// the float64 values behind their tags (rowb + 8 * slot) and exchange tags when inverted.  Returns kTie if two of the
+// compared values are equal (an exact tie), kUnsorted if the passes did not converge (a long run of equal q).
+constexpr int kTie = 1, kUnsorted = 2;
+template <int K, bool ZC = false>
+__device__ __forceinline__ int fix_equal_q(unsigned (&k)[K], unsigned rowb, int lane) {
+    constexpr unsigned kQ = 1u << kTagBits;  // (ZC: keys below kQ are the zero class, all exactly tied: left alone)
     bool tie = false;
 #pragma unroll 1
     for (int pass = 0; pass < 6; ++pass) {
         bool swapped = false;
         // the pair (last key of lane l, first key of lane l + 1) first, on both lanes' values as the pass finds them
         const unsigned knext = lane < 63 ? (unsigned)__shfl_down((int)k[0], 1, kWave) : 0xffffffffu;
-        const bool eqx = (k[K - 1] ^ knext) < kQ;
+        const bool eqx = (k[K - 1] ^ knext) < kQ && (!ZC || k[K - 1] >= kQ);
         const unsigned long long bx = __ballot(eqx);
         if (bx != 0ull) {  // wave-uniform, rare
             const double va = lds_f64(rowb + 8u * (k[K - 1] & kTagMask));
@@ -189,7 +195,7 @@ __device__ __forceinline__ bool fix_equal_q(unsigned (&k)[K], unsigned rowb, int
         unsigned long long prev = 0ull, b0 = 0ull, multi = 0ull;
 #pragma unroll
         for (int i = 0; i + 1 < K; ++i) {
-            const bool eq = (k[i] ^ k[i + 1]) < kQ;
+            const bool eq = (k[i] ^ k[i + 1]) < kQ && (!ZC || k[i] >= kQ);
             const unsigned long long b = __ballot(eq);
             multi |= b & prev;
             if (i == 0) b0 = b;
@@ -207,9 +213,9 @@ __device__ __forceinline__ bool fix_equal_q(unsigned (&k)[K], unsigned rowb, int
         }
         // a key in two equal-q pairs (a run of three or more) may need another pass
         multi |= (bx & prev) | ((bx << 1) & b0);
-        if (multi == 0ull || !__any(swapped)) return __any(tie);
+        if (multi == 0ull || !__any(swapped)) return __any(tie) ? kTie : 0;
     }
-    return true;
+    return kUnsorted;
 }
 
 template <int K, bool IDENT>
@@ -345,7 +351,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
         make_keys<K>(u, m, lane, ku);
         wave_fence();
         if (!(abl & 1)) sdws::wave_sort<K>(ku, lane, (m + K - 1) / K);
-        const bool tie = (abl & 8) ? false : fix_equal_q<K>(ku, rowb, lane);
+        const bool tie = (abl & 8) ? false : fix_equal_q<K>(ku, rowb, lane) != 0;
         redo = tie && cell_live && bad_cell[wave] == 0 && abl == 0;  // wave-uniform
     }
     // every wave is done with its row; a workgroup with an ambiguous segment leaves the (tile, group) to RANK / APPLY
@@ -366,6 +372,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
     // ---- y: climatology + sorted observations -----------------------------------------------------------------
     double yc = 0.0;
     double t[K];  // IDENT: the sorted observations of the ranks this lane owns
+    bool redo_y = false;  // a run of equal-q observations too long for the fix-up passes: RANK / APPLY take the (tile, group)
     if (!p->from_state) {
         if (n > 0) {
             SD_LANE();
@@ -389,7 +396,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
                 make_keys<K>(v, n, lane, ky);
             }
             if (!(abl & 2)) sdws::wave_sort<K>(ky, lane, (n + K - 1) / K);
-            if (!(abl & 8)) (void)fix_equal_q<K>(ky, rowb, lane);  // tied observations are interchangeable
+            if (!(abl & 8)) redo_y = (fix_equal_q<K>(ky, rowb, lane) & kUnsorted) != 0 && cell_live;  // tied observations are interchangeable
 #pragma unroll
             for (int i = 0; i < K; ++i) t[i] = lds_f64(rowb + 8u * (K * lane + i < n ? (ky[i] & kTagMask) : (unsigned)(RS - 1)));
             if (!IDENT) {
@@ -467,9 +474,238 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
             lds_store_f64(K * lane + i < m ? rowb + 8u * (unsigned)(L::own(lane) + i) : spare, res);
         }
     }
+    redo_flag[wave] = redo_y ? 1 : 0;
     __syncthreads();
+    any_redo = 0;
+#pragma unroll
+    for (int w = 0; w < kW; ++w) any_redo |= redo_flag[w];
+    if (any_redo) {  // nothing has been written yet
+        if (threadIdx.x == 0) {
+            const int slot = atomicAdd(p->work_count, 1);
+            if (slot < p->work_cap) p->worklist[slot] = tile_id * p->G + g;
+        }
+        return;
+    }
     const bool vec_o = (p->ld_out % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->out) & 15) == 0);
     if (!(abl & 16)) store_tile_sw<K>(p->out, p->ld_out, p->ord_p + begp, m, c0, p->C, vec_o, tile, RS);
+#undef SD_LANE
+}
+
+// ---- BcsdPrecipitation (bcsd.py:115-185) --------------------------------------------------------------------------
+// The same pass without a climate-trend shift: x_hist is only validated (bcsd.py:130-147), the raw x_fut series is ranked
+// (bcsd.py:167), the result is the mapped value over y_climo (ratio anomalies, bcsd.py:170-185).  Zero-inflated series: the
+// exact zeros of a segment are one tie -- np.interp gives every one of them the largest rank among them (quantile.py:488) --
+// so they form key class 0 (sorted in front, in any order, never compared), n0 of them are counted, and sorted position r
+// maps through rank max(r, n0 - 1).  Ties among the wet days, or negative values, send the (tile, group) to RANK / APPLY.
+template <int K, bool IDENT>
+__global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int NR = K / 2;
+    constexpr int CH = K >= 20 ? K / 4 : K >= 14 ? K / 2 : K;
+    using L = Lay<K>;
+    double* const scratch = reinterpret_cast<double*>(smem_raw);
+    int* const bad_cell = reinterpret_cast<int*>(scratch + 64 + 16);
+    int* const redo_flag = bad_cell + kW;
+    double* const tile = scratch + kHeadDoubles;
+    const int RS = p->RS;
+    if (threadIdx.x >= 32 && threadIdx.x < 32 + kW) bad_cell[threadIdx.x - 32] = 0;
+
+    int64_t tile_id;
+    int g;
+    xcd_tile_of_block(blockIdx.x, p->ntiles, &tile_id, &g);
+    if (p->gmask != 0ull) g = nth_set_bit(p->gmask, g);
+    if (tile_id >= p->ntiles || g < 0 || g >= p->G) return;
+
+    const int64_t c0 = tile_id * kW;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_now() / kWave);
+#define SD_LANE() const int lane = tid_now() % kWave
+    const int64_t c = c0 + wave;
+    const bool cell_ok = c < p->C;
+    double* const row = tile + wave * RS;
+    const unsigned rowb = lds_addr(row);
+    const int64_t seg = c * p->G + g;
+    const int begf = p->off_f[g];
+    const int n = p->off_f[g + 1] - begf;
+    const int begp = p->off_p[g];
+    const int m = p->off_p[g + 1] - begp;
+    if (m == 0) return;
+    const bool vec_f = (p->ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->y) & 15) == 0) &&
+                       (p->X == nullptr || (reinterpret_cast<uintptr_t>(p->X) & 15) == 0);
+    const bool vec_p = (p->ld_p % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->Xp) & 15) == 0);
+    const bool cell_live = cell_ok && p->status_fit[cell_ok ? c : 0] == 0;
+    const unsigned spare = rowb + 8u * (unsigned)(RS - 1);
+    __syncthreads();
+
+    // ---- x side: validation of x_hist, the x_fut tile ------------------------------------------------------------------
+    {
+        SD_LANE();
+        TileRegs<NR> xf;
+        if (!p->from_state && p->X != nullptr && n > 0) {
+            TileRegs<NR> xh;
+            tile_issue<NR>(p->X, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, xh);
+            tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
+            (void)tile_reduce_mean<NR>(xh, n, c0, p->C, scratch, p->status_fit, wave, lane, bad_cell);  // non-finite samples -> status
+        } else {
+            tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
+        }
+        tile_commit_sw<NR, K>(xf, m, c0, p->C, tile, RS, p->status_p, bad_cell);
+    }
+    __syncthreads();
+
+    unsigned ku[K];  // sorted keys of the x_fut segment: tag = time slot of the sample at that sorted position
+    int n0 = 0;      // exact zeros of the x_fut segment
+    bool redo = false;
+    TileRegs<NR> yt;  // the y_obs tile is requested ahead of the sort: no shift to keep here, the registers are free
+    {
+        SD_LANE();
+        const double* ob = row + L::own(K * lane < m ? lane : 0);
+        double v[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) v[i] = ob[i];
+#pragma unroll
+        for (int i = 0; i < K; ++i) n0 += __popcll(__ballot(K * lane + i < m && v[i] == 0.0));
+        const double lo = make_keys<K, true>(v, m, lane, ku);
+        if (!p->from_state && n > 0) tile_issue<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, yt);
+        sdws::wave_sort<K>(ku, lane, (m + K - 1) / K);
+        const bool tie = fix_equal_q<K, true>(ku, rowb, lane) != 0;
+        redo = (tie || lo < 0.0) && cell_live && bad_cell[wave] == 0;
+    }
+    redo_flag[wave] = redo ? 1 : 0;
+    __syncthreads();
+    int any_redo = 0;
+#pragma unroll
+    for (int w = 0; w < kW; ++w) any_redo |= redo_flag[w];
+    if (any_redo) {
+        if (threadIdx.x == 0) {
+            const int slot = atomicAdd(p->work_count, 1);
+            if (slot < p->work_cap) p->worklist[slot] = tile_id * p->G + g;
+        }
+        return;
+    }
+
+    // ---- y: climatology + sorted observations in the row (plain order) ----------------------------------------------
+    double yc = 0.0;
+    bool redo_y = false;
+    if (!p->from_state) {
+        if (n > 0) {
+            SD_LANE();
+            tile_commit_sw<NR, K>(yt, n, c0, p->C, tile, RS, p->status_fit, nullptr);
+            __syncthreads();
+            unsigned ky[K];
+            {
+                const double* ob = row + L::own(K * lane < n ? lane : 0);
+                double v[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) v[i] = ob[i];
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < K; ++i) s += K * lane + i < n ? v[i] : 0.0;
+                yc = wave_sum(s) / (double)n;  // bcsd.py:138
+                if (lane == 0 && cell_ok && p->return_anoms && yc <= 0.0) atomicOr(&p->status_fit[c], SDI_BAD_CLIMO);  // bcsd.py:140-141
+                const double lo = make_keys<K, true>(v, n, lane, ky);
+                redo_y = lo < 0.0 && cell_live;
+            }
+            sdws::wave_sort<K>(ky, lane, (n + K - 1) / K);
+            redo_y = (redo_y || (fix_equal_q<K, true>(ky, rowb, lane) & kUnsorted) != 0) && cell_live;  // tied observations are interchangeable
+            double t[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) t[i] = lds_f64(rowb + 8u * (K * lane + i < n ? (ky[i] & kTagMask) : (unsigned)(RS - 1)));
+            wave_fence();  // all reads by tag done: the row becomes the sorted segment (np.sort, quantile.py:462)
+#pragma unroll
+            for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < n ? rowb + 8u * (unsigned)(K * lane + i) : spare, t[i]);
+        }
+    } else {
+        SD_LANE();
+        if (cell_ok) {
+            yc = p->y_climo[seg];
+            const double* src = p->ys + c * p->Tf + begf;
+            for (int i = lane; i < n; i += kWave) row[i] = src[i];
+        }
+    }
+
+    // ---- map sorted position r through rank max(r, n0 - 1) and the fitted inverse CDF (quantile.py:488, 523-545) --------
+    {
+        SD_LANE();
+        wave_fence();
+        double t[K];
+        const int rz = n0 - 1;
+        if (IDENT) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int r = K * lane + i;
+                const int re = r > rz ? r : rz;
+                t[i] = row[r < m ? re : 0];
+            }
+        } else {
+            double slo = 0.0, ilo = 0.0, shi = 0.0, ihi = 0.0;
+            if (m > n && n > 0) {
+                const int e = n < 10 ? n : 10;
+                const double dn = pp_denom(n);
+                ols_line(row, 0, e, dn, &slo, &ilo);
+                ols_line(row, n - e, e, dn, &shi, &ihi);
+            }
+            const double nan = __longlong_as_double(0x7ff8000000000000ll);
+            const int32_t* qi = p->qidx + begp;
+            const double* qv = p->qval + begp;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int r = K * lane + i;
+                const bool in = r < m;
+                const int re = in ? (r > rz ? r : rz) : 0;
+                const int idx = in ? qi[re] : -3;
+                const double w = in ? qv[re] : 0.0;
+                double v;
+                if (idx >= 0) {
+                    const double y0 = row[idx];
+                    const double y1 = row[idx + 1 < n ? idx + 1 : idx];
+                    v = w == 0.0 ? y0 : y0 + w * (y1 - y0);
+                } else if (idx == -1) {
+                    v = w * slo + ilo;
+                } else if (idx == -2) {
+                    v = w * shi + ihi;
+                } else {
+                    v = nan;
+                }
+                t[i] = v;
+                if ((i + 1) % CH == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        wave_fence();  // every lane has read what it needs of the row
+#pragma unroll
+        for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < m ? rowb + 8u * (ku[i] & kTagMask) : spare, t[i]);
+        wave_fence();
+        // ---- ratio anomalies (bcsd.py:170-185), in place: q / y_climo by the reciprocal and one correction step ------------
+        double* ob = row + L::own(K * lane < m ? lane : 0);
+        double q[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) q[i] = ob[i];
+        const double rc = 1.0 / yc;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            double res = q[i];
+            if (p->return_anoms) {
+                const double a = q[i] * rc;
+                res = __builtin_fma(__builtin_fma(-yc, a, q[i]), rc, a);
+                res = __builtin_isfinite(res) ? res : q[i] / yc;  // (zero or denormal climatology: the plain quotient)
+            }
+            lds_store_f64(K * lane + i < m ? rowb + 8u * (unsigned)(L::own(lane) + i) : spare, res);
+        }
+    }
+    redo_flag[wave] = redo_y ? 1 : 0;
+    __syncthreads();
+    any_redo = 0;
+#pragma unroll
+    for (int w = 0; w < kW; ++w) any_redo |= redo_flag[w];
+    if (any_redo) {  // negative observations: nothing has been written, RANK / APPLY take the (tile, group)
+        if (threadIdx.x == 0) {
+            const int slot = atomicAdd(p->work_count, 1);
+            if (slot < p->work_cap) p->worklist[slot] = tile_id * p->G + g;
+        }
+        return;
+    }
+    const bool vec_o = (p->ld_out % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->out) & 15) == 0);
+    store_tile_sw<K>(p->out, p->ld_out, p->ord_p + begp, m, c0, p->C, vec_o, tile, RS);
 #undef SD_LANE
 }
 
@@ -479,12 +715,18 @@ int launch_ki(sd_ctx* ctx, Params p, int nmax, const int* group_len) {
     p.RS = row_slots<K>(nmax);
     const size_t lds = ((size_t)kW * p.RS + kHeadDoubles) * sizeof(double);
     if (lds > ctx->lds_max) return sd_set_error(SD_ERR_UNSUPPORTED, "segment of %d samples needs %zu bytes of LDS", nmax, lds);
-    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fx_kernel<K, IDENT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
     const int64_t tx = (p.ntiles + 7) / 8;
     const int64_t nblocks = 8 * tx * (p.gmask ? __builtin_popcountll(p.gmask) : p.G);
     SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "grid too large");
-    SD_LAUNCH(ctx, "bcsd_fx_kernel", (bcsd_fx_kernel<K, IDENT>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
+    if (p.kind == SD_BCSD_TAS) {
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fx_kernel<K, IDENT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        SD_LAUNCH(ctx, "bcsd_fx_kernel", (bcsd_fx_kernel<K, IDENT>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
+    } else {
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fxp_kernel<K, IDENT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        SD_LAUNCH(ctx, "bcsd_fxp_kernel", (bcsd_fxp_kernel<K, IDENT>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
+    }
     return SD_OK;
 }
 
