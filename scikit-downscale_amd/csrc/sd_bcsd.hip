@@ -455,24 +455,15 @@ int upload_group_table(sd_ctx* ctx, const int32_t* gid, int64_t T, int G, DevGro
     return SD_OK;
 }
 
-// BcsdTemperature takes the fused kernel of sd_bcsd_fz.hip (x side, y side, inverse CDF and shift of a segment in
-// one workgroup pass); the segments it hands back (work list: near-equal shifted samples) and BcsdPrecipitation take
-// RANK + APPLY.  The fused kernel can park the shift in a workspace slab between its x side and its map step
-// (8 more bytes per sample written and read, no second read of the x_fut tile / second rolling mean).
-bool fz_shift_slab() {
-    const char* e = sd_dev_env("SD_FZ_SLAB");
-    return e ? e[0] == '1' : false;
-}
-bool use_fz_path(int kind, int nmax, bool detrend) {
+// BcsdTemperature and BcsdPrecipitation take the fused kernels of sd_bcsd_fx.hip (x side, y side, inverse CDF and shift /
+// ratio of a segment in one workgroup pass, sorts on 32-bit keys in registers); the segments they hand back (work list:
+// exactly tied samples, runs of equal keys too long for the fix-up) take RANK + APPLY, and so does every segment of
+// more than 1 536 samples and QuantileMapper(detrend=True).
+bool use_fused_path(int nmax, bool detrend) {
     const char* e = sd_dev_env("SD_BCSD_FUSED");  // "0": RANK + APPLY for every segment (A/B measurements)
     if (e && e[0] == '0') return false;
-    if (detrend) return false;  // QuantileMapper(detrend=True): RANK + APPLY carry the trend lines
-    // BcsdPrecipitation: the fused kernel of sd_bcsd_fx.hip (zero class in the keys); SD_BCSD_FX=0 keeps it on RANK + APPLY
-    if (kind != SD_BCSD_TAS) {
-        const char* fx = sd_dev_env("SD_BCSD_FX");
-        return sd_bcsd_fx_supported(nmax) && !(fx && fx[0] == '0');
-    }
-    return sd_bcsd_fz_supported(nmax) || sd_bcsd_fx_supported(nmax);
+    if (detrend) return false;  // QuantileMapper(detrend=True): RANK / APPLY carry the trend lines
+    return sd_bcsd_fx_supported(nmax);
 }
 
 // Hand-off / work-list workspace of one predict call, carved from the context workspace.
@@ -485,11 +476,10 @@ struct RsWorkspace {
     int* work_count = nullptr;
     int work_cap = 0;
 };
-int carve_workspace(sd_ctx* ctx, int nmax, int64_t C, int G, bool fused, bool want_shift, bool want_x_climo, bool want_trend,
-                    RsWorkspace* w) {
+int carve_workspace(sd_ctx* ctx, int nmax, int64_t C, int G, bool fused, bool want_x_climo, bool want_trend, RsWorkspace* w) {
     size_t rank_bytes = 0, shift_bytes = 0;
     sd_bcsd_rs_handoff_bytes(nmax, C, G, &rank_bytes, &shift_bytes);
-    if (!want_shift) shift_bytes = 0;
+    shift_bytes = 0;  // (the round-3 fused kernel could park its shift here; the current one keeps it in registers)
     const size_t cg_bytes = ((sizeof(double) * (size_t)G * (size_t)C + 255) / 256) * 256;
     const size_t xc_bytes = (want_x_climo ? cg_bytes : 0) + (want_trend ? 2 * cg_bytes : 0);
     const int64_t items = ((C + 7) / 8) * (int64_t)G;
@@ -515,9 +505,7 @@ int carve_workspace(sd_ctx* ctx, int nmax, int64_t C, int G, bool fused, bool wa
 int run_predict_kernels(sd_ctx* ctx, sdrs::Params& p, bool fused, int nmax_all, const std::vector<int>& glen) {
     if (fused) {
         if (const char* e = sd_dev_env("SD_FZ_ABLATE")) p.dev_flags = atoi(e);
-        const char* fx = sd_dev_env("SD_BCSD_FX");  // "0": the round-3 fused kernel (f64 merge sort through LDS), A/B measurements
-        if (sd_bcsd_fx_supported(nmax_all) && (p.kind != SD_BCSD_TAS || !(fx && fx[0] == '0'))) SD_TRY(sd_bcsd_fx_launch(ctx, p, nmax_all, glen.data()));
-        else SD_TRY(sd_bcsd_fz_launch(ctx, p, nmax_all, glen.data()));
+        SD_TRY(sd_bcsd_fx_launch(ctx, p, nmax_all, glen.data()));
         p.use_worklist = 1;
         p.shift = nullptr;
     }
@@ -984,9 +972,9 @@ static int predict_with_table(sd_ctx* ctx, const sd_bcsd_state* st, const double
         p.identity = identity ? 1 : 0;
         p.from_state = 1;
         p.detrend = st->detrend; p.y_trend = st->y_trend;
-        const bool fused = use_fz_path(st->kind, nmax_all, st->detrend != 0);
+        const bool fused = use_fused_path(nmax_all, st->detrend != 0);
         RsWorkspace w;
-        SD_TRY(carve_workspace(ctx, nmax_all, C, st->G, fused, fused && fz_shift_slab(), false, st->detrend != 0, &w));
+        SD_TRY(carve_workspace(ctx, nmax_all, C, st->G, fused, false, st->detrend != 0, &w));
         p.ranks = w.ranks; p.shift = w.shift; p.trend_u = w.trend_u;
         p.worklist = w.worklist; p.work_count = w.work_count; p.work_cap = w.work_cap;
         const std::vector<int> glen = group_lengths(st->goff, &gt.host_off, st->G);
@@ -1176,12 +1164,12 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
     p.status_fit = status_f.as<int32_t>(); p.status_p = status_p.as<int32_t>();
     p.identity = identity ? 1 : 0;
     {
-        // No persisted sorted state.  BcsdTemperature: one fused kernel per segment (no hand-off at all); the segments
-        // it hands back, and BcsdPrecipitation: RANK writes 2 bytes/sample (rank of every x_fut sample in its shifted
+        // No persisted sorted state.  One fused kernel per segment (no hand-off at all); for the segments it hands back
+        // RANK writes 2 bytes/sample (rank of every x_fut sample in its shifted
         // segment) + x_climo, APPLY sorts y_obs on chip, maps the ranks and restores the shift.
-        const bool fused = use_fz_path(kind, nmax_all, detrend);
+        const bool fused = use_fused_path(nmax_all, detrend);
         RsWorkspace w;
-        SD_TRY(carve_workspace(ctx, nmax_all, C, G, fused, fused && fz_shift_slab(), true, detrend, &w));
+        SD_TRY(carve_workspace(ctx, nmax_all, C, G, fused, true, detrend, &w));
         p.ranks = w.ranks; p.shift = w.shift; p.x_climo = w.x_climo; p.trend_u = w.trend_u;
         p.worklist = w.worklist; p.work_count = w.work_count; p.work_cap = w.work_cap;
         const std::vector<int> glen = group_lengths(gf.host_off, &gp.host_off, G);

@@ -131,14 +131,17 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 // ---- keys ---------------------------------------------------------------------------------------------------------
 // v[i] = sample K * lane + i of the segment (any value where that position is past m); key = (q << 11) | slot
 // ZC (BcsdPrecipitation): exact zeros form class q = 0 of their own -- they are all tied, whatever order the sort leaves
-// them in -- and every other sample gets q >= 1 (lo must not be negative: the caller hands such segments back)
-template <int K, bool ZC>
+// them in -- and every other sample gets q >= 1 (lo must not be negative: the caller hands such segments back).
+// FULL: the segment length is a multiple of K, so a lane is all data or all pad: one select per key instead of a compare
+// and a select, and no masking in the search for the extremes (lanes past the segment hold a copy of lane 0's block).
+template <int K, bool ZC, bool FULL>
 __device__ __forceinline__ void keys_from_range(const double (&v)[K], int m, int lane, double lo, double hi, unsigned (&key)[K]) {
     const int j0 = K * lane;
     const double sc = (double)(kQD - (ZC ? 1u : 0u)) / (hi - lo);  // +inf when every sample is equal: all keys tie, the fix-up sorts it out
     const double off = -lo * sc + (ZC ? 1.0 : 0.0);
     const unsigned tag0 = (unsigned)Lay<K>::own(lane);
     const unsigned pad0 = ((kQD + 1u + tag0) << kTagBits) | tag0;
+    const bool lane_in = j0 < m;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
         unsigned q = (unsigned)__builtin_fma(v[i], sc, off);  // v_cvt_u32_f64: truncates, saturates, NaN -> 0
@@ -146,22 +149,27 @@ __device__ __forceinline__ void keys_from_range(const double (&v)[K], int m, int
         if (ZC) q = v[i] == 0.0 ? 0u : (q > 1u ? q : 1u);
         const unsigned dk = (q << kTagBits) | (tag0 + (unsigned)i);
         const unsigned pk = pad0 + (unsigned)i * ((1u << kTagBits) + 1u);
-        key[i] = j0 + i < m ? dk : pk;
+        key[i] = (FULL ? lane_in : j0 + i < m) ? dk : pk;
     }
 }
-template <int K, bool ZC = false>
-__device__ __forceinline__ double make_keys(const double (&v)[K], int m, int lane, unsigned (&key)[K]) {
+template <int K, bool ZC, bool FULL>
+__device__ __forceinline__ double make_keys_impl(const double (&v)[K], int m, int lane, unsigned (&key)[K]) {
     const int j0 = K * lane;
     double lo = __builtin_inf(), hi = -__builtin_inf();
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        const bool in = j0 + i < m;
+        const bool in = FULL || j0 + i < m;
         lo = vmin(lo, in ? v[i] : lo);
         hi = vmax(hi, in ? v[i] : hi);
     }
     lo = wave_min_f64(lo);
-    keys_from_range<K, ZC>(v, m, lane, lo, wave_max_f64(hi), key);
+    keys_from_range<K, ZC, FULL>(v, m, lane, lo, wave_max_f64(hi), key);
     return lo;
+}
+template <int K, bool ZC = false>
+__device__ __forceinline__ double make_keys(const double (&v)[K], int m, int lane, unsigned (&key)[K]) {
+    if (m % K == 0) return make_keys_impl<K, ZC, true>(v, m, lane, key);  // wave-uniform (the whole launch, in fact)
+    return make_keys_impl<K, ZC, false>(v, m, lane, key);
 }
 
 // ---- exact order inside runs of equal q -------------------------------------------------------------------------------
@@ -328,7 +336,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
 #pragma unroll
             for (int ii = 0; ii < CH; ++ii) {
                 const double s = (p4[ii] + p4[ii + 4]) + w[ii + 8];
-                const int j = K * lane + cbeg + ii;
+                const int j = K * bl + cbeg + ii;  // (lanes past the segment redo lane 0's samples: in-range values for the extremes)
                 const int lo = j - 4 > 0 ? j - 4 : 0;
                 const int hi = j + 5 < m ? j + 5 : m;
                 const int cnt = hi - lo > 1 ? (hi - lo < 10 ? hi - lo : 9) : 1;

@@ -1,4 +1,4 @@
-// Register/LDS merge-sort BCSD paths (sd_bcsd_fz.hip: one fused kernel per segment; sd_bcsd_rs.hip: the
+// Register-sort BCSD paths (sd_bcsd_fx.hip: one fused kernel per segment; sd_bcsd_rs.hip: the
 // RANK / APPLY / FIT kernels): parameters and launchers.
 #pragma once
 #include "sd_internal.h"
@@ -32,7 +32,7 @@ struct Params {
     unsigned long long gmask;
     int slab_nr, slab_k;
     // Work list of (tile, group) items = tile * G + group.  The fused kernel appends the items it cannot serve
-    // (near-equal shifted samples, see sd_bcsd_fz.hip); RANK / APPLY launched with use_worklist walk the list with a
+    // (tied samples, see sd_bcsd_fx.hip); RANK / APPLY launched with use_worklist walk the list with a
     // fixed grid instead of covering every (tile, group).
     int64_t* worklist;
     int* work_count;  // device counter (items appended, may exceed work_cap: the excess is lost and reported)
@@ -50,7 +50,6 @@ struct Params {
 }  // namespace sdrs
 
 bool sd_bcsd_rs_supported(int nmax);
-bool sd_bcsd_fz_supported(int nmax);
 int sd_bcsd_rs_width(int nmax);  // samples per lane (K) of the kernels serving segments of up to nmax samples
 int sd_bcsd_rs_row_stride(int nmax);
 // workspace bytes of the RANK -> APPLY hand-off slabs (both multiples of 256)
@@ -59,9 +58,8 @@ void sd_bcsd_rs_handoff_bytes(int nmax, int64_t C, int G, size_t* rank_bytes, si
 // kernels but some groups fit 19 samples per lane (30-day months of a daily series), those groups get their own launch
 // of the narrower, ~10 % cheaper kernels.
 int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax, const int* group_len = nullptr);
-// BcsdTemperature fused kernel (sd_bcsd_fz.hip): x side, y side, inverse CDF and shift of a segment in one workgroup
-// pass; segments it cannot serve are appended to p.worklist (the caller then runs RANK + APPLY with use_worklist).
-int sd_bcsd_fz_launch(sd_ctx* ctx, const sdrs::Params& p, int nmax, const int* group_len = nullptr);
-// round 4: the same contract on the register-resident 32-bit key sort of sd_wsort.h (sd_bcsd_fx.hip), segments <= 1 536
+// Fused kernels (sd_bcsd_fx.hip; BcsdTemperature and BcsdPrecipitation, segments of up to 1 536 samples): x side, y side,
+// inverse CDF and shift / ratio of a segment in one workgroup pass on the register-resident 32-bit key sort of sd_wsort.h;
+// segments they cannot serve are appended to p.worklist (the caller then runs RANK + APPLY with use_worklist).
 bool sd_bcsd_fx_supported(int nmax);
 int sd_bcsd_fx_launch(sd_ctx* ctx, const sdrs::Params& p, int nmax, const int* group_len = nullptr);

@@ -12,8 +12,9 @@
 //               have equal lengths, else the precomputed index + weight table with OLS tails); the x_fut tile is
 //               read a second time to rebuild the shift; the result goes out transposed.
 //   MODE_FIT    the y side alone, writing the fitted state.
-// They serve BcsdPrecipitation (zero-inflated: ranks among exact ties need the search), every fit that keeps a
-// state, and the BcsdTemperature segments the fused kernel of sd_bcsd_fz.hip hands back through its work list.
+// They serve every fit that keeps a state, QuantileMapper(detrend=True), segments of 1 537 .. 2 112 samples, and the
+// segments the fused kernels of sd_bcsd_fx.hip hand back through their work list (exact ties: the search gives the
+// largest rank among them).
 // Sort and tile helpers: sd_wave.h / sd_sortnet.h.
 #include "sd_bcsd_rs.h"
 #include "sd_wave.h"

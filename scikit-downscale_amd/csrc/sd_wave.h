@@ -1,5 +1,4 @@
-// Wave-level building blocks of the BCSD register/LDS merge-sort kernels (device code shared by sd_bcsd_rs.hip and
-// sd_bcsd_fz.hip): tile movement between time-major HBM fields and per-cell LDS rows, the per-wave merge sort, the
+// Wave-level building blocks of the BCSD kernels (device code shared by sd_bcsd_rs.hip and sd_bcsd_fx.hip): tile movement between time-major HBM fields and per-cell LDS rows, the per-wave merge sort, the
 // 9-sample rolling mean (bcsd.py:247-250) and the Cunnane plotting-position helpers (quantile.py:23-43).
 #pragma once
 #include "sd_internal.h"

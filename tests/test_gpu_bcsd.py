@@ -134,9 +134,8 @@ def test_every_register_sort_width_split_and_fused(ctx, kind, T, Tp, C):
 def test_fused_kernel_variants_agree_bit_for_bit(dev_ctx, monkeypatch):
     """BcsdTemperature takes the fused kernel (ranks read off position tags carried through the sort).  The
     development library can switch it off (SD_BCSD_FUSED=0: RANK + APPLY with the explicit rank search for every
-    segment) or let it park the shift in a workspace slab (SD_FZ_SLAB=1) instead of re-reading x_fut: same
-    arithmetic, so all three must agree bit for bit -- fused entry point and predict from a state, equal and unequal
-    segment lengths (identity / table + tail paths), every kernel width."""
+    segment): same arithmetic up to the order of one sum, so the two must agree to 1e-13 -- fused entry point and
+    predict from a state, equal and unequal segment lengths (identity / table + tail paths), every kernel width."""
     ctx = dev_ctx
     rng = np.random.default_rng(11)
     for T, Tp, C in ((365, 365, 6), (3650, 3650, 9), (14600, 14600, 8), (14600, 20000, 5), (14600, 3000, 3), (9000, 8000, 11)):
@@ -146,7 +145,7 @@ def test_fused_kernel_variants_agree_bit_for_bit(dev_ctx, monkeypatch):
         gid, gid_p = month_gid(index), month_gid(index_p)
         dX, dy, dXp = ctx.to_device(X), ctx.to_device(y), ctx.to_device(Xp)
         res = {}
-        for name, env in (("fused", {}), ("slab", {"SD_FZ_SLAB": "1"}), ("search", {"SD_BCSD_FUSED": "0"})):
+        for name, env in (("fused", {}), ("search", {"SD_BCSD_FUSED": "0"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             a, sa = ctx.bcsd_fit_predict(0, dX, dy, gid, 12, dXp, gid_p)
@@ -158,7 +157,6 @@ def test_fused_kernel_variants_agree_bit_for_bit(dev_ctx, monkeypatch):
                 monkeypatch.delenv(k)
         # The fused kernel (sd_bcsd_fx.hip) sums the y_obs climatology over blocks of 20 samples per lane, RANK / APPLY
         # over blocks of 21 (19, 13, 5): the two paths agree to the last bits of that one mean, not bit for bit.
-        assert np.array_equal(res["fused"][0], res["slab"][0]) and np.array_equal(res["fused"][1], res["slab"][1]), (T, Tp)
         for k in (0, 1):
             assert_close(res["fused"][k], res["search"][k], rtol=1e-13, what=f"fused vs search {T}->{Tp}")
         assert_close(res["fused"][0], res["fused"][1], rtol=1e-13, what=f"fit+predict vs predict from state {T}->{Tp}")
