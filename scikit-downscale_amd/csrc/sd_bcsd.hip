@@ -297,11 +297,10 @@ __global__ void __launch_bounds__(256) status_public_kernel(const int32_t* __res
                                                             int64_t C, int32_t* __restrict__ outp) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) {
-        const int32_t bits = a[c] | (b ? b[c] : 0);
-        int32_t code = SD_CELL_OK;
-        if (bits & SDI_MASKED) code = SD_CELL_MASKED;
-        else if (bits & SDI_NONFINITE) code = SD_CELL_NONFINITE;
-        else if (bits & SDI_BAD_CLIMO) code = SD_CELL_BAD_CLIMO;
+        // a = what fit found, b = what predict found: the reference raises in fit first (base.py:18-20, then bcsd.py:140-141),
+        // so a cell with a bad climatology AND a non-finite predict sample reports the climatology
+        int32_t code = sd_public_status(a[c]);
+        if (code == SD_CELL_OK && b) code = sd_public_status(b[c]);
         outp[c] = code;
     }
 }

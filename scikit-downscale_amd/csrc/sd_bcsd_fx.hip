@@ -327,15 +327,14 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
                 const int idx = cbeg - 4 + t;  // sample K*bl + idx
                 w[t] = idx < 0 ? pb[idx] : idx >= K ? nb[idx - K] : ob[idx];
             }
-            // nine-sample window sums by shared partial sums (pairs, fours, eights): 4 additions per sample instead of 8
-            double p2[CH + 7], p4[CH + 5];
-#pragma unroll
-            for (int t = 0; t < CH + 7; ++t) p2[t] = w[t] + w[t + 1];
-#pragma unroll
-            for (int t = 0; t < CH + 5; ++t) p4[t] = p2[t] + p2[t + 2];
 #pragma unroll
             for (int ii = 0; ii < CH; ++ii) {
-                const double s = (p4[ii] + p4[ii + 4]) + w[ii + 8];
+                // the nine samples are added in time order, like the oracle and the RANK kernel do: samples whose shifted values
+                // are one ulp apart then rank the same way on every path (sharing partial sums between windows would save four
+                // additions per sample and decide such pairs differently)
+                double s = 0.0;
+#pragma unroll
+                for (int d = 0; d < 9; ++d) s += w[ii + d];
                 const int j = K * bl + cbeg + ii;  // (lanes past the segment redo lane 0's samples: in-range values for the extremes)
                 const int lo = j - 4 > 0 ? j - 4 : 0;
                 const int hi = j + 5 < m ? j + 5 : m;
