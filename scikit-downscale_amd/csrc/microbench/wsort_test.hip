@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(512, 4) sort_kernel(unsigned* keys, int nseg, 
         if (r > 0) {
             // scramble again (bijection on the keys, so they stay distinct)
 #pragma unroll
-            for (int i = 0; i < K; ++i) k[i] = (k[i] * 2654435761u) ^ 0x5bd1e995u;
+            for (int i = 0; i < K; ++i) k[i] = (k[i] * 2654435761u) ^ 0x5bd1e995u;  // (timing loop only)
         }
         sdws::wave_sort<K>(k, lane, lanes_used);
     }
@@ -46,7 +46,7 @@ int run(int nseg, int reps) {
     unsigned s = 12345u + K;
     for (size_t i = 0; i < n; ++i) {
         s = s * 1664525u + 1013904223u;
-        h[i] = (s >> 4) ^ (unsigned)(i * 2654435761u);
+        h[i] = ((s >> 4) ^ (unsigned)(i * 2654435761u)) & 0x7fffffffu;  // below the pads of the partly used waves
     }
     unsigned* d;
     CK(hipMalloc(&d, n * 4));

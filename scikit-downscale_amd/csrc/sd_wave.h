@@ -147,7 +147,6 @@ __device__ __forceinline__ void merge_rounds(double* row, int np, int lane, doub
             const bool ok = (t <= hi_addr) && (lds_f64(t) <= lds_f64(S - t));
             pos = ok ? t : pos;
         }
-        __builtin_amdgcn_s_setprio(3);
         const int lo = (int)(pos - am8) >> 3;
         const int inext = __shfl_down(lo, 1, kWave);
         const int ihi = (d + K >= LA + LB) ? LA : inext;  // co-rank of the end of this lane's window
@@ -161,7 +160,9 @@ __device__ __forceinline__ void merge_rounds(double* row, int np, int lane, doub
                 w[s] = src[s];
                 if (s % 7 == 6) __builtin_amdgcn_sched_barrier(0);  // issue the loads in batches
             }
-            __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_s_setprio(0);  // (outside the divergent region: every wave drops back, busy lanes or not)
+        if (busy) {
 #pragma unroll
             for (int c = 0; c < net.n; ++c) {
                 const double mn = vmin(w[net.a[c]], w[net.b[c]]);
