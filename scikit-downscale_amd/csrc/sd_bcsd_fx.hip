@@ -116,6 +116,26 @@ __device__ __forceinline__ void store_tile_sw(double* __restrict__ dst, int64_t 
     }
 }
 
+// non-finite samples of an issued tile -> per-cell status (BcsdPrecipitation only validates x_hist: bcsd.py:130-147): no sums,
+// no exchange, no barrier of its own -- the flags are read behind the barrier that follows the x_fut commit
+template <int RPT>
+__device__ __forceinline__ void tile_check_finite(const TileRegs<RPT>& t, int nrows, int64_t c0, int64_t C, int32_t* status, int* bad_cell) {
+    const int tid = tid_now();
+    const int cp = tid & 3, rr = tid >> 2;
+    const int64_t c = c0 + 2 * cp;
+    bool bad0 = false, bad1 = false;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const bool in = rr + k * kRowsPerPass < nrows;
+        bad0 |= in && !finite64(t.v0[k]);
+        bad1 |= in && !finite64(t.v1[k]);
+    }
+    if (bad0 && c < C) atomicOr(&status[c], SDI_NONFINITE);
+    if (bad1 && c + 1 < C) atomicOr(&status[c + 1], SDI_NONFINITE);
+    if (bad0) bad_cell[2 * cp] = 1;
+    if (bad1) bad_cell[2 * cp + 1] = 1;
+}
+
 // ---- wave reductions --------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_min_f64(double v) {
 #pragma unroll
@@ -546,13 +566,12 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
 
     // ---- x side: validation of x_hist, the x_fut tile ------------------------------------------------------------------
     {
-        SD_LANE();
         TileRegs<NR> xf;
         if (!p->from_state && p->X != nullptr && n > 0) {
             TileRegs<NR> xh;
             tile_issue<NR>(p->X, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, xh);
             tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
-            (void)tile_reduce_mean<NR>(xh, n, c0, p->C, scratch, p->status_fit, wave, lane, bad_cell);  // non-finite samples -> status
+            tile_check_finite<NR>(xh, n, c0, p->C, p->status_fit, bad_cell);
         } else {
             tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
         }
