@@ -15,6 +15,9 @@
 
 #include <cstring>
 
+#include <chrono>
+#include <thread>
+
 #include "sd_bcsd_rs.h"
 #include "sd_internal.h"
 #include "sd_sortnet.h"
@@ -1202,19 +1205,78 @@ int sd_bcsd_fit(sd_ctx* ctx, int kind, const double* X, const double* y, const i
     return sd_bcsd_fit_dev(ctx, kind, dX.as<double>(), dy.as<double>(), C, group_id, G, T, C, return_anoms, out);
 }
 
+// Host-buffer predict.  Large grids go through in blocks of cells, pipelined over the two directions of the PCIe link: while the
+// kernels of block i run and block i - 1 of the result drains to the host (a second host thread, ring and stream:
+// sd_copy_d2h_2d), block i + 1 of X comes in.  A block of cells is a column block of the row-major fields and a slice of the
+// cell-major state.
 int sd_bcsd_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, const int32_t* group_id_p, int64_t Tp,
                     double* out, int32_t* cell_status) {
     SD_CHECK_ARG(ctx && st && Xp && group_id_p && out, "sd_bcsd_predict: NULL argument");
     SD_CHECK_ARG(Tp > 0, "sd_bcsd_predict: bad sizes");
     SD_HIP(hipSetDevice(ctx->device));
-    sd_scratch dX, dout;
-    const size_t bytes = sizeof(double) * (size_t)Tp * (size_t)st->C;
-    SD_HIP(dX.alloc(ctx, bytes));
-    SD_HIP(dout.alloc(ctx, bytes));
-    SD_TRY(sd_copy_h2d(ctx, dX.p, Xp, bytes));
-    SD_TRY(sd_bcsd_predict_dev(ctx, st, dX.as<double>(), st->C, group_id_p, Tp, dout.as<double>(), st->C, cell_status));
-    SD_TRY(sd_copy_d2h(ctx, out, dout.p, bytes));
+    const int64_t C = st->C;
+    const size_t bytes = sizeof(double) * (size_t)Tp * (size_t)C;
+    const int nblk = (bytes >= ((size_t)256 << 20) && C >= 1024) ? 4 : 1;
+    if (nblk == 1) {
+        sd_scratch dX, dout;
+        SD_HIP(dX.alloc(ctx, bytes));
+        SD_HIP(dout.alloc(ctx, bytes));
+        SD_TRY(sd_copy_h2d(ctx, dX.p, Xp, bytes));
+        SD_TRY(sd_bcsd_predict_dev(ctx, st, dX.as<double>(), C, group_id_p, Tp, dout.as<double>(), C, cell_status));
+        SD_TRY(sd_copy_d2h(ctx, out, dout.p, bytes));
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        return SD_OK;
+    }
+    sd_advise_result_buffer(out, bytes);
+    const size_t pitch = sizeof(double) * (size_t)C;
+    const int64_t per = ((C + nblk - 1) / nblk + 7) / 8 * 8;  // blocks of whole tiles
+    // packed [Tp, cells of the block] device buffers: the transfers are linear, the kernels take the block's width as pitch
+    sd_scratch dX, dout[2];
+    SD_HIP(dX.alloc(ctx, sizeof(double) * (size_t)Tp * (size_t)per));
+    SD_HIP(dout[0].alloc(ctx, sizeof(double) * (size_t)Tp * (size_t)per));
+    SD_HIP(dout[1].alloc(ctx, sizeof(double) * (size_t)Tp * (size_t)per));
+    std::thread drain;
+    int drain_rc = SD_OK;
+    std::string drain_err;
+    int rc = SD_OK;
+    int blk = 0;
+    for (int64_t c0 = 0; c0 < C && rc == SD_OK; c0 += per, ++blk) {
+        const int64_t cw = std::min(per, C - c0);
+        const size_t width = sizeof(double) * (size_t)cw;
+        const auto t_a = std::chrono::steady_clock::now();
+        rc = sd_copy_h2d_2d(ctx, dX.p, width, Xp + c0, pitch, width, (size_t)Tp);
+        if (rc != SD_OK) break;
+        const auto t_b = std::chrono::steady_clock::now();
+        sd_bcsd_state view = *st;  // the block's slice of the state (cell-major arrays; nothing owned)
+        view.C = cw;
+        view.ys = st->ys + c0 * st->T;
+        if (st->x_climo) view.x_climo = st->x_climo + c0 * st->G;
+        if (st->y_climo) view.y_climo = st->y_climo + c0 * st->G;
+        if (st->y_trend) view.y_trend = st->y_trend + c0 * st->G * 2;
+        view.status = st->status + c0;
+        if (blk >= 2 && drain.joinable()) drain.join();  // the drain of block blk - 2 used this result buffer (joined below anyway)
+        double* res = dout[blk & 1].as<double>();
+        rc = sd_bcsd_predict_dev(ctx, &view, dX.as<double>(), cw, group_id_p, Tp, res, cw,
+                                 cell_status ? cell_status + c0 : nullptr);  // (returns when the block's kernels are done)
+        if (rc != SD_OK) break;
+        const auto t_c = std::chrono::steady_clock::now();
+        if (drain.joinable()) drain.join();
+        const auto t_d = std::chrono::steady_clock::now();
+        if (sd_dev_env("SD_TRACE_PIPE")) {
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "block %d: h2d %.2f ms, predict %.2f ms, wait for previous drain %.2f ms\n", blk, ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d));
+        }
+        if (drain_rc != SD_OK) break;
+        double* dst = out + c0;
+        drain = std::thread([=, &drain_rc, &drain_err]() {
+            drain_rc = sd_copy_d2h_2d(ctx, dst, pitch, res, width, width, (size_t)Tp);
+            if (drain_rc != SD_OK) drain_err = sd_last_error();  // (the message is thread-local)
+        });
+    }
+    if (drain.joinable()) drain.join();
     SD_HIP(hipStreamSynchronize(ctx->stream));
+    if (rc != SD_OK) return rc;
+    if (drain_rc != SD_OK) return sd_set_error(drain_rc, "%s", drain_err.c_str());
     return SD_OK;
 }
 

@@ -73,6 +73,11 @@ struct sd_ctx {
     hipEvent_t stage_ev[kStageBufs] = {nullptr, nullptr, nullptr};
     hipEvent_t stage_join = nullptr;
     hipStream_t copy_stream = nullptr;
+    // a second, smaller ring + stream for results going back to the host while the next inputs come in (sd_copy_d2h_2d)
+    static constexpr int kDrainBufs = 2;
+    void* drain[kDrainBufs] = {nullptr, nullptr};
+    hipEvent_t drain_ev[kDrainBufs] = {nullptr, nullptr};
+    hipStream_t drain_stream = nullptr;
 };
 void sd_gt_cache_clear(sd_ctx* ctx);
 // Large host <-> device copies of the host-buffer entry points.  Pageable host memory goes through a ring of pinned
@@ -82,6 +87,11 @@ void sd_gt_cache_clear(sd_ctx* ctx);
 // sd_copy_d2h: ordered behind the work already queued on ctx->stream; returns when the host buffer is complete.
 int sd_copy_h2d(sd_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int sd_copy_d2h(sd_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+// Column blocks of row-major fields ([rows] x width bytes, pitches in bytes), through the same kind of pinned rings.
+// sd_copy_h2d_2d: like sd_copy_h2d.  sd_copy_d2h_2d: the source must be complete (no stream ordering); it runs on a ring and a
+// stream of its own, so that it can be called from a second host thread while the first one uploads the next block.
+int sd_copy_h2d_2d(sd_ctx* ctx, void* dst_dev, size_t dpitch, const void* src_host, size_t spitch, size_t width, size_t rows);
+int sd_copy_d2h_2d(sd_ctx* ctx, void* dst_host, size_t dpitch, const void* src_dev, size_t spitch, size_t width, size_t rows);
 // asks for transparent huge pages on the 2 MB-aligned interior of a host range that is about to be written for the first
 // time (a fresh result array; NumPy does the same for its own large allocations): first-touch faults of 4 KB pages cap a
 // copy at ~14 GB/s on the GPU box, of huge pages at > 100 GB/s (csrc/microbench/pcie_rate.hip)

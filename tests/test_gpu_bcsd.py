@@ -596,6 +596,35 @@ def test_full_size_grid_is_consistent(ctx):
     out.free()
 
 
+@pytest.mark.parametrize("kind", [0, 1])
+def test_host_predict_in_cell_blocks_matches_resident(ctx, kind):
+    """Host-buffer predict of a grid large enough (>= 256 MB per field) to go through sd_bcsd_predict's pipeline: four blocks
+    of cells, each uploaded (2-D staged copy), predicted on its slice of the fitted state and drained by a second host thread
+    while the next block comes in.  Must equal the resident path bit for bit, ragged last block, masked and non-finite
+    cells (per-block status slices) included."""
+    rng = np.random.default_rng(5 + kind)
+    T, C = 14600, 2308  # 4 blocks of 584, 584, 584, 556 cells
+    index = pd.date_range("1980-01-01", periods=T, freq="D")
+    gid = month_gid(index)
+    if kind == 0:
+        X, y, Xp = (15 + 8 * rng.standard_normal((T, C)) for _ in range(3))
+    else:
+        X, y, Xp = (rng.gamma(0.7, 4.0, (T, C)) * (rng.random((T, C)) > 0.5) for _ in range(3))
+        y = y + 0.01
+    X[0, 700] = np.nan       # masked cell (block 1)
+    Xp[1234, 2300] = np.inf  # non-finite predict sample (last block)
+    st = ctx.bcsd_fit(kind, X, y, gid, 12, True)
+    out_h, st_h = ctx.bcsd_predict(st, Xp, gid)                 # host buffers: the pipeline
+    out_d, st_d = ctx.bcsd_predict(st, ctx.to_device(Xp), gid)  # resident
+    assert np.array_equal(st_h, st_d) and st_h[700] != 0 and st_h[2300] != 0 and (np.delete(st_h, [700, 2300]) == 0).all()
+    got, ref = out_h, out_d.to_host()
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(got[:, 700]).all() and np.isnan(got[:, 2300]).all()
+    ok = ~np.isnan(ref)
+    assert np.array_equal(got[ok], ref[ok])
+    exp, _ = bo.pointwise_fit_predict(kind, X[:, :3], y[:, :3], Xp[:, :3], gid, gid)
+    assert_close(got[:, :3], exp, what=f"host pipeline kind={kind}")
+
+
 def test_full_size_precipitation_grid_is_consistent(ctx):
     """BASELINE config 3 size (BcsdPrecipitation, 250 000 cells x 14 600 steps, zero-inflated) through the same
     size-independent property: identical 8 192-cell blocks must reproduce block 0 bit for bit wherever they land; the
