@@ -340,9 +340,11 @@ def pointwise_end_to_end(index, seed, c_full, n_cells=8192):
         model = PointWiseDownscaler(BcsdTemperature(return_anoms=True))
         model.fit(Xg, yg)
         res = model.predict(Xpg)
-        _ = np.asarray(res.values if hasattr(res, "values") else res)
+        field = np.asarray(res.values if hasattr(res, "values") else res)
         dt = time.perf_counter() - t0
-        del model, res
+        # (released outside the timed region, like `out` in end_to_end: until round 4 the rebinding of a throw-away name freed the
+        # previous pass's 1 GB result *inside* it -- 42 ms of munmap per pass, profiles/r04/prof_pointwise2.log)
+        del model, res, field
         if it >= 2:
             times.append(dt)
     med = sorted(times)[len(times) // 2]

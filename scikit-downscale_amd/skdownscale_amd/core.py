@@ -127,8 +127,14 @@ class LazyGridArray(GridArray):
         return self._full is not None
 
     def iter_blocks(self):
+        """(selection, GridArray) per spatial block.  Once ``values`` has assembled the field the blocks are views of it:
+        nothing is computed a second time."""
         for i, (sel, thunk) in enumerate(self._thunks):
-            if i == 0 and self._first is not None:
+            if self._full is not None:
+                idx = tuple(sel.get(d, slice(None)) for d in self.dims)
+                coords = {k: (np.asarray(v)[sel[k]] if k in sel else v) for k, v in self.coords.items()}
+                yield sel, GridArray(self._full[idx], self.dims, coords, self.name)
+            elif i == 0 and self._first is not None:
                 yield sel, self._first
             else:
                 yield sel, thunk()

@@ -729,6 +729,10 @@ def test_chunked_grids_and_attributes_on_the_engine():
     assert seen == 6 and not got.computed  # ... and nothing assembled until .values is asked for
     assert np.array_equal(np.isnan(got.values), np.isnan(expected.values)) and got.computed
     np.testing.assert_allclose(got.values[~np.isnan(got.values)], expected.values[~np.isnan(expected.values)], rtol=1e-12)
+    # ... after which the blocks are views of the assembled field: iterating again computes nothing
+    got._thunks = [(sel, lambda: (_ for _ in ()).throw(AssertionError("block computed twice"))) for sel, _ in got._thunks]
+    for sel, block in got.iter_blocks():
+        assert np.shares_memory(block.values, got.values)
     # attributes: scalars on the model grid, array-valued ones through a template (group axis first)
     n = whole.get_attr("n_features_in_", "int64")
     assert n.dims == ("y", "x") and n.values[0, 0] == 1
