@@ -65,6 +65,53 @@ int row_slots(int nmax) {
 
 __device__ __forceinline__ unsigned lds_u32(unsigned a) { return *reinterpret_cast<__attribute__((address_space(3))) unsigned*>((uintptr_t)a); }
 
+// ---- wave reductions ----------------------------------------------------------------------------------------------
+// In registers (DPP row shifts, then the two row broadcasts; the result is read off lane 63): six dependent steps of three
+// instructions each instead of six LDS round trips of ~130 clocks -- these reductions sit on the critical path of a
+// workgroup between two barriers.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double v) {  // lanes without a source (or masked out) keep their own value
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROWMASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane63_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+#define SD_DPP_REDUCE(OP)                        \
+    v = OP(v, dpp_f64<0x111, 0xF>(v)); /* row_shr:1 */  \
+    v = OP(v, dpp_f64<0x112, 0xF>(v)); /* row_shr:2 */  \
+    v = OP(v, dpp_f64<0x114, 0xF>(v)); /* row_shr:4 */  \
+    v = OP(v, dpp_f64<0x118, 0xF>(v)); /* row_shr:8 */  \
+    v = OP(v, dpp_f64<0x142, 0xA>(v)); /* row_bcast15 -> rows 1, 3 */ \
+    v = OP(v, dpp_f64<0x143, 0xC>(v)); /* row_bcast31 -> rows 2, 3 */ \
+    return lane63_f64(v)
+__device__ __forceinline__ double wave_min_f64(double v) { SD_DPP_REDUCE(vmin); }
+__device__ __forceinline__ double wave_max_f64(double v) { SD_DPP_REDUCE(vmax); }
+#undef SD_DPP_REDUCE
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp0_f64(double v) {  // lanes without a source (or masked out) read 0.0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {  // the same six steps; the sum of all 64 lanes, on every lane
+    v += dpp0_f64<0x111, 0xF>(v);
+    v += dpp0_f64<0x112, 0xF>(v);
+    v += dpp0_f64<0x114, 0xF>(v);
+    v += dpp0_f64<0x118, 0xF>(v);
+    v += dpp0_f64<0x142, 0xA>(v);
+    v += dpp0_f64<0x143, 0xC>(v);
+    return lane63_f64(v);
+}
+// the keys of the neighbouring lanes: wave shifts by one lane (lanes without a neighbour get `edge`)
+__device__ __forceinline__ unsigned from_next_lane(unsigned v, unsigned edge) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false);  // wave_shl:1: lane i <- lane i + 1
+}
+__device__ __forceinline__ unsigned from_prev_lane(unsigned v, unsigned edge) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xF, 0xF, false);  // wave_shr:1: lane i <- lane i - 1
+}
+
 // ---- tile movement with the swizzled row layout ---------------------------------------------------------------
 template <int RPT, int K>
 __device__ __forceinline__ void tile_commit_sw(const TileRegs<RPT>& t, int nrows, int64_t c0, int64_t C, double* tile, int RS,
@@ -116,6 +163,46 @@ __device__ __forceinline__ void store_tile_sw(double* __restrict__ dst, int64_t 
     }
 }
 
+// column sums of one group's rows for the 8 cells of the tile from issued tile registers, as far as one wave gets: the wave's
+// partial sums go to scratch[wave][cell]; the caller adds the 8 partials of its cell behind its next barrier (sd_wave.h's
+// tile_reduce_mean does the same with two barriers of its own)
+template <int RPT>
+__device__ __forceinline__ void tile_reduce_partials(const TileRegs<RPT>& t, int nrows, int64_t c0, int64_t C, double* scratch,
+                                                     int32_t* status, int wave, int lane, int* bad_cell) {
+    const int tid = tid_now();
+    const int cp = tid & 3, rr = tid >> 2;
+    const int64_t c = c0 + 2 * cp;
+    double s0 = 0.0, s1 = 0.0;
+    bool bad0 = false, bad1 = false;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const bool in = rr + k * kRowsPerPass < nrows;
+        bad0 |= in && !finite64(t.v0[k]);
+        bad1 |= in && !finite64(t.v1[k]);
+        s0 += in ? t.v0[k] : 0.0;
+        s1 += in ? t.v1[k] : 0.0;
+    }
+    if (bad0 && c < C) atomicOr(&status[c], SDI_NONFINITE);
+    if (bad1 && c + 1 < C) atomicOr(&status[c + 1], SDI_NONFINITE);
+    if (bad0) bad_cell[2 * cp] = 1;
+    if (bad1) bad_cell[2 * cp + 1] = 1;
+    // lanes with equal (lane & 3) hold the same cell pair: lanes l, l + 4, l + 8, l + 12 of a row by rotations of the row,
+    // the four rows through the LDS crossbar
+    s0 += dpp_f64<0x124, 0xF>(s0);  // row_ror:4
+    s1 += dpp_f64<0x124, 0xF>(s1);
+    s0 += dpp_f64<0x128, 0xF>(s0);  // row_ror:8
+    s1 += dpp_f64<0x128, 0xF>(s1);
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        s0 += __shfl_xor(s0, o, kWave);
+        s1 += __shfl_xor(s1, o, kWave);
+    }
+    if (lane < 4) {
+        scratch[wave * kW + 2 * lane] = s0;
+        scratch[wave * kW + 2 * lane + 1] = s1;
+    }
+}
+
 // non-finite samples of an issued tile -> per-cell status (BcsdPrecipitation only validates x_hist: bcsd.py:130-147): no sums,
 // no exchange, no barrier of its own -- the flags are read behind the barrier that follows the x_fut commit
 template <int RPT>
@@ -134,18 +221,6 @@ __device__ __forceinline__ void tile_check_finite(const TileRegs<RPT>& t, int nr
     if (bad1 && c + 1 < C) atomicOr(&status[c + 1], SDI_NONFINITE);
     if (bad0) bad_cell[2 * cp] = 1;
     if (bad1) bad_cell[2 * cp + 1] = 1;
-}
-
-// ---- wave reductions --------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_min_f64(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = vmin(v, __shfl_xor(v, o, kWave));
-    return v;
-}
-__device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = vmax(v, __shfl_xor(v, o, kWave));
-    return v;
 }
 
 // ---- keys ---------------------------------------------------------------------------------------------------------
@@ -205,7 +280,7 @@ __device__ __forceinline__ int fix_equal_q(unsigned (&k)[K], unsigned rowb, int 
     for (int pass = 0; pass < 6; ++pass) {
         bool swapped = false;
         // the pair (last key of lane l, first key of lane l + 1) first, on both lanes' values as the pass finds them
-        const unsigned knext = lane < 63 ? (unsigned)__shfl_down((int)k[0], 1, kWave) : 0xffffffffu;
+        const unsigned knext = from_next_lane(k[0], 0xffffffffu);
         const bool eqx = (k[K - 1] ^ knext) < kQ && (!ZC || k[K - 1] >= kQ);
         const unsigned long long bx = __ballot(eqx);
         if (bx != 0ull) {  // wave-uniform, rare
@@ -215,8 +290,7 @@ __device__ __forceinline__ int fix_equal_q(unsigned (&k)[K], unsigned rowb, int 
             tie |= eqx && va == vb;
             const unsigned d = sw ? (k[K - 1] ^ knext) : 0u;  // equal q: the xor exchanges the tags
             k[K - 1] ^= d;
-            const unsigned din = (unsigned)__shfl_up((int)d, 1, kWave);
-            if (lane > 0) k[0] ^= din;
+            k[0] ^= from_prev_lane(d, 0u);
             swapped |= sw;
         }
         // pairs inside the lane, in ascending order
@@ -305,6 +379,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
 
     // ---- x climatology (bcsd.py:222) + the x_fut tile ---------------------------------------------------
     double xc = 0.0;
+    bool xc_from_partials = false;  // (workgroup-uniform)
     {
         SD_LANE();
         TileRegs<NR> xf;
@@ -315,7 +390,8 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
             TileRegs<NR> xh;
             tile_issue<NR>(p->X, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, xh);
             if (!(abl & 64)) tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
-            xc = tile_reduce_mean<NR>(xh, n, c0, p->C, scratch, p->status_fit, wave, lane, bad_cell);
+            tile_reduce_partials<NR>(xh, n, c0, p->C, scratch, p->status_fit, wave, lane, bad_cell);
+            xc_from_partials = true;
         } else if (!(abl & 64)) {
             tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
         }
@@ -326,6 +402,12 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
         }
     }
     __syncthreads();
+    if (xc_from_partials) {  // x_climo (bcsd.py:222): the waves' partial column sums, in wave order
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < kW; ++w) tot += scratch[w * kW + wave];  // wave <-> cell c0 + wave
+        xc = tot / (double)n;
+    }
 
     // ---- shift (kept), shifted series -> row, keys -> sort ------------------------------------------------
     double shift[K];
@@ -419,7 +501,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
                 double s = 0.0;
 #pragma unroll
                 for (int i = 0; i < K; ++i) s += K * lane + i < n ? v[i] : 0.0;
-                yc = wave_sum(s) / (double)n;  // bcsd.py:223
+                yc = wave_sum_f64(s) / (double)n;  // bcsd.py:223
                 make_keys<K>(v, n, lane, ky);
             }
             if (!(abl & 2)) sdws::wave_sort<K>(ky, lane, (n + K - 1) / K);
@@ -627,7 +709,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
                 double s = 0.0;
 #pragma unroll
                 for (int i = 0; i < K; ++i) s += K * lane + i < n ? v[i] : 0.0;
-                yc = wave_sum(s) / (double)n;  // bcsd.py:138
+                yc = wave_sum_f64(s) / (double)n;  // bcsd.py:138
                 if (lane == 0 && cell_ok && p->return_anoms && yc <= 0.0) atomicOr(&p->status_fit[c], SDI_BAD_CLIMO);  // bcsd.py:140-141
                 const double lo = make_keys<K, true>(v, n, lane, ky);
                 redo_y = lo < 0.0 && cell_live;
