@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SD_VERSION 102  /* bump on every change of an exported signature: the Python loader refuses other versions */
+#define SD_VERSION 103  /* bump on every change of an exported signature: the Python loader refuses other versions */
 
 /* return codes */
 #define SD_OK 0
@@ -181,6 +181,16 @@ int sd_bcsd_state_import(sd_ctx* ctx, int kind, int G, int64_t T, int64_t C, int
 /* SD_BCSD_QM_DETREND states: slope and intercept of the fitted segments' lines, [C][G][2] (x_trend_fit_.lr_model_.coef_ /
  * .intercept_ of every group's QuantileMapper, quantile.py:97,145).  set_trend completes a state made by
  * sd_bcsd_state_import (only the intercepts enter predictions). */
+/* Tail handling of the fitted inverse CDF (qm_kwargs={'qt_kwargs': {'extrapolate': ..., 'n_endpoints': ...}}: bcsd.py:59-67 ->
+ * quantile.py:418-431, 523-545): which side continues along the least-squares line through the first / last n_endpoints
+ * points of the fitted CDF (SD_QT_TAIL_LOWER | SD_QT_TAIL_UPPER = 'both', the default; 'min' = lower only, 'max' = upper only,
+ * None / '1to1' = neither: np.interp then holds the end value), and n_endpoints >= 1 (default 10).  Reaches predictions only when
+ * a predict group is longer than its fit group.  Applies to later sd_bcsd_predict* calls on the state; group segments of up to
+ * 2 112 samples (SD_ERR_UNSUPPORTED beyond for non-default settings).  (`alpha` / `beta` of the CunnaneTransformer never reach
+ * the result in the reference -- quantile.py:462 calls plotting_positions(n) with its defaults -- and have no entry here.) */
+#define SD_QT_TAIL_LOWER 1
+#define SD_QT_TAIL_UPPER 2
+int sd_bcsd_state_set_tails(sd_bcsd_state* st, int extrapolate, int n_endpoints);
 int sd_bcsd_state_get_trend(const sd_bcsd_state* st, double* y_trend);
 int sd_bcsd_state_set_trend(sd_bcsd_state* st, const double* y_trend);
 int sd_bcsd_state_destroy(sd_bcsd_state* st);
@@ -200,6 +210,16 @@ int sd_analog_predict(sd_ctx* ctx, const sd_analog_state* st, const double* Xq, 
 int sd_analog_predict_dev(sd_ctx* ctx, const sd_analog_state* st, const double* Xq_dev, int64_t ld, int64_t Tq, int k,
                           int kind, int has_thresh, double thresh, const int32_t* sample_inds_dev, double* out_dev,
                           int64_t ld_out, int64_t* inds_dev, double* dist_dev, int32_t* cell_status);
+/* fit + predict in one call, no fitted state left behind (AnalogBase.fit, gard.py:58-87, followed by PureAnalog.predict,
+ * gard.py:273-364, on the same object): for callers that drop the estimator after predicting.  Results are bit-identical to
+ * sd_analog_fit* -> sd_analog_predict*; F == 1, `SD_ANALOG_MEAN` without a threshold (or k == 1) on series the tile-shaped fit
+ * serves run as one fused per-cell kernel, everything else takes the two calls internally.  SD_ANALOG_SAMPLE is not served
+ * (it needs sample_inds: use the split calls). */
+int sd_analog_fit_predict(sd_ctx* ctx, const double* X, const double* y, int64_t T, int F, int64_t C, const double* Xq, int64_t Tq,
+                          int k, int kind, int has_thresh, double thresh, double* out, int32_t* cell_status);
+int sd_analog_fit_predict_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t ld, int64_t T, int F, int64_t C,
+                              const double* Xq_dev, int64_t ld_q, int64_t Tq, int k, int kind, int has_thresh, double thresh,
+                              double* out_dev, int64_t ld_out, int32_t* cell_status);
 /* AnalogRegression.predict (gard.py:152-224).  has_thresh: exceedance_prob from a logistic regression of (analog value >
  * thresh) on the analogs' features (the reference reports predict_proba(x)[0, 0], the probability of NOT exceeding;
  * 1.0 when every analog exceeds), linear model and RMSE on the exceeding analogs; a query without any exceeding analog

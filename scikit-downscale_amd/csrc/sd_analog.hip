@@ -1971,6 +1971,333 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// fit + predict of the BASELINE case in one kernel (sd_analog_fit_predict_dev: gard.py:58-87 with 273-364 on the same call)
+// ------------------------------------------------------------------------------------------------
+// The per-cell workgroup that has merged the sorted runs of analog_tile_sort_kernel answers the cell's queries before it
+// leaves: the tail of analog_sort2_kernel<K, true> followed by analog_f1_mean3_kernel, with the sorted view handed over on
+// chip.  No fitted state exists: xs / xi / yx (20 bytes written and 16 read back per training sample) never travel.  The
+// tags of the sorted keys (= xi) are parked in LDS behind the key array; x and y are gathered through them twice, once into
+// the sorted order of each.  Arithmetic, summation orders and the window search are those of the two kernels, so the result
+// is bit-identical to fit -> predict.  Cells the fast paths cannot decide -- the tag pass fails (equal or nearly equal
+// training values), or a query's window is not strictly separated (the exact walk needs xi and the unsorted copies) -- are
+// appended to `worklist`; the host answers them with the split path.  Pointers are relative to the chunk of cells of this
+// launch, `cell0` is the grid index of its first cell.
+template <int K>
+__global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __restrict__ runs, int np,
+                                                               const int32_t* __restrict__ odd_flags,
+                                                               const double* __restrict__ Xc, const double* __restrict__ yc,
+                                                               const double* __restrict__ Xq /* [C][Tq] */, int64_t Tq, int64_t T,
+                                                               int64_t C, const int32_t* __restrict__ fit_status, int32_t* status,
+                                                               int32_t* worklist, int32_t* work_count, int64_t cell0,
+                                                               PredictArgs pa, int skip_prob) {
+    constexpr int PER = K;  // consecutive samples per thread in the prefix sums: ceil(n / 1024) <= K
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ double wsum[16];
+    double* buf = reinterpret_cast<double*>(smem_raw);          // np + 1 doubles
+    int* xch = reinterpret_cast<int*>(buf + np + 1);            // 1025 ints (co-ranks of the merge rounds; reduction scratch)
+    double* red = reinterpret_cast<double*>(xch);
+    unsigned short* tagl = reinterpret_cast<unsigned short*>(xch + 1026);  // n tags: training index of the sorted position
+    const int nthr = blockDim.x;
+    const int n = (int)T, k = pa.k;
+    const int per = (n + nthr - 1) / nthr;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+#define SD_TID()                                        \
+    int tid = (int)threadIdx.x;                         \
+    asm volatile("" : "+v"(tid));                       \
+    const int lane = tid & 63, wave = tid >> 6;         \
+    (void)lane;                                         \
+    (void)wave
+#define SD_LW(i) ((int)(((i) & 1) ? (Lw2[(i) >> 1] >> 16) : (Lw2[(i) >> 1] & 0xffffu)))
+    const double kk = uniform_f64((double)k), rk = uniform_f64(1.0 / (double)k);
+    const int M = n - k > 0 ? n - k : 0;
+    int nsteps = 0;
+    while ((1 << nsteps) < (k + 1 < M + 1 ? k + 1 : M + 1)) ++nsteps;
+    int64_t step, end;
+    for (int64_t c = first_cell(C, &step, &end); c < end; c += step) {
+        global_f64* const orow = (global_f64*)(pa.out + c * 3 * pa.oc_Tq);  // (uniform) staging rows: predictions, probabilities, spreads
+        global_f64* const prow = orow + pa.oc_Tq;
+        global_f64* const erow = prow + pa.oc_Tq;
+        if (fit_status[c] != 0) {
+            // masked / non-finite training series: every query answers NaN (what the query phase below does for such a cell)
+            for (int j = (int)threadIdx.x; j < (int)Tq; j += nthr) {
+                orow[j] = nan;
+                erow[j] = nan;
+                if (!skip_prob || k == 1) prow[j] = nan;
+            }
+            continue;
+        }
+        // ---- the sorted runs of 64 * K tagged keys -> merge rounds 6 .. (analog_sort2_kernel<K, true>)
+        __syncthreads();
+        {
+            SD_TID();
+            const double* rc = runs + c * (int64_t)np;
+            double kv[K + 1];
+#pragma unroll
+            for (int t2 = 0; t2 <= K; ++t2) {
+                const int i = tid + t2 * nthr;
+                kv[t2] = i < np ? rc[i] : inf;
+            }
+#pragma unroll
+            for (int t2 = 0; t2 <= K; ++t2) {
+                const int i = tid + t2 * nthr;
+                if (i <= np) buf[i] = kv[t2];
+            }
+        }
+        __syncthreads();
+        {
+            SD_TID();
+            sdsort::block_merge_rounds<K>(buf, np, xch, tid, nthr, 6);
+            bool odd = odd_flags[c] != 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = K * tid + i;
+                if (j + 1 < n) odd |= ((__double_as_longlong(buf[j]) ^ __double_as_longlong(buf[j + 1])) >> 14) == 0;
+            }
+            if (__syncthreads_or(odd) != 0) {
+                if (tid == 0) worklist[atomicAdd(work_count, 1)] = (int32_t)(cell0 + c);
+                continue;
+            }
+            // tags -> LDS; x in training order -> buf; gathered through the tags -> registers -> buf = xs
+#pragma unroll
+            for (int s2 = 0; s2 < K; ++s2) {
+                const int pos = tid + s2 * nthr;
+                if (pos < n) tagl[pos] = (unsigned short)(__double_as_longlong(buf[pos]) & kTagMask);
+            }
+            __syncthreads();
+            const double* x = Xc + c * T;
+            double xv[K];
+#pragma unroll
+            for (int s2 = 0; s2 < K; ++s2) {
+                const int pos = tid + s2 * nthr;
+                xv[s2] = pos < n ? x[pos] : 0.0;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < K; ++s2) {
+                const int pos = tid + s2 * nthr;
+                if (pos < n) buf[pos] = sd_finite(xv[s2]) ? xv[s2] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s2 = 0; s2 < K; ++s2) {
+                const int pos = tid + s2 * nthr;
+                xv[s2] = pos < n ? buf[tagl[pos]] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s2 = 0; s2 < K; ++s2) {
+                const int pos = tid + s2 * nthr;
+                if (pos < n) buf[pos] = xv[s2];
+            }
+            if (tid == 0) buf[n] = inf;
+        }
+        __syncthreads();
+        // ---- generation 1 (analog_f1_mean3_kernel): sorted training values -> window start of every query
+        SD_TID();
+        const double* qrow = Xq + c * Tq;
+        const int nq = (int)Tq;  // (one pass: the host sends Tq <= kPhQ * 1024 here)
+        double qv[kPhQ];
+        unsigned hasmask = 0u;
+#pragma unroll
+        for (int i = 0; i < kPhQ; ++i) {
+            const int j = tid + i * nthr;
+            qv[i] = 0.0;
+            if (j < nq) {
+                qv[i] = qrow[j];
+                hasmask |= 1u << i;
+            }
+        }
+        unsigned Lw2[kPhQ / 2];
+        unsigned okmask = 0u, nanmask = 0u, walkmask = 0u;
+#pragma unroll
+        for (int i0 = 0; i0 < kPhQ; i0 += 2) {
+            double q[2];
+            bool has[2], ok[2];
+            int lo[2], hi[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                has[j] = (hasmask >> (i0 + j)) & 1u;
+                q[j] = qv[i0 + j];
+                ok[j] = has[j] && sd_finite(q[j]);
+                if (has[j] && !ok[j]) atomicOr(&status[c], SDI_NONFINITE);
+                if (!ok[j]) q[j] = 0.0;
+            }
+            int pos[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pos[j] = -1;
+#pragma unroll 1
+            for (int len = n; len > 1;) {
+                int half = len >> 1;
+                if ((half & 15) == 0) --half;
+                len -= half;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pos[j] += buf[pos[j] + half] < q[j] ? half : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = pos[j] + 1 + (buf[pos[j] + 1] < q[j] ? 1 : 0);
+                lo[j] = p - k > 0 ? p - k : 0;
+                hi[j] = p < M ? p : M;
+            }
+#pragma unroll 1
+            for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int mid = (lo[j] + hi[j]) >> 1;
+                    const bool act = lo[j] < hi[j];
+                    const bool right = sq_dist(q[j], buf[mid]) > sq_dist(q[j], buf[mid + k]);
+                    lo[j] = (act && right) ? mid + 1 : lo[j];
+                    hi[j] = (act && !right) ? mid : hi[j];
+                }
+            }
+            Lw2[i0 >> 1] = (unsigned)lo[0] | ((unsigned)lo[1] << 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = i0 + j;
+                if (!has[j]) continue;
+                if (!ok[j]) {
+                    nanmask |= 1u << i;
+                    continue;
+                }
+                const int L = lo[j];
+                const double dL = sq_dist(q[j], buf[L]), dR = sq_dist(q[j], buf[L + k - 1]);
+                const double worst = dL > dR ? dL : dR;
+                const bool sep_l = L == 0 || sq_dist(q[j], buf[L - 1]) > worst;
+                const bool sep_r = L + k >= n || sq_dist(q[j], buf[L + k]) > worst;
+                if (sep_l && sep_r) okmask |= 1u << i;
+                else walkmask |= 1u << i;
+            }
+        }
+        if (__syncthreads_or(walkmask != 0u) != 0) {  // some window needs the exact walk: the whole cell goes to the split path
+            if (tid == 0) worklist[atomicAdd(work_count, 1)] = (int32_t)(cell0 + c);
+            continue;
+        }
+        // ---- y in training order -> buf (and its mean, summed as analog_sort2_kernel does); gathered -> buf = yx
+        double ybar;
+        {
+            const double* yy = yc + c * T;
+            double yv[K];
+            double ysum = 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < K; ++s2) {
+                const int pos = tid + s2 * nthr;
+                yv[s2] = pos < n ? yy[pos] : 0.0;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < K; ++s2) {
+                const int pos = tid + s2 * nthr;
+                if (pos < n) buf[pos] = yv[s2];
+                ysum += yv[s2];
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) ysum += __shfl_xor(ysum, o, 64);
+            if (lane == 0) red[wave] = ysum;
+            __syncthreads();
+#pragma unroll
+            for (int s2 = 0; s2 < K; ++s2) {
+                const int pos = tid + s2 * nthr;
+                yv[s2] = pos < n ? buf[tagl[pos]] : 0.0;
+            }
+            double tot = 0.0;
+            for (int w = 0; w < 16; ++w) tot += red[w];
+            ybar = uniform_f64(tot / (double)n);
+            __syncthreads();
+#pragma unroll
+            for (int s2 = 0; s2 < K; ++s2) {
+                const int pos = tid + s2 * nthr;
+                if (pos < n) buf[pos] = yv[s2];
+            }
+        }
+        __syncthreads();
+        if (k == 1) {
+            // a single analog (best_analog, or n_analogs = 1: gard.py:291-296)
+#pragma unroll
+            for (int i = 0; i < kPhQ; ++i) {
+                const int idx = tid + i * nthr;
+                const bool okq = (okmask >> i) & 1u;
+                if (okq || ((nanmask >> i) & 1u)) {
+                    const double a1 = buf[okq ? SD_LW(i) : 0];
+                    const bool exc = !pa.has_thresh || a1 > pa.thresh;  // gard.py:307
+                    orow[idx] = !okq ? nan : (pa.kind == SD_ANALOG_BEST || exc) ? a1 : 0.0;
+                    prow[idx] = !okq ? nan : pa.has_thresh ? (exc ? 1.0 : 0.0) : 1.0;
+                    erow[idx] = !okq ? nan : exc ? 0.0 : nan;
+                }
+            }
+            continue;
+        }
+        // ---- generation 2: exclusive prefix sums of d = yx - mean(y) -> window means
+        const int beg = per * tid;
+        double d[PER];
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int j = beg + i;
+            d[i] = (i < per && j < n) ? buf[j] - ybar : 0.0;
+            a += d[i];
+            b += d[i] * d[i];
+        }
+        double ia = a, ib = b;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
+            if (lane >= o) {
+                ia += ta;
+                ib += tb;
+            }
+        }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = ia;
+        __syncthreads();
+        double ra = ia - a;
+        for (int w = 0; w < wave; ++w) ra += wsum[w];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int j = beg + i;
+            if (i < per && j <= n) buf[j] = ra;
+            ra += d[i];
+        }
+        if (tid == nthr - 1 && beg + per == n) buf[n] = ra;
+        __syncthreads();
+        double m1[kPhQ];
+#pragma unroll
+        for (int i = 0; i < kPhQ; ++i) m1[i] = (okmask >> i) & 1u ? div_by(buf[SD_LW(i) + k] - buf[SD_LW(i)], kk, rk) : 0.0;
+        // ---- generation 3: exclusive prefix sums of d^2 -> spreads, outputs
+        __syncthreads();
+        if (lane == 63) wsum[wave] = ib;
+        __syncthreads();
+        double rb = ib - b;
+        for (int w = 0; w < wave; ++w) rb += wsum[w];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int j = beg + i;
+            if (i < per && j <= n) buf[j] = rb;
+            rb += d[i] * d[i];
+        }
+        if (tid == nthr - 1 && beg + per == n) buf[n] = rb;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kPhQ; ++i) {
+            const int idx = tid + i * nthr;
+            double pred, err;
+            if ((okmask >> i) & 1u) {
+                const double var = div_by(buf[SD_LW(i) + k] - buf[SD_LW(i)], kk, rk) - m1[i] * m1[i];
+                pred = ybar + m1[i];                 // gard.py:329-333
+                err = sqrt(var > 0.0 ? var : 0.0);   // gard.py:345
+            } else if ((nanmask >> i) & 1u) {
+                pred = err = nan;
+            } else {
+                continue;
+            }
+            orow[idx] = pred;
+            erow[idx] = err;
+            if (!skip_prob) prow[idx] = pred != pred ? nan : 1.0;  // gard.py:346
+        }
+    }
+#undef SD_LW
+#undef SD_TID
+}
+
+// ------------------------------------------------------------------------------------------------
 // general F predict: brute force, training rows staged through LDS, per-thread top-k in scratch
 // ------------------------------------------------------------------------------------------------
 constexpr int kBfThreads = 256;
@@ -2854,6 +3181,154 @@ int predict_host(int mode, sd_ctx* ctx, const sd_analog_state* st, const double*
     return SD_OK;
 }
 
+// columns `list[0 .. nw)` of a [R, ld] field <-> a packed [R, nw] field (cells the fused kernel handed back)
+__global__ void __launch_bounds__(256) analog_gather_cells_kernel(const double* __restrict__ src, int64_t ld, int64_t R,
+                                                                  const int32_t* __restrict__ list, int64_t nw,
+                                                                  double* __restrict__ dst) {
+    const int64_t total = R * nw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nw, j = i - r * nw;
+        dst[i] = src[r * ld + list[j]];
+    }
+}
+__global__ void __launch_bounds__(256) analog_scatter_cells_kernel(const double* __restrict__ src, int64_t R,
+                                                                   const int32_t* __restrict__ list, int64_t nw,
+                                                                   double* __restrict__ dst, int64_t ld) {
+    const int64_t total = R * nw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nw, j = i - r * nw;
+        dst[r * ld + list[j]] = src[i];
+    }
+}
+
+template <int K>
+int launch_fused_k(sd_ctx* ctx, int nbc, size_t lds, const double* runs, int np, const int32_t* odd, const double* Xc, const double* yc,
+                   const double* qc, int64_t Tq, int64_t T, int64_t cc, const int32_t* st_fit, int32_t* st_p, int32_t* worklist,
+                   int32_t* work_count, int64_t cell0, const PredictArgs& pw, int skip_prob) {
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_fused_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_LAUNCH(ctx, "analog_f1_fused_kernel", analog_f1_fused_kernel<K>, dim3(nbc), dim3(1024), lds, runs, np, odd, Xc, yc, qc, Tq, T, cc, st_fit,
+              st_p, worklist, work_count, cell0, pw, skip_prob);
+    return SD_OK;
+}
+
+// LDS of analog_f1_fused_kernel: keys (np + 1 doubles), co-ranks (1025 ints, padded), tags (T x 16 bit); + its static arrays
+size_t fused_lds_bytes(int np, int64_t T) { return sizeof(double) * (size_t)(np + 1) + sizeof(int) * 1026 + ((sizeof(uint16_t) * (size_t)T + 15) & ~(size_t)15); }
+
+// the split path on device fields: fit -> predict -> drop the state
+int fit_predict_split(sd_ctx* ctx, const double* X, const double* y, int64_t ld, int64_t T, int F, int64_t C, const double* Xq,
+                      int64_t ld_q, int64_t Tq, int k, int kind, int has_thresh, double thresh, double* out, int64_t ld_out,
+                      int32_t* cell_status) {
+    SD_CHECK_ARG(ld_q == ld, "sd_analog_fit_predict: this configuration needs ld_q == ld");
+    sd_analog_state* st = nullptr;
+    SD_TRY(sd_analog_fit_dev(ctx, X, y, ld, T, F, C, &st));
+    const int rc = predict_common(0, ctx, st, Xq, ld_q, Tq, k, kind, has_thresh, thresh, nullptr, 0, out, ld_out, nullptr, nullptr, cell_status);
+    sd_analog_state_destroy(st);
+    return rc;
+}
+
+int fit_predict_dev(sd_ctx* ctx, const double* X, const double* y, int64_t ld, int64_t T, int F, int64_t C, const double* Xq,
+                    int64_t ld_q, int64_t Tq, int k, int kind, int has_thresh, double thresh, double* out, int64_t ld_out,
+                    int32_t* cell_status) {
+    SD_CHECK_ARG(ctx && X && y && Xq && out, "sd_analog_fit_predict: NULL argument");
+    SD_CHECK_ARG(T > 0 && C > 0 && Tq > 0 && ld >= C && ld_q >= C && ld_out >= C, "sd_analog_fit_predict: bad sizes");
+    SD_CHECK_ARG(F >= 1 && F <= kMaxF, "sd_analog_fit_predict: F=%d outside [1,%d]", F, kMaxF);
+    SD_CHECK_ARG(k >= 1 && k <= T, "sd_analog_fit_predict: k=%d must be in [1, T=%lld]", k, (long long)T);
+    SD_CHECK_ARG(kind >= SD_ANALOG_BEST && kind <= SD_ANALOG_MEAN && kind != SD_ANALOG_SAMPLE, "sd_analog_fit_predict: kind %d (sample_analogs needs the split calls)", kind);
+    SD_HIP(hipSetDevice(ctx->device));
+    if (k == 1) kind = SD_ANALOG_BEST;  // (as in predict_common: gard.py:291-296)
+    const int K = F == 1 ? sort2_width(T, ctx->lds_max) : 0;
+    const int64_t chunk_t = 64 * (int64_t)(K > 0 ? K : 1);
+    const int np = (int)(((T + chunk_t - 1) / chunk_t) * chunk_t);
+    const bool fused = K != 0 && tile_sort_applies(K, T, C, ctx->lds_max) && ((kind == SD_ANALOG_MEAN && !has_thresh) || k == 1) &&
+                       Tq <= (int64_t)kPhQ * 1024 && fused_lds_bytes(np, T) + 512 <= ctx->lds_max && sd_dev_env("SD_ANALOG_NOFUSE") == nullptr;
+    if (!fused) return fit_predict_split(ctx, X, y, ld, T, F, C, Xq, ld_q, Tq, k, kind, has_thresh, thresh, out, ld_out, cell_status);
+
+    PredictArgs pa;
+    pa.k = k; pa.kind = kind; pa.has_thresh = has_thresh; pa.thresh = thresh;
+    pa.sample = nullptr; pa.ld_s = 0; pa.out = out; pa.ld_out = ld_out; pa.inds = nullptr; pa.dist = nullptr; pa.oc_Tq = 0;
+    const int64_t chunk = 16384;
+    const int64_t cc_max = C < chunk ? C : chunk;
+    sd_scratch Xc, yc, runs, st_fit, st_p, odd, list, qc, oc, status_pub;
+    SD_HIP(Xc.alloc(ctx, sizeof(double) * (size_t)T * C));
+    SD_HIP(yc.alloc(ctx, sizeof(double) * (size_t)T * C));
+    SD_HIP(runs.alloc(ctx, sizeof(double) * (size_t)np * C));
+    SD_HIP(st_fit.alloc(ctx, sizeof(int32_t) * (size_t)C));
+    SD_HIP(st_p.alloc(ctx, sizeof(int32_t) * (size_t)C));
+    SD_HIP(odd.alloc(ctx, sizeof(int32_t) * (size_t)C));
+    SD_HIP(list.alloc(ctx, sizeof(int32_t) * (size_t)(C + 1)));
+    SD_HIP(qc.alloc(ctx, sizeof(double) * (size_t)Tq * cc_max));
+    SD_HIP(oc.alloc(ctx, sizeof(double) * (size_t)Tq * 3 * cc_max));
+    pa.one_class = st_p.as<int32_t>();
+    int32_t* work_count = list.as<int32_t>();
+    int32_t* worklist = work_count + 1;
+    SD_HIP(hipMemsetAsync(st_fit.p, 0, sizeof(int32_t) * (size_t)C, ctx->stream));
+    SD_HIP(hipMemsetAsync(st_p.p, 0, sizeof(int32_t) * (size_t)C, ctx->stream));
+    SD_HIP(hipMemsetAsync(odd.p, 0, sizeof(int32_t) * (size_t)C, ctx->stream));
+    SD_HIP(hipMemsetAsync(work_count, 0, sizeof(int32_t), ctx->stream));
+    SD_TRY(launch_tile_sort(ctx, K, X, y, ld, T, C, Xc.as<double>(), yc.as<double>(), runs.as<double>(), np, st_fit.as<int32_t>(), odd.as<int32_t>()));
+    const int skip_prob = !has_thresh ? 1 : 0;
+    const size_t lds = fused_lds_bytes(np, T);
+    int nb = (ctx->cu_count / 8) * 8;
+    if (nb < 8) nb = 8;
+    for (int64_t cb = 0; cb < C; cb += chunk) {
+        const int64_t cc = C - cb < chunk ? C - cb : chunk;
+        dim3 tgrid((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32));
+        SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, tgrid, dim3(256), 0, Xq + cb, ld_q, Tq, 1, 0, cc, qc.as<double>(),
+                  st_p.as<int32_t>() + cb, 0);
+        PredictArgs pw = pa;
+        pw.out = oc.as<double>();
+        pw.oc_Tq = Tq;
+        int nbc = nb;
+        if ((int64_t)nbc > ((cc + 7) / 8) * 8) nbc = (int)(((cc + 7) / 8) * 8);
+        const double* r = runs.as<double>() + cb * (int64_t)np;
+        const double* xc = Xc.as<double>() + cb * T;
+        const double* yy = yc.as<double>() + cb * T;
+        const int32_t* sf = st_fit.as<int32_t>() + cb;
+        int32_t* sp = st_p.as<int32_t>() + cb;
+        const int32_t* od = odd.as<int32_t>() + cb;
+        int rc = SD_OK;
+        switch (K) {
+            case 13: rc = launch_fused_k<13>(ctx, nbc, lds, r, np, od, xc, yy, qc.as<double>(), Tq, T, cc, sf, sp, worklist, work_count, cb, pw, skip_prob); break;
+            case 15: rc = launch_fused_k<15>(ctx, nbc, lds, r, np, od, xc, yy, qc.as<double>(), Tq, T, cc, sf, sp, worklist, work_count, cb, pw, skip_prob); break;
+            default: rc = launch_fused_k<17>(ctx, nbc, lds, r, np, od, xc, yy, qc.as<double>(), Tq, T, cc, sf, sp, worklist, work_count, cb, pw, skip_prob); break;
+        }
+        SD_TRY(rc);
+        SD_LAUNCH(ctx, "analog_untranspose_kernel", analog_untranspose_kernel,
+                  dim3((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32), skip_prob ? 2 : 3), dim3(256), 0, (const double*)oc.p, Tq, cc,
+                  out + cb, ld_out, skip_prob);
+    }
+    int32_t nw = 0;
+    SD_HIP(hipMemcpyAsync(&nw, work_count, sizeof(nw), hipMemcpyDeviceToHost, ctx->stream));
+    if (cell_status) {
+        SD_HIP(status_pub.alloc(ctx, sizeof(int32_t) * C));
+        SD_LAUNCH(ctx, "analog_status_public_kernel", analog_status_public_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0,
+                  (const int32_t*)st_fit.p, (const int32_t*)st_p.p, C, status_pub.as<int32_t>());
+        SD_HIP(hipMemcpyAsync(cell_status, status_pub.p, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+#ifdef SD_DEV
+    if (sd_dev_env("SD_ANALOG_COUNT")) fprintf(stderr, "analog fit_predict: %d of %lld cells handed back to the split path\n", nw, (long long)C);
+#endif
+    if (nw == 0) return SD_OK;
+    // cells handed back (ties among the training values or on a window boundary): the split path answers them.  Few: on packed
+    // copies of their columns; many: the whole grid in place (the same numbers either way).
+    if ((int64_t)nw * 2 > C) return fit_predict_split(ctx, X, y, ld, T, F, C, Xq, ld_q, Tq, k, kind, has_thresh, thresh, out, ld_out, nullptr);
+    sd_scratch Xw, yw, Qw, Ow;
+    SD_HIP(Xw.alloc(ctx, sizeof(double) * (size_t)T * nw));
+    SD_HIP(yw.alloc(ctx, sizeof(double) * (size_t)T * nw));
+    SD_HIP(Qw.alloc(ctx, sizeof(double) * (size_t)Tq * nw));
+    SD_HIP(Ow.alloc(ctx, sizeof(double) * (size_t)Tq * 3 * nw));
+    auto blocks = [&](int64_t total) { return dim3((unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)ctx->cu_count * 16)); };
+    SD_LAUNCH(ctx, "analog_gather_cells_kernel", analog_gather_cells_kernel, blocks(T * nw), dim3(256), 0, X, ld, T, (const int32_t*)worklist, (int64_t)nw, Xw.as<double>());
+    SD_LAUNCH(ctx, "analog_gather_cells_kernel", analog_gather_cells_kernel, blocks(T * nw), dim3(256), 0, y, ld, T, (const int32_t*)worklist, (int64_t)nw, yw.as<double>());
+    SD_LAUNCH(ctx, "analog_gather_cells_kernel", analog_gather_cells_kernel, blocks(Tq * nw), dim3(256), 0, Xq, ld_q, Tq, (const int32_t*)worklist, (int64_t)nw, Qw.as<double>());
+    SD_TRY(fit_predict_split(ctx, Xw.as<double>(), yw.as<double>(), nw, T, 1, nw, Qw.as<double>(), nw, Tq, k, kind, has_thresh, thresh, Ow.as<double>(), nw, nullptr));
+    SD_LAUNCH(ctx, "analog_scatter_cells_kernel", analog_scatter_cells_kernel, blocks(3 * Tq * nw), dim3(256), 0, (const double*)Ow.p, 3 * Tq, (const int32_t*)worklist,
+              (int64_t)nw, out, ld_out);
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -3014,6 +3489,32 @@ int sd_analog_predict(sd_ctx* ctx, const sd_analog_state* st, const double* Xq, 
                       int has_thresh, double thresh, const int32_t* sample_inds, double* out, int64_t* inds,
                       double* dist, int32_t* cell_status) {
     return predict_host(0, ctx, st, Xq, Tq, k, kind, has_thresh, thresh, sample_inds, out, inds, dist, cell_status);
+}
+
+int sd_analog_fit_predict_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t ld, int64_t T, int F, int64_t C,
+                              const double* Xq_dev, int64_t ld_q, int64_t Tq, int k, int kind, int has_thresh, double thresh,
+                              double* out_dev, int64_t ld_out, int32_t* cell_status) {
+    return fit_predict_dev(ctx, X_dev, y_dev, ld, T, F, C, Xq_dev, ld_q, Tq, k, kind, has_thresh, thresh, out_dev, ld_out, cell_status);
+}
+
+int sd_analog_fit_predict(sd_ctx* ctx, const double* X, const double* y, int64_t T, int F, int64_t C, const double* Xq, int64_t Tq, int k,
+                          int kind, int has_thresh, double thresh, double* out, int32_t* cell_status) {
+    SD_CHECK_ARG(ctx && X && y && Xq && out, "sd_analog_fit_predict: NULL argument");
+    SD_CHECK_ARG(T > 0 && C > 0 && Tq > 0 && F >= 1, "sd_analog_fit_predict: bad sizes");
+    SD_HIP(hipSetDevice(ctx->device));
+    sd_scratch dX, dy, dq, dout;
+    const size_t xb = sizeof(double) * (size_t)T * F * C, yb = sizeof(double) * (size_t)T * C, qb = sizeof(double) * (size_t)Tq * F * C,
+                 ob = sizeof(double) * (size_t)Tq * 3 * C;
+    SD_HIP(dX.alloc(ctx, xb));
+    SD_HIP(dy.alloc(ctx, yb));
+    SD_HIP(dq.alloc(ctx, qb));
+    SD_HIP(dout.alloc(ctx, ob));
+    SD_TRY(sd_copy_h2d(ctx, dX.p, X, xb));
+    SD_TRY(sd_copy_h2d(ctx, dy.p, y, yb));
+    SD_TRY(sd_copy_h2d(ctx, dq.p, Xq, qb));
+    SD_TRY(fit_predict_dev(ctx, dX.as<double>(), dy.as<double>(), C, T, F, C, dq.as<double>(), C, Tq, k, kind, has_thresh, thresh, dout.as<double>(), C,
+                           cell_status));
+    return sd_copy_d2h(ctx, out, dout.p, ob);
 }
 
 int sd_analogreg_predict_dev(sd_ctx* ctx, const sd_analog_state* st, const double* Xq_dev, int64_t ld, int64_t Tq,

@@ -544,7 +544,8 @@ double h_pp_at(int i, double denom) { return ((double)(i + 1) - kAlpha) / denom;
 struct QTables {
     sd_scratch idx, val;
 };
-int build_q_tables(sd_ctx* ctx, const std::vector<int64_t>& off_f, const std::vector<int64_t>& off_p, int G, QTables* q) {
+int build_q_tables(sd_ctx* ctx, const std::vector<int64_t>& off_f, const std::vector<int64_t>& off_p, int G, QTables* q,
+                   int tails = SD_QT_TAIL_LOWER | SD_QT_TAIL_UPPER) {
     const int64_t Tp = off_p[G];
     std::vector<int32_t> qi(Tp);
     std::vector<double> qv(Tp);
@@ -555,8 +556,16 @@ int build_q_tables(sd_ctx* ctx, const std::vector<int64_t>& off_f, const std::ve
             const int64_t t = off_p[g] + r;
             const double p = h_pp_at(r, dm);
             if (n == 0) { qi[t] = -3; qv[t] = 0.0; continue; }
-            if (p < h_pp_at(0, dn)) { qi[t] = -1; qv[t] = p; continue; }
-            if (p > h_pp_at(n - 1, dn)) { qi[t] = -2; qv[t] = p; continue; }
+            // beyond the fitted positions: the OLS line of that side, or -- extrapolate 'min' / 'max' / None / '1to1' --
+            // np.interp's end value (quantile.py:527-530)
+            if (p < h_pp_at(0, dn)) {
+                if (tails & SD_QT_TAIL_LOWER) { qi[t] = -1; qv[t] = p; } else { qi[t] = 0; qv[t] = 0.0; }
+                continue;
+            }
+            if (p > h_pp_at(n - 1, dn)) {
+                if (tails & SD_QT_TAIL_UPPER) { qi[t] = -2; qv[t] = p; } else { qi[t] = n - 1; qv[t] = 0.0; }
+                continue;
+            }
             int i = (int)std::floor(p * dn + kAlpha) - 1;
             i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
             while (i + 1 < n && h_pp_at(i + 1, dn) <= p) ++i;
@@ -953,6 +962,9 @@ static int predict_with_table(sd_ctx* ctx, const sd_bcsd_state* st, const double
     int W = 0, stride = 0;
     const int nmax_all = gt.nmax > st->nmax ? gt.nmax : st->nmax;
     const bool rs = use_rs_path(nmax_all, ld > ld_out ? ld : ld_out);
+    if (!rs && (st->qt_tails != (SD_QT_TAIL_LOWER | SD_QT_TAIL_UPPER) || st->qt_endpoints != 10))
+        return sd_set_error(SD_ERR_UNSUPPORTED, "non-default extrapolate / n_endpoints serve group segments of up to %d samples (longest here: %d)",
+                            64 * 33, nmax_all);
     const bool lng = !rs && use_long_path(nmax_all, ctx->lds_max) && long_width(gt.nmax, ctx->lds_max) != 0;
     if (st->detrend && !rs && !lng)
         return sd_set_error(SD_ERR_UNSUPPORTED, "detrended quantile mapping serves group segments of up to %d samples (longest here: %d)",
@@ -961,8 +973,9 @@ static int predict_with_table(sd_ctx* ctx, const sd_bcsd_state* st, const double
     QTables qt;
     if (rs) {
         const bool identity = st->goff == gt.host_off;  // equal fit / predict group lengths: no inverse-CDF tables needed
-        if (!identity) SD_TRY(build_q_tables(ctx, st->goff, gt.host_off, st->G, &qt));
+        if (!identity) SD_TRY(build_q_tables(ctx, st->goff, gt.host_off, st->G, &qt, st->qt_tails));
         sdrs::Params p = {};
+        p.n_endpoints = st->qt_endpoints;
         p.kind = st->kind; p.G = st->G; p.return_anoms = st->return_anoms; p.RS = sd_bcsd_rs_row_stride(nmax_all);
         p.C = C; p.Tf = st->T; p.ntiles = (C + 7) / 8;
         p.Xp = Xp_dev; p.ld_p = ld; p.out = out_dev; p.ld_out = ld_out;
@@ -1324,6 +1337,15 @@ int sd_bcsd_predict_trend(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp
                                      cell_status));
     SD_TRY(sd_copy_d2h(ctx, out, dout.p, bytes));
     SD_HIP(hipStreamSynchronize(ctx->stream));
+    return SD_OK;
+}
+
+int sd_bcsd_state_set_tails(sd_bcsd_state* st, int extrapolate, int n_endpoints) {
+    SD_CHECK_ARG(st, "sd_bcsd_state_set_tails: NULL state");
+    SD_CHECK_ARG(extrapolate >= 0 && extrapolate <= (SD_QT_TAIL_LOWER | SD_QT_TAIL_UPPER), "sd_bcsd_state_set_tails: extrapolate = %d", extrapolate);
+    SD_CHECK_ARG(n_endpoints >= 1, "sd_bcsd_state_set_tails: n_endpoints = %d (a line needs at least one point)", n_endpoints);
+    st->qt_tails = extrapolate;
+    st->qt_endpoints = n_endpoints;
     return SD_OK;
 }
 

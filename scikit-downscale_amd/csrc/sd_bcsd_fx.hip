@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
             wave_fence();
             double slo = 0.0, ilo = 0.0, shi = 0.0, ihi = 0.0;
             if (m > n && n > 0) {  // tails are reachable only when the predict segment is longer
-                const int e = n < 10 ? n : 10;
+                const int e = n < p->n_endpoints ? n : p->n_endpoints;
                 const double dn = pp_denom(n);
                 ols_line(row, 0, e, dn, &slo, &ilo);
                 ols_line(row, n - e, e, dn, &shi, &ihi);
@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
         } else {
             double slo = 0.0, ilo = 0.0, shi = 0.0, ihi = 0.0;
             if (m > n && n > 0) {
-                const int e = n < 10 ? n : 10;
+                const int e = n < p->n_endpoints ? n : p->n_endpoints;
                 const double dn = pp_denom(n);
                 ols_line(row, 0, e, dn, &slo, &ilo);
                 ols_line(row, n - e, e, dn, &shi, &ihi);
@@ -863,5 +863,6 @@ int sd_bcsd_fx_launch(sd_ctx* ctx, const sdrs::Params& p, int nmax, const int* g
     sdrs::Params q = p;
     q.gmask = 0ull;
     q.use_worklist = 0;
+    if (q.n_endpoints <= 0) q.n_endpoints = 10;
     return sdfx::launch_width(ctx, q, nmax, group_len);
 }

@@ -44,6 +44,7 @@ struct Params {
     int detrend;
     double* trend_u;       // RANK -> APPLY: [C*G][2] slope, intercept of the predict segment's line
     double* y_trend;       // state [C][G][2]: slope, intercept of the fitted segment's line
+    int n_endpoints;  // points of the OLS tail lines (quantile.py:426, 537-541); the launchers turn 0 into the default 10
     int dev_flags;  // development library only (SD_FZ_ABLATE): phases skipped to time the rest; results are then wrong
 };
 

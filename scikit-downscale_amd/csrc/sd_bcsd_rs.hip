@@ -254,7 +254,7 @@ __device__ __forceinline__ void segment_body(ParamsPtr p, int64_t tile_id, int g
     } else {
         double slo = 0.0, ilo = 0.0, shi = 0.0, ihi = 0.0;
         if (m > n && n > 0) {  // tails are reachable only when the predict segment is longer
-            const int e = n < 10 ? n : 10;
+            const int e = n < p->n_endpoints ? n : p->n_endpoints;
             const double dn = pp_denom(n);
             ols_line(row, 0, e, dn, &slo, &ilo);
             ols_line(row, n - e, e, dn, &shi, &ihi);
@@ -439,6 +439,7 @@ void sd_bcsd_rs_width_split(int nmax, int G, const int* group_len, unsigned long
 
 int sd_bcsd_rs_launch(sd_ctx* ctx, int mode, const sdrs::Params& p, int nmax, const int* group_len) {
     sdrs::Params q = p;
+    if (q.n_endpoints <= 0) q.n_endpoints = 10;
     const int kmax = sd_bcsd_rs_width(nmax);
     q.gmask = 0ull;
     q.slab_nr = (kmax + 1) / 2;

@@ -108,6 +108,7 @@ struct sd_bcsd_state {
     sd_ctx* ctx = nullptr;
     int kind = 0, G = 0, return_anoms = 1;
     int detrend = 0;  // QuantileMapper(detrend=True): ys holds the sorted detrended observations
+    int qt_tails = 3, qt_endpoints = 10;  // sd_bcsd_state_set_tails: OLS continuation of the fitted CDF (lower | upper), points per line
     int64_t T = 0, C = 0;
     std::vector<int64_t> goff;  // host copy, [G+1]
     int nmax = 0;

@@ -67,6 +67,7 @@ SIGNATURES = {
     "sd_bcsd_state_status": [_p, _p],
     "sd_bcsd_state_export": [_p, _p, _p, _p, _p, _p],
     "sd_bcsd_state_import": [_p, _int, _int, _i64, _i64, _int, _p, _p, _p, _p, _p, C.POINTER(_p)],
+    "sd_bcsd_state_set_tails": [_p, _int, _int],
     "sd_bcsd_state_get_trend": [_p, _p],
     "sd_bcsd_state_set_trend": [_p, _p],
     "sd_bcsd_state_destroy": [_p],
@@ -74,6 +75,8 @@ SIGNATURES = {
     "sd_analog_fit_dev": [_p, _p, _p, _i64, _i64, _int, _i64, C.POINTER(_p)],
     "sd_analog_predict": [_p, _p, _p, _i64, _int, _int, _int, _dbl, _p, _p, _p, _p, _p],
     "sd_analog_predict_dev": [_p, _p, _p, _i64, _i64, _int, _int, _int, _dbl, _p, _p, _i64, _p, _p, _p],
+    "sd_analog_fit_predict": [_p, _p, _p, _i64, _int, _i64, _p, _i64, _int, _int, _int, _dbl, _p, _p],
+    "sd_analog_fit_predict_dev": [_p, _p, _p, _i64, _i64, _int, _i64, _p, _i64, _i64, _int, _int, _int, _dbl, _p, _i64, _p],
     "sd_analogreg_predict": [_p, _p, _p, _i64, _int, _int, _dbl, _p, _p],
     "sd_analogreg_predict_dev": [_p, _p, _p, _i64, _i64, _int, _int, _dbl, _p, _i64, _p],
     "sd_analog_state_info": [_p, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_i64)],
@@ -106,7 +109,8 @@ SIGNATURES = {
 }
 
 _libs = {}
-ABI_VERSION = 102  # include/sd_downscale.h: SD_VERSION
+QT_TAIL_LOWER, QT_TAIL_UPPER = 1, 2  # sd_bcsd_state_set_tails
+ABI_VERSION = 103  # include/sd_downscale.h: SD_VERSION
 
 
 class EngineError(RuntimeError):

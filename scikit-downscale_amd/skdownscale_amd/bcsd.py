@@ -59,12 +59,25 @@ def check_supported(model):
         raise TypeError(f"QuantileMapper.__init__() got an unexpected keyword argument {sorted(extra)[0]!r}")
     if qm.get("detrend", False) and (qm.get("lt_kwargs") or {}).get("lr_kwargs"):
         raise NotImplementedError("LinearTrendTransformer(lr_kwargs=...): only the LinearRegression defaults run on the HIP engine")
-    qt = qm.get("qt_kwargs") or {}
-    for k, v in qt.items():
+    qt_settings(model)
+
+
+def qt_settings(model):
+    """(extrapolate, n_endpoints) of ``qm_kwargs['qt_kwargs']`` (bcsd.py:59-67 -> quantile.py:92, 136: every group's
+    CunnaneTransformer gets them).  ``alpha`` / ``beta`` are accepted and without effect, as in the reference: its fit calls
+    ``plotting_positions(len(X))`` with the defaults (quantile.py:462)."""
+    qt = (model.qm_kwargs or {}).get("qt_kwargs") or {}
+    for k in qt:
         if k not in _QT_DEFAULTS:
             raise TypeError(f"CunnaneTransformer.__init__() got an unexpected keyword argument {k!r}")
-        if v != _QT_DEFAULTS[k]:
-            raise NotImplementedError(f"CunnaneTransformer({k}={v!r}): only the default {_QT_DEFAULTS[k]!r} runs on the HIP engine")
+    extrapolate = qt.get("extrapolate", _QT_DEFAULTS["extrapolate"])
+    if extrapolate not in ("min", "max", "both", "1to1", None):
+        # the reference takes any other value as "no extrapolation" (quantile.py:527-528 only tests membership): so does np.interp here
+        extrapolate = None
+    n_endpoints = qt.get("n_endpoints", _QT_DEFAULTS["n_endpoints"])
+    if not isinstance(n_endpoints, (int, np.integer)) or n_endpoints < 1:
+        raise NotImplementedError(f"CunnaneTransformer(n_endpoints={n_endpoints!r}): a positive integer is needed on the HIP engine")
+    return extrapolate, int(n_endpoints)
 
 
 class BcsdGridModel:
@@ -77,8 +90,9 @@ class BcsdGridModel:
     (bcsd.py:51-53) -- its keys select fitted day-of-year groups, which is the reference's behaviour."""
 
     def __init__(self, kind, return_anoms=True, grouper=MONTH_GROUPER, ctx=None, trend_grouper=None, day_grouper=DAY_GROUPER,
-                 detrend=False):
+                 detrend=False, extrapolate="both", n_endpoints=10):
         self.kind = kind
+        self.tails = (extrapolate, int(n_endpoints))  # qt_kwargs: tail handling of the fitted inverse CDFs
         self.return_anoms = bool(return_anoms)
         self.detrend = bool(detrend)  # qm_kwargs={'detrend': True}: quantile.py:95-98, 128-145 per group
         self.grouper = grouper
@@ -113,8 +127,13 @@ class BcsdGridModel:
         else:
             gid = self.group_ids_fit(index)
             self.state = self.ctx.bcsd_fit(self.kind, X, y, gid, len(self.keys), self.return_anoms, detrend=self.detrend)
+        self._apply_tails()
         self.status_ = self.state.status()
         return self
+
+    def _apply_tails(self):
+        if self.tails != ("both", 10):
+            self.state.set_tails(*self.tails)
 
     def predict(self, Xp, index_p, out=None, out_dtype=None):
         if self.state is None:
@@ -167,8 +186,10 @@ class BcsdBase(TimeSynchronousDownscaler):
             self.timestep = "monthly"
 
     def _new_grid(self):
+        extrapolate, n_endpoints = qt_settings(self)
         return BcsdGridModel(self._kind, self.return_anoms, self.time_grouper, trend_grouper=self.climate_trend,
-                             day_grouper=self.climate_trend_grouper, detrend=bool((self.qm_kwargs or {}).get("detrend", False)))
+                             day_grouper=self.climate_trend_grouper, detrend=bool((self.qm_kwargs or {}).get("detrend", False)),
+                             extrapolate=extrapolate, n_endpoints=n_endpoints)
 
     def _fit_engine(self, X2, y2, index):
         self._pre_fit()
@@ -221,6 +242,7 @@ class BcsdBase(TimeSynchronousDownscaler):
         grid = self._new_grid()
         grid.keys = keys
         grid.state = grid.ctx.bcsd_import(exported)
+        grid._apply_tails()
         return grid
 
     def __getstate__(self):

@@ -106,6 +106,14 @@ class BcsdState(_State):
         check(self.ctx.lib.sd_bcsd_state_status(self.vptr, ptr(st)))
         return st
 
+    def set_tails(self, extrapolate="both", n_endpoints=10):
+        """CunnaneTransformer(extrapolate, n_endpoints) of the fitted inverse CDFs (quantile.py:418-431, 523-545) for later
+        predict calls: which tails continue along the least-squares line through the first / last ``n_endpoints`` points."""
+        masks = {"both": 3, "min": _lib.QT_TAIL_LOWER, "max": _lib.QT_TAIL_UPPER, "1to1": 0, None: 0}
+        if extrapolate not in masks:
+            raise ValueError(f"extrapolate={extrapolate!r}: expected one of 'min', 'max', 'both', '1to1', None")
+        check(self.ctx.lib.sd_bcsd_state_set_tails(self.vptr, masks[extrapolate], int(n_endpoints)))
+
     def export(self):
         i = self.info()
         ys = np.empty((i["C"], i["T"]))
@@ -518,6 +526,35 @@ class Context:
             T, F, Cc = X.shape
             check(self.lib.sd_analog_fit(self.handle, ptr(X), ptr(y), T, F, Cc, C.byref(h)))
         return AnalogState(self, h.value, self.lib.sd_analog_state_destroy)
+
+    def analog_fit_predict(self, X, y, Xq, k, kind, thresh=None, out=None):
+        """AnalogBase.fit + PureAnalog.predict in one call without a fitted state (sd_analog_fit_predict*): X [T,F,C], y [T,C],
+        Xq [Tq,F,C], all numpy or all DeviceArray -> (out [Tq,3,C], status [C]); bit-identical to analog_fit -> analog_predict."""
+        dev = isinstance(X, DeviceArray)
+        if not dev:
+            X, y, Xq = _lib.as_f64(X), _lib.as_f64(y), _lib.as_f64(Xq)
+        if isinstance(y, DeviceArray) != dev or isinstance(Xq, DeviceArray) != dev:
+            raise ValueError("X, y and Xq must all be numpy arrays or all DeviceArrays")
+        if len(X.shape) != 3 or tuple(y.shape) != (X.shape[0], X.shape[2]):
+            raise ValueError(f"expected X [T, F, C] and y [T, C], got {tuple(X.shape)} and {tuple(y.shape)}")
+        T, F, Cc = X.shape
+        if len(Xq.shape) != 3 or Xq.shape[1] != F or Xq.shape[2] != Cc:
+            raise ValueError(f"Xq: expected a [Tq, {F}, {Cc}] field, got shape {tuple(Xq.shape)}")
+        k = int(k)
+        if k < 1 or k > T:
+            raise ValueError(f"k={k}: expected 1 <= k <= {T} (the number of training samples)")
+        Tq = Xq.shape[0]
+        status = np.empty(Cc, dtype=np.int32)
+        has_t, tv = (0, 0.0) if thresh is None else (1, float(thresh))
+        if dev:
+            assert X.ld == y.ld
+            out = self.empty((Tq, 3, Cc)) if out is None else out
+            check(self.lib.sd_analog_fit_predict_dev(self.handle, X.vptr, y.vptr, y.ld, T, F, Cc, Xq.vptr, Xq.ld, Tq, k, kind, has_t, tv,
+                                                     out.vptr, out.ld, ptr(status)))
+        else:
+            out = np.empty((Tq, 3, Cc))
+            check(self.lib.sd_analog_fit_predict(self.handle, ptr(X), ptr(y), T, F, Cc, ptr(Xq), Tq, k, kind, has_t, tv, ptr(out), ptr(status)))
+        return out, status
 
     def analog_predict(self, state, Xq, k, kind, thresh=None, sample_inds=None, want_neighbors=False, out=None):
         info = state.info()

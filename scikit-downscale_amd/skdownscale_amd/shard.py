@@ -398,7 +398,7 @@ class ShardedPointWiseDownscaler:
         spatial, sp_shape, C, sp_coords = self._layout
         cells = np.array([e - s for s, e in cell_partition(C, self.world)], dtype=np.int64)
         on_gpu = self.comm is not None and hasattr(self.comm, "ctx")
-        resident = self._resident_bcsd(Xl, kwargs) if (method == "predict" and on_gpu and self.world > 1) else None
+        resident = self._resident_bcsd(Xl, kwargs) if (method == "predict" and on_gpu) else None
         if resident is not None:
             local, lead_dims, lead_shape, lead_coords, dtype = resident
         else:
@@ -408,9 +408,9 @@ class ShardedPointWiseDownscaler:
             lead_coords = {k: v for k, v in res.coords.items() if k in lead_dims}
             rows = int(np.prod(lead_shape, dtype=np.int64))
             local = np.ascontiguousarray(np.asarray(res.values, dtype=np.float64).reshape(rows, res.shape[-1]))
-        if self.comm is None or self.world == 1:
+        if self.comm is None or (self.world == 1 and not on_gpu):
             full = local
-        else:
+        else:  # (a one-rank RCCL communicator takes the same path: the gather is a device copy into the root buffer)
             if on_gpu and resident is None:
                 local = self.comm.ctx.to_device(local)  # (results of the other estimators are host arrays: up for the gather)
             views = self.comm.gather_field(local, cells, 0)

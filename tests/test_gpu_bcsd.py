@@ -69,6 +69,43 @@ def test_bcsd_precipitation_bad_climatology(ctx):
     assert_close(out, g["out_abs"], what="badclimo/abs")
 
 
+QT_VARIANTS = [dict(n_endpoints=5), dict(n_endpoints=3, extrapolate="both"), dict(extrapolate="min"), dict(extrapolate="max"),
+               dict(extrapolate=None), dict(extrapolate="1to1"), dict(alpha=0.3, beta=0.2), dict(n_endpoints=40)]
+
+
+def test_qt_kwargs_golden(ctx):
+    """qm_kwargs={'qt_kwargs': ...} (bcsd.py:59-67 -> quantile.py:418-431, 523-545) against g19_qt_kwargs.npz from the real
+    reference: a predict series longer than the fit series reaches the tails of the fitted inverse CDFs, where `extrapolate`
+    picks OLS line or end value per side and `n_endpoints` the points of the line; `alpha` / `beta` are without effect there
+    and here.  Through the engine (state.set_tails) for all cells at once, and through the estimator surface for one cell."""
+    from skdownscale_amd import BcsdPrecipitation, BcsdTemperature, synth
+
+    g = load("g19_qt_kwargs")
+    T, Tp, C = int(g["T"]), int(g["Tp"]), int(g["C"])
+    index, index_p = synth.daily_calendar(T), synth.daily_calendar(Tp)
+    cells = np.arange(C)
+    gid, gid_p = month_gid(index), month_gid(index_p)
+    tas = [synth.tas_field(n, int(g["seed"]), i, cells, int(g["c_full"])) for n, i in (("X_hist", index), ("y_obs", index), ("X_fut", index_p))]
+    pr = [synth.pr_field(n, int(g["seed"]), t, cells, int(g["c_full"])) for n, t in (("X_hist", T), ("y_obs", T), ("X_fut", Tp))]
+    assert len(QT_VARIANTS) == int(g["n_variants"])
+    for kind, fields, n, cls in ((0, tas, len(QT_VARIANTS), BcsdTemperature), (1, pr, int(g["n_pr"]), BcsdPrecipitation)):
+        X, y, Xp = fields
+        for i, kw in enumerate(QT_VARIANTS[:n]):
+            exp = g[("tas" if kind == 0 else "pr") + str(i)]
+            st = ctx.bcsd_fit(kind, X, y, gid, 12, True)
+            st.set_tails(kw.get("extrapolate", "both"), kw.get("n_endpoints", 10))
+            out, status = ctx.bcsd_predict(st, Xp, gid_p)
+            assert (status == 0).all()
+            assert_close(out, exp, what=f"qt_kwargs {kw} kind={kind}")
+            dout, _ = ctx.bcsd_predict(st, ctx.to_device(Xp), gid_p)
+            assert np.array_equal(dout.to_host(), out)
+            m = cls(qm_kwargs={"qt_kwargs": kw})
+            m.fit(pd.DataFrame({"x": X[:, 1]}, index=index), pd.DataFrame({"y": y[:, 1]}, index=index))
+            got = m.predict(pd.DataFrame({"x": Xp[:, 1]}, index=index_p)).values[:, 0]
+            assert_close(got, exp[:, 1], what=f"estimator qt_kwargs {kw} kind={kind}")
+    assert not np.allclose(g["tas0"], g["tas6"])  # (n_endpoints does reach the result; alpha / beta do not)
+
+
 def test_masked_and_nan_cells(ctx):
     g = load("g7_masked")
     index, index_p, X, y, Xp = tas_inputs(g)

@@ -139,6 +139,35 @@ def test_single_rank_communicator_self_gather(ctx):
     comm.close()
 
 
+def test_sharded_downscaler_on_a_one_rank_rccl_communicator(ctx):
+    """The sharded drop-in surface on the RCCL transport with one rank: the BCSD prediction stays on the GPU from upload to
+    gather (shard.py: _resident_bcsd + Communicator.gather_field), rank 0 downloads the gathered buffer once; y in another
+    spatial dim order than X (aligned by name), a masked cell.  Must equal PointWiseDownscaler."""
+    from skdownscale_amd import BcsdTemperature, GridArray, PointWiseDownscaler
+    from skdownscale_amd.shard import Communicator, ShardedPointWiseDownscaler
+
+    comm = Communicator.from_env(ctx)
+    rng = np.random.default_rng(14)
+    index = pd.date_range("1980-01-01", periods=1461)
+    Xg = GridArray(15 + 8 * rng.standard_normal((1461, 3, 4)), ("time", "y", "x"), {"time": index})
+    yg = GridArray(13 + 9 * rng.standard_normal((1461, 4, 3)), ("time", "x", "y"), {"time": index})
+    Xg.values[0, 1, 2] = np.nan
+    sharded = ShardedPointWiseDownscaler(BcsdTemperature(), comm=comm)
+    sharded.fit(Xg, yg)
+    calls = []
+    orig = sharded._resident_bcsd
+    sharded._resident_bcsd = lambda *a, **k: calls.append(1) or orig(*a, **k)
+    got = sharded.predict(Xg)
+    plain = PointWiseDownscaler(BcsdTemperature())
+    plain.fit(Xg, yg)
+    want = plain.predict(Xg)
+    assert calls and got.dims == want.dims and got.shape == want.shape
+    assert np.array_equal(np.isnan(got.values), np.isnan(want.values)) and np.isnan(got.values[:, 1, 2]).all()
+    ok = ~np.isnan(want.values)
+    assert np.array_equal(got.values[ok], want.values[ok])
+    comm.close()
+
+
 def test_large_host_copies_take_the_staged_path(ctx):
     """host <-> device copies above 8 MB go through the pinned staging ring (several chunks, ragged tail)"""
     rng = np.random.default_rng(5)

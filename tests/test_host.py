@@ -71,6 +71,7 @@ def test_unsupported_configurations_raise():
 
     check_supported(BcsdTemperature())
     check_supported(BcsdTemperature(qm_kwargs={"qt_kwargs": {"n_endpoints": 10}}))
+    check_supported(BcsdTemperature(qm_kwargs={"qt_kwargs": {"extrapolate": None, "n_endpoints": 3}}))
     nasanex = BcsdTemperature(time_grouper="daily_nasa-nex")
     nasanex._pre_fit()  # swaps PaddedDOYGrouper in (bcsd.py:36-38)
     check_supported(nasanex)
@@ -79,7 +80,7 @@ def test_unsupported_configurations_raise():
     check_supported(BcsdTemperature(climate_trend=DAY_GROUPER))
     check_supported(BcsdTemperature(qm_kwargs={"detrend": True}))
     for bad in (BcsdTemperature(time_grouper="M"), BcsdTemperature(qm_kwargs={"detrend": True, "lt_kwargs": {"lr_kwargs": {"fit_intercept": False}}}),
-                BcsdTemperature(qm_kwargs={"qt_kwargs": {"extrapolate": None}})):
+                BcsdTemperature(qm_kwargs={"qt_kwargs": {"n_endpoints": 0}})):
         with pytest.raises(NotImplementedError):
             check_supported(bad)
 
@@ -294,6 +295,23 @@ def test_padded_doy_grouper_matches_the_reference():
     index = pd.date_range(start="1980-01-01", end="1982-12-31")
     groups = dict(list(PaddedDOYGrouper(pd.DataFrame({"foo": np.arange(len(index), dtype=float)}, index=index))))
     np.testing.assert_array_equal(np.unique(groups[123].index.dayofyear), np.arange(123 - 15, 123 + 16))
+
+
+def test_bcsd_qt_kwargs_are_validated_like_the_reference():
+    """qm_kwargs={'qt_kwargs': ...}: unknown keys fail like CunnaneTransformer.__init__ would, `alpha` / `beta` are accepted
+    (and unused, quantile.py:462), `extrapolate` / `n_endpoints` are carried to the engine (no GPU needed for the checks)."""
+    from skdownscale_amd import BcsdTemperature
+    from skdownscale_amd.bcsd import qt_settings
+
+    assert qt_settings(BcsdTemperature()) == ("both", 10)
+    assert qt_settings(BcsdTemperature(qm_kwargs={"qt_kwargs": {"alpha": 0.3, "beta": 0.1}})) == ("both", 10)
+    assert qt_settings(BcsdTemperature(qm_kwargs={"qt_kwargs": {"extrapolate": "min", "n_endpoints": 4}})) == ("min", 4)
+    assert qt_settings(BcsdTemperature(qm_kwargs={"qt_kwargs": {"extrapolate": None}})) == (None, 10)
+    assert qt_settings(BcsdTemperature(qm_kwargs={"qt_kwargs": {"extrapolate": "sideways"}})) == (None, 10)  # quantile.py:527-528
+    with pytest.raises(TypeError, match="unexpected keyword argument 'gamma'"):
+        qt_settings(BcsdTemperature(qm_kwargs={"qt_kwargs": {"gamma": 1}}))
+    with pytest.raises(NotImplementedError):
+        qt_settings(BcsdTemperature(qm_kwargs={"qt_kwargs": {"n_endpoints": 0}}))
 
 
 def test_pure_regression_argument_checks():
