@@ -440,9 +440,13 @@ def main():
         out = ctx.empty((T, 3, C))
 
         def step(cells=None, dst=None):
-            st = ctx.analog_fit(fields["X"], fields["y"])
-            _, status = ctx.analog_predict(st, fields["Xq"], 30, _lib.ANALOG_MEAN, out=out)
-            st.close()
+            if os.environ.get("SD_BENCH_ANALOG_SPLIT"):  # the two calls (a fitted state written, read back and dropped)
+                st = ctx.analog_fit(fields["X"], fields["y"])
+                _, status = ctx.analog_predict(st, fields["Xq"], 30, _lib.ANALOG_MEAN, out=out)
+                st.close()
+                return status
+            # fit + predict in one call: the step keeps no fitted state (sd_analog_fit_predict_dev)
+            _, status = ctx.analog_fit_predict(fields["X"], fields["y"], fields["Xq"], 30, _lib.ANALOG_MEAN, out=out)
             return status
 
     def barrier():

@@ -1979,8 +1979,9 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
 // tags of the sorted keys (= xi) are parked in LDS behind the key array; x and y are gathered through them twice, once into
 // the sorted order of each.  Arithmetic, summation orders and the window search are those of the two kernels, so the result
 // is bit-identical to fit -> predict.  Cells the fast paths cannot decide -- the tag pass fails (equal or nearly equal
-// training values), or a query's window is not strictly separated (the exact walk needs xi and the unsorted copies) -- are
-// appended to `worklist`; the host answers them with the split path.  Pointers are relative to the chunk of cells of this
+// training values), or a query's window is not strictly separated (the exact walk: inlined here it costs the kernel 60 more
+// spilled registers and 3 ms per 16 384 cells for a case continuous data never produces) -- are appended to `worklist`; the
+// host answers them with the split path.  Pointers are relative to the chunk of cells of this
 // launch, `cell0` is the grid index of its first cell.
 template <int K>
 __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __restrict__ runs, int np,
@@ -2096,16 +2097,12 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
         SD_TID();
         const double* qrow = Xq + c * Tq;
         const int nq = (int)Tq;  // (one pass: the host sends Tq <= kPhQ * 1024 here)
-        double qv[kPhQ];
-        unsigned hasmask = 0u;
+        // (the queries of a thread are fetched two pairs ahead of their use instead of all at once: 8 registers instead of 32)
+        double qn[4];
 #pragma unroll
-        for (int i = 0; i < kPhQ; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int j = tid + i * nthr;
-            qv[i] = 0.0;
-            if (j < nq) {
-                qv[i] = qrow[j];
-                hasmask |= 1u << i;
-            }
+            qn[i] = j < nq ? qrow[j] : 0.0;
         }
         unsigned Lw2[kPhQ / 2];
         unsigned okmask = 0u, nanmask = 0u, walkmask = 0u;
@@ -2116,8 +2113,11 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
             int lo[2], hi[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                has[j] = (hasmask >> (i0 + j)) & 1u;
-                q[j] = qv[i0 + j];
+                has[j] = tid + (i0 + j) * nthr < nq;
+                q[j] = qn[j];
+                qn[j] = qn[j + 2];
+                const int jn = tid + (i0 + j + 4) * nthr;
+                qn[j + 2] = (i0 + j + 4 < kPhQ && jn < nq) ? qrow[jn] : 0.0;
                 ok[j] = has[j] && sd_finite(q[j]);
                 if (has[j] && !ok[j]) atomicOr(&status[c], SDI_NONFINITE);
                 if (!ok[j]) q[j] = 0.0;
@@ -3270,6 +3270,7 @@ int fit_predict_dev(sd_ctx* ctx, const double* X, const double* y, int64_t ld, i
     const size_t lds = fused_lds_bytes(np, T);
     int nb = (ctx->cu_count / 8) * 8;
     if (nb < 8) nb = 8;
+    if ((int64_t)nb > ((C + 7) / 8) * 8) nb = (int)(((C + 7) / 8) * 8);
     for (int64_t cb = 0; cb < C; cb += chunk) {
         const int64_t cc = C - cb < chunk ? C - cb : chunk;
         dim3 tgrid((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32));
@@ -3415,9 +3416,10 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->xi, sizeof(int32_t) * (size_t)T * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->yx, sizeof(double) * (size_t)T * C));
             SD_HIP(sd_pool_malloc(ctx, (void**)&st->ybar, sizeof(double) * C));
-            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const int K2 = sd_dev_env("SD_ANALOG_SORT1") ? 0 : sort2_width(T, ctx->lds_max);
+            if (K2 == 0)
+                SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_sort_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if (K2 != 0) {
                 // (no prefix sums yet: the BASELINE path -- analog_f1_mean3_kernel -- builds its own on chip; the kernels
                 // that read them from memory get them from ensure_prefix_sums on their first call)

@@ -393,6 +393,86 @@ def test_full_size_grid_is_consistent(ctx):
     out.free()
 
 
+def same_bits(a, b):
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+
+
+@pytest.mark.parametrize("T,Tq,C", [(14600, 14600, 41), (13000, 9000, 19), (15360, 16384, 9), (14600, 20000, 5), (17000, 500, 3), (731, 400, 7)])
+def test_fit_predict_in_one_call_is_bit_identical(ctx, T, Tq, C):
+    """sd_analog_fit_predict*: fit + predict without a fitted state.  On long F = 1 series the per-cell workgroup that merged
+    the sorted runs answers the queries itself (analog_f1_fused_kernel); the result equals analog_fit -> analog_predict bit for
+    bit -- ragged tiles, a masked cell, a cell with a non-finite sample, a cell with a non-finite query, cells the fused kernel
+    hands back (tied training values; a query with a tie on its window boundary) included; query series longer than one pass,
+    series the tile-shaped fit does not serve and short series take the two calls internally.  Host buffers and resident
+    fields, mean_analogs (k = 30), a single analog (k = 1, with and without a threshold) and the kinds the fused kernel does
+    not serve."""
+    rng = np.random.default_rng(T + Tq)
+    X = rng.standard_normal((T, 1, C))
+    y = 2.0 * X[:, 0, :] + rng.standard_normal((T, C))
+    Xq = 1.1 * rng.standard_normal((Tq, 1, C))
+    X[0, 0, 1] = np.nan                                  # masked cell (core.py:35-37)
+    if C > 4:
+        X[T // 2, 0, 2] = np.inf                         # a non-finite training sample
+        Xq[Tq // 3, 0, 3] = np.nan                       # a non-finite query: its cell is reported, that row is NaN
+        X[:, 0, 4] = np.round(X[:, 0, 4] * 8) / 8        # tied training values: handed back by the tag pass
+    if C > 6:
+        c = 6                                            # a tie on a window boundary: query midway between two training values, k = 1 ... 30
+        order = np.argsort(X[:, 0, c])
+        a, b = X[order[100], 0, c], X[order[101], 0, c]
+        X[order[101], 0, c] = b = a + 0.25
+        Xq[5, 0, c] = a + 0.125
+    cases = [(30, 3, None), (1, 3, None), (1, 0, 0.3), (30, 2, None), (30, 3, 0.3), (2, 3, None)]
+    for k, kind, thresh in cases:
+        st = ctx.analog_fit(X, y)
+        ref, sref = ctx.analog_predict(st, Xq, k, kind, thresh=thresh)
+        st.close()
+        got, sgot = ctx.analog_fit_predict(X, y, Xq, k, kind, thresh=thresh)
+        assert sgot.tolist() == sref.tolist(), (k, kind, thresh)
+        assert same_bits(got, ref), (k, kind, thresh)
+    if C > 4:
+        assert sref[1] == 1 and sref[2] == 2 and sref[3] == 2
+    dX, dy, dq = ctx.to_device(X), ctx.to_device(y), ctx.to_device(Xq)
+    st = ctx.analog_fit(dX, dy)
+    ref, sref = ctx.analog_predict(st, dq, 30, 3)
+    got, sgot = ctx.analog_fit_predict(dX, dy, dq, 30, 3)
+    assert sgot.tolist() == sref.tolist() and same_bits(got.to_host(), ref.to_host())
+    live = [c for c in range(C) if c not in (1, 2)]
+    rows = np.unique(np.linspace(0, Tq - 1, 12).astype(np.int64))
+    assert_close(got.to_host()[rows][:, :, live[:2]], ao.pointwise_analog(X[:, :, live[:2]], y[:, live[:2]], Xq[rows][:, :, live[:2]], 30, ao.KIND_MEAN),
+                 what="fit_predict vs oracle")
+    st.close()
+
+
+def test_fit_predict_large_grid_is_bit_identical(ctx):
+    """16 384 cells x 14 600 steps, k = 30: the fused call against fit -> predict on the same resident fields, every cell and
+    sampled rows; a few cells with tied training values exercise the hand-back (packed columns through the split path)."""
+    from skdownscale_amd import synth
+
+    T, C, k = 14600, 16384, 30
+    fields = {}
+    for name, stream, kw in (("X", 20, {}), ("y", 20, dict(amp=2.0, stream2=21, amp2=1.0)), ("Xq", 22, {})):
+        d = ctx.empty((T, C))
+        ctx.synth_fill(d, synth.GAUSS, 5, stream, c_offset=0, c_full=C, **kw)
+        fields[name] = d
+    for c in (7, 4099, 16383):  # tied training values (the exact zeros of a dry-day series) in three cells
+        ctx.synth_fill(fields["X"].cells(c, c + 1), synth.PRECIP, 5, 23, c_offset=c, c_full=C, p_dry=0.5)
+    X3, Xq3 = ctx.wrap(fields["X"].ptr, (T, 1, C)), ctx.wrap(fields["Xq"].ptr, (T, 1, C))
+    st = ctx.analog_fit(X3, fields["y"])
+    ref, sref = ctx.analog_predict(st, Xq3, k, 3)
+    st.close()
+    got, sgot = ctx.analog_fit_predict(X3, fields["y"], Xq3, k, 3)
+    assert sgot.tolist() == sref.tolist() and (sgot == 0).all()
+    rows = np.unique(np.linspace(0, T - 1, 48).astype(np.int64))
+    for t in rows:
+        a = ctx.wrap(got.ptr + int(t) * 3 * C * 8, (3, C)).to_host()
+        b = ctx.wrap(ref.ptr + int(t) * 3 * C * 8, (3, C)).to_host()
+        assert same_bits(a, b), f"row {t}"
+    for d in fields.values():
+        d.free()
+    got.free()
+    ref.free()
+
+
 PROB_TIGHT = 1e-6    # exceedance probability vs the reference's objective solved tightly (logistic_kwargs tol=1e-12)
 PROB_DEFAULT = 1e-3  # ... vs the reference's default LogisticRegression: its L-BFGS stops at tol=1e-4, within ~2e-4 of the optimum
 
