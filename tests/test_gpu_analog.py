@@ -443,6 +443,27 @@ def test_fit_predict_in_one_call_is_bit_identical(ctx, T, Tq, C):
     st.close()
 
 
+def test_fit_predict_random_sizes(ctx):
+    """Random series lengths around the widths of the tile-shaped fit (K = 13 / 15, partly filled last runs), query counts up to
+    one pass, k from 1 to 200, continuous and quantised data (quantised: every cell is handed back): fused call == fit -> predict."""
+    rng = np.random.default_rng(404)
+    for case in range(14):
+        T = int(rng.integers(9300, 15361))
+        Tq = int(rng.integers(1, 16385))
+        C = int(rng.integers(1, 20))
+        k = int(rng.choice([1, 2, 7, 30, 200]))
+        X = rng.standard_normal((T, 1, C))
+        if case % 5 == 4:
+            X = np.round(X * 64) / 64
+        y = rng.standard_normal((T, C)) + X[:, 0, :]
+        Xq = 1.3 * rng.standard_normal((Tq, 1, C))
+        st = ctx.analog_fit(X, y)
+        ref, sref = ctx.analog_predict(st, Xq, k, 3)
+        st.close()
+        got, sgot = ctx.analog_fit_predict(X, y, Xq, k, 3)
+        assert sgot.tolist() == sref.tolist() and same_bits(got, ref), (case, T, Tq, C, k)
+
+
 def test_fit_predict_large_grid_is_bit_identical(ctx):
     """16 384 cells x 14 600 steps, k = 30: the fused call against fit -> predict on the same resident fields, every cell and
     sampled rows; a few cells with tied training values exercise the hand-back (packed columns through the split path)."""
