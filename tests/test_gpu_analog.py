@@ -364,7 +364,7 @@ def test_large_grid_is_consistent(ctx):
 def test_full_size_grid_is_consistent(ctx):
     """BASELINE config 4 size (PureAnalog k = 30, F = 1, 100 000 cells x 14 600 steps, fit + predict) through the block
     property: identical 8 192-cell blocks reproduce block 0 bit for bit (any chunk of the fit's tile sort, any workgroup of
-    the window search); the first cells match the oracle's brute-force neighbours."""
+    the window search); the first cells match the oracle's brute-force neighbours; the fused fit + predict call reproduces it."""
     from skdownscale_amd import synth
 
     T, C, B, k = 14600, 100_000, 8192, 30
@@ -388,6 +388,12 @@ def test_full_size_grid_is_consistent(ctx):
     Xqh = fields["Xq"].cells(0, n).to_host()[rows][:, None, :]
     assert_close(got[:, :, :n], ao.pointwise_analog(Xh, yh, Xqh, k, ao.KIND_MEAN), what="full-size grid vs oracle")
     st.close()
+    # the same grid through the fused call (what bench.py config 4 times): bit-identical on the sampled rows
+    out2, status2 = ctx.analog_fit_predict(ctx.wrap(fields["X"].ptr, (T, 1, C)), fields["y"], ctx.wrap(fields["Xq"].ptr, (T, 1, C)), k, 3)
+    assert (status2 == 0).all()
+    for i, t in enumerate(rows):
+        assert np.array_equal(ctx.wrap(out2.ptr + int(t) * 3 * C * 8, (3, C)).to_host(), got[i]), f"fused call differs in row {t}"
+    out2.free()
     for d in fields.values():
         d.free()
     out.free()
