@@ -36,3 +36,13 @@ def test_random_grids_through_the_pointwise_downscaler():
     import fuzz_pointwise
 
     assert fuzz_pointwise.main(120.0, 9000, 200) == 0
+
+
+@pytest.mark.parametrize("seed", [41, 42])
+def test_random_configurations_of_the_fused_bcsd_kernels(seed):
+    """tools/dev/fuzz_fx.py: bcsd_fx_kernel / bcsd_fxp_kernel against the NumPy oracle -- every sort width, equal / longer / shorter
+    predict series, partly filled lanes, exact ties, near-tied observations, zero-inflated series, masked and non-finite cells, one
+    call and via a fitted state, and the state again with random tails (`extrapolate`, `n_endpoints`: sd_bcsd_state_set_tails)."""
+    import fuzz_fx
+
+    fuzz_fx.main(250, seed)

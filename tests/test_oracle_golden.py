@@ -331,6 +331,30 @@ def test_detrended_mapping_of_a_40_year_series_oracle_matches_golden():
             assert_close(out, g[f"out_{name}"][:, c], what=f"QuantileMapper(detrend) 14 600 samples {name} cell {c}")
 
 
+def test_bcsd_qt_kwargs_oracle_matches_golden():
+    """g19_qt_kwargs.npz (BcsdTemperature / BcsdPrecipitation with qm_kwargs={'qt_kwargs': ...} in the real reference; predict
+    series longer than the fit series, so the tails of the fitted inverse CDFs are reached): the oracle with `extrapolate` /
+    `n_endpoints` (quantile.py:523-545) reproduces every variant; `alpha` / `beta` have no parameter in the oracle because they
+    have no effect in the reference (tas6 == the defaults, asserted when the golden was made)."""
+    from skdownscale_amd import synth
+
+    g = load("g19_qt_kwargs")
+    T, Tp, C = int(g["T"]), int(g["Tp"]), int(g["C"])
+    index, index_p = synth.daily_calendar(T), synth.daily_calendar(Tp)
+    cells = np.arange(C)
+    tas = [synth.tas_field(n, int(g["seed"]), i, cells, int(g["c_full"])) for n, i in (("X_hist", index), ("y_obs", index), ("X_fut", index_p))]
+    pr = [synth.pr_field(n, int(g["seed"]), t, cells, int(g["c_full"])) for n, t in (("X_hist", T), ("y_obs", T), ("X_fut", Tp))]
+    variants = [dict(n_endpoints=5), dict(n_endpoints=3, extrapolate="both"), dict(extrapolate="min"), dict(extrapolate="max"),
+                dict(extrapolate=None), dict(extrapolate="1to1"), dict(), dict(n_endpoints=40)]
+    assert len(variants) == int(g["n_variants"])
+    for kind, (X, y, Xp), n, key in ((bo.TAS, tas, len(variants), "tas"), (bo.PR, pr, int(g["n_pr"]), "pr")):
+        for i, kw in enumerate(variants[:n]):
+            out, st = bo.pointwise_fit_predict(kind, X, y, Xp, month_gid(index), month_gid(index_p), **kw)
+            assert (st == 0).all()
+            assert_close(out, g[f"{key}{i}"], what=f"qt_kwargs {kw} {key}")
+    assert not np.allclose(g["tas2"], g["tas3"])  # (the variants do differ)
+
+
 def test_pointwise_transformer_loop_oracle_matches_golden():
     """g18_pointwise_transformers.npz (the reference's per-cell loop: CunnaneTransformer transform / inverse_transform,
     QuantileMapper.transform, BcsdTemperature.y_climo_) against the NumPy restatements."""

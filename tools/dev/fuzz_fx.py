@@ -88,6 +88,16 @@ def main(n_cases, seed):
             out2, st2 = ctx.bcsd_predict(state, dXp, gid_p)
             assert np.array_equal(st2, est), (what, st2, est)
             assert_close(out2.to_host(), exp, what="state " + what)
+            if rng.random() < 0.5:
+                # the same state with other tails (qm_kwargs={'qt_kwargs': ...}: sd_bcsd_state_set_tails)
+                ex = [None, "min", "max", "both", "1to1"][int(rng.integers(5))]
+                ne = int(rng.choice([1, 2, 3, 5, 10, 25, 60]))
+                state.set_tails(ex, ne)
+                exp3, est3 = bo.pointwise_fit_predict(kind, X, y, Xp, gid, gid_p, G=G, return_anoms=ra, extrapolate=ex, n_endpoints=ne)
+                out3, st3 = ctx.bcsd_predict(state, dXp, gid_p)
+                assert np.array_equal(st3, est3), (what, ex, ne)
+                assert_close(out3.to_host(), exp3, what=f"state, extrapolate={ex} n_endpoints={ne} " + what)
+                stats["tails"] = stats.get("tails", 0) + 1
             state.close()
             stats["state"] += 1
         stats["cases"] += 1
