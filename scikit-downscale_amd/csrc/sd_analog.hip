@@ -344,7 +344,6 @@ size_t fused_lds_bytes(int np, int64_t T) { return sizeof(double) * (size_t)(np 
 int fit_predict_split(sd_ctx* ctx, const double* X, const double* y, int64_t ld, int64_t T, int F, int64_t C, const double* Xq,
                       int64_t ld_q, int64_t Tq, int k, int kind, int has_thresh, double thresh, double* out, int64_t ld_out,
                       int32_t* cell_status) {
-    SD_CHECK_ARG(ld_q == ld, "sd_analog_fit_predict: this configuration needs ld_q == ld");
     sd_analog_state* st = nullptr;
     SD_TRY(sd_analog_fit_dev(ctx, X, y, ld, T, F, C, &st));
     const int rc = predict_common(0, ctx, st, Xq, ld_q, Tq, k, kind, has_thresh, thresh, nullptr, 0, out, ld_out, nullptr, nullptr, cell_status);
@@ -435,6 +434,16 @@ int fit_predict_dev(sd_ctx* ctx, const double* X, const double* y, int64_t ld, i
     SD_HIP(hipStreamSynchronize(ctx->stream));
 #ifdef SD_DEV
     if (sd_dev_env("SD_ANALOG_COUNT")) fprintf(stderr, "analog fit_predict: %d of %lld cells handed back to the split path\n", nw, (long long)C);
+    if (sd_dev_env("SD_FUSED_TRACE")) {  // phase clocks (100 MHz ticks of s_memtime) of the first cells of workgroup 0, last chunk
+        long long h[128];
+        SD_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(sd_fused_trace), sizeof(h)));
+        for (int r = 0; r < 8; ++r) {
+            fprintf(stderr, "fused trace cell %d: runs %lld merge %lld tags+xs %lld search %lld yx %lld prefix %lld outputs %lld (means %lld, prefix of squares %lld, barrier %lld, spreads + stores %lld)\n", r, h[r * 16 + 1] - h[r * 16],
+                    h[r * 16 + 2] - h[r * 16 + 1], h[r * 16 + 3] - h[r * 16 + 2], h[r * 16 + 4] - h[r * 16 + 3], h[r * 16 + 5] - h[r * 16 + 4],
+                    h[r * 16 + 6] - h[r * 16 + 5], h[r * 16 + 7] - h[r * 16 + 6], h[r * 16 + 8] - h[r * 16 + 6], h[r * 16 + 9] - h[r * 16 + 8],
+                    h[r * 16 + 10] - h[r * 16 + 9], h[r * 16 + 7] - h[r * 16 + 10]);
+        }
+    }
 #endif
     if (nw == 0) return SD_OK;
     // cells handed back (ties among the training values or on a window boundary): the split path answers them.  Few: on packed

@@ -905,6 +905,15 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
 // spilled registers and 3 ms per 16 384 cells for a case continuous data never produces) -- are appended to `worklist`; the
 // host answers them with the split path.  Pointers are relative to the chunk of cells of this
 // launch, `cell0` is the grid index of its first cell.
+#ifdef SD_DEV
+__device__ long long sd_fused_trace[8 * 16];  // development library: phase clocks of the first 8 cells of workgroup 0 (SD_FUSED_TRACE)
+#define SD_FSTAMP(slot)                                                                                                     \
+    do {                                                                                                                    \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && traced < 8) sd_fused_trace[traced * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define SD_FSTAMP(slot) do { } while (0)
+#endif
 template <int K>
 __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __restrict__ runs, int np,
                                                                const int32_t* __restrict__ odd_flags,
@@ -937,6 +946,9 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
     int nsteps = 0;
     while ((1 << nsteps) < (k + 1 < M + 1 ? k + 1 : M + 1)) ++nsteps;
     int64_t step, end;
+#ifdef SD_DEV
+    int traced = 0;
+#endif
     for (int64_t c = first_cell(C, &step, &end); c < end; c += step) {
         global_f64* const orow = (global_f64*)(pa.out + c * 3 * pa.oc_Tq);  // (uniform) staging rows: predictions, probabilities, spreads
         global_f64* const prow = orow + pa.oc_Tq;
@@ -952,6 +964,7 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
         }
         // ---- the sorted runs of 64 * K tagged keys -> merge rounds 6 .. (analog_sort2_kernel<K, true>)
         __syncthreads();
+        SD_FSTAMP(0);
         {
             SD_TID();
             const double* rc = runs + c * (int64_t)np;
@@ -968,9 +981,11 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
             }
         }
         __syncthreads();
+        SD_FSTAMP(1);
         {
             SD_TID();
             sdsort::block_merge_rounds<K>(buf, np, xch, tid, nthr, 6);
+            SD_FSTAMP(2);
             bool odd = odd_flags[c] != 0;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
@@ -1015,6 +1030,7 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
             if (tid == 0) buf[n] = inf;
         }
         __syncthreads();
+        SD_FSTAMP(3);
         // ---- generation 1 (analog_f1_mean3_kernel): sorted training values -> window start of every query
         SD_TID();
         const double* qrow = Xq + c * Tq;
@@ -1094,6 +1110,7 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
             if (tid == 0) worklist[atomicAdd(work_count, 1)] = (int32_t)(cell0 + c);
             continue;
         }
+        SD_FSTAMP(4);
         // ---- y in training order -> buf (and its mean, summed as analog_sort2_kernel does); gathered -> buf = yx
         double ybar;
         {
@@ -1131,6 +1148,7 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
             }
         }
         __syncthreads();
+        SD_FSTAMP(5);
         if (k == 1) {
             // a single analog (best_analog, or n_analogs = 1: gard.py:291-296)
 #pragma unroll
@@ -1180,10 +1198,12 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
         }
         if (tid == nthr - 1 && beg + per == n) buf[n] = ra;
         __syncthreads();
+        SD_FSTAMP(6);
         double m1[kPhQ];
 #pragma unroll
         for (int i = 0; i < kPhQ; ++i) m1[i] = (okmask >> i) & 1u ? div_by(buf[SD_LW(i) + k] - buf[SD_LW(i)], kk, rk) : 0.0;
         // ---- generation 3: exclusive prefix sums of d^2 -> spreads, outputs
+        SD_FSTAMP(8);
         __syncthreads();
         if (lane == 63) wsum[wave] = ib;
         __syncthreads();
@@ -1196,7 +1216,9 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
             rb += d[i] * d[i];
         }
         if (tid == nthr - 1 && beg + per == n) buf[n] = rb;
+        SD_FSTAMP(9);
         __syncthreads();
+        SD_FSTAMP(10);
 #pragma unroll
         for (int i = 0; i < kPhQ; ++i) {
             const int idx = tid + i * nthr;
@@ -1214,6 +1236,10 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
             erow[idx] = err;
             if (!skip_prob) prow[idx] = pred != pred ? nan : 1.0;  // gard.py:346
         }
+        SD_FSTAMP(7);
+#ifdef SD_DEV
+        ++traced;
+#endif
     }
 #undef SD_LW
 #undef SD_TID

@@ -442,6 +442,15 @@ def test_fit_predict_in_one_call_is_bit_identical(ctx, T, Tq, C):
     ref, sref = ctx.analog_predict(st, dq, 30, 3)
     got, sgot = ctx.analog_fit_predict(dX, dy, dq, 30, 3)
     assert sgot.tolist() == sref.tolist() and same_bits(got.to_host(), ref.to_host())
+    # queries that are a cell range of a wider resident field (their pitch differs from the training fields'): fused and split path
+    wide = ctx.to_device(np.concatenate([Xq[:, 0, :], Xq[:, 0, :]], axis=1))  # [Tq, 2 C]
+    from skdownscale_amd.engine import DeviceArray
+
+    qv = DeviceArray(ctx, (Tq, 1, C), dptr=wide.cells(C, 2 * C).ptr, owner=False, ld=2 * C)
+    for kind in (3, 2):
+        g2, s2 = ctx.analog_fit_predict(dX, dy, qv, 30, kind)
+        r2, rs2 = ctx.analog_predict(st, dq, 30, kind)
+        assert s2.tolist() == rs2.tolist() and same_bits(g2.to_host(), r2.to_host()), kind
     live = [c for c in range(C) if c not in (1, 2)]
     rows = np.unique(np.linspace(0, Tq - 1, 12).astype(np.int64))
     assert_close(got.to_host()[rows][:, :, live[:2]], ao.pointwise_analog(X[:, :, live[:2]], y[:, live[:2]], Xq[rows][:, :, live[:2]], 30, ao.KIND_MEAN),
