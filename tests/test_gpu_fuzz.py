@@ -46,3 +46,12 @@ def test_random_configurations_of_the_fused_bcsd_kernels(seed):
     import fuzz_fx
 
     fuzz_fx.main(250, seed)
+
+
+def test_random_configurations_of_the_fused_analog_call():
+    """tools/dev/fuzz_analog_fused.py: sd_analog_fit_predict* (analog_f1_fused_kernel, its hand-back of tied cells, its internal
+    fall-back to the two calls) against analog_fit -> analog_predict, bit for bit; 6 140 cases passed at the end of round 4
+    (profiles/r04/fuzz_analog_fused_summary.txt)."""
+    import fuzz_analog_fused
+
+    fuzz_analog_fused.main(300, 5)
