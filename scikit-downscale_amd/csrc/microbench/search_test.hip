@@ -130,6 +130,99 @@ __global__ void __launch_bounds__(1024) search_kernel(const double* __restrict__
     }
 }
 
+// ---- window start of the k nearest values (analog_f1_mean3_kernel, generation 1) after the lower bound p:
+//   R0  what the kernels do: 5 bisection steps over the k + 1 candidates p - k .. p on  (q - x[L])^2 > (q - x[L + k])^2
+//   R1  fixed strides 16, 8, 4, 2, 1 from p - k on  x[L] + x[L + k] < 2 q  (one addition and one compare instead of two subtractions,
+//       two multiplications and a compare; the kernels' exact separation check afterwards decides whether a window is accepted, so
+//       the start only has to be right, not derived the same way)
+__device__ __forceinline__ double sqd(double q, double x) {
+    const double d = q - x;
+    return d * d;
+}
+template <int R>
+__global__ void __launch_bounds__(1024) refine_kernel(const double* __restrict__ xs, int n, const double* __restrict__ q, int nq, int k, int reps,
+                                                      int* __restrict__ out, unsigned long long* __restrict__ clocks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* buf = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int i = tid; i <= n; i += nthr) buf[i] = i < n ? xs[i] : __longlong_as_double(0x7ff0000000000000ll);
+    double qv[kQ];
+#pragma unroll
+    for (int i = 0; i < kQ; ++i) {
+        const int j = tid + i * nthr;
+        qv[i] = j < nq ? q[j] : 0.0;
+    }
+    __syncthreads();
+    const int M = n - k > 0 ? n - k : 0;
+    int nsteps = 0;
+    while ((1 << nsteps) < (k + 1 < M + 1 ? k + 1 : M + 1)) ++nsteps;
+    int res[kQ];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+        for (int i0 = 0; i0 < kQ; i0 += 2) {
+            int pos[2] = {-1, -1};
+            double a[2] = {qv[i0], qv[i0 + 1]};
+#pragma unroll 1
+            for (int len = n; len > 1;) {
+                const int half = next_half(len);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pos[j] += buf[pos[j] + half] < a[j] ? half : 0;
+            }
+            int lo[2], hi[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = pos[j] + 1 + (buf[pos[j] + 1] < a[j] ? 1 : 0);
+                lo[j] = p - k > 0 ? p - k : 0;
+                hi[j] = p < M ? p : M;
+            }
+            if (R == 0) {
+#pragma unroll 1
+                for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int mid = (lo[j] + hi[j]) >> 1;
+                        const bool act = lo[j] < hi[j];
+                        const bool right = sqd(a[j], buf[mid]) > sqd(a[j], buf[mid + k]);
+                        lo[j] = (act && right) ? mid + 1 : lo[j];
+                        hi[j] = (act && !right) ? mid : hi[j];
+                    }
+                }
+            } else {
+                int ps[2] = {lo[0] - 1, lo[1] - 1};  // last start known to lie left of the window
+                const double a2[2] = {a[0] + a[0], a[1] + a[1]};
+#pragma unroll 1
+                for (int half = 1 << (nsteps - 1); half >= 1; half >>= 1) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int idx = ps[j] + half;
+                        const int ic = idx < M ? idx : M;
+                        const bool right = idx < hi[j] && (buf[ic] + buf[ic + k]) < a2[j];
+                        ps[j] += right ? half : 0;
+                    }
+                }
+                lo[0] = ps[0] + 1;
+                lo[1] = ps[1] + 1;
+            }
+            res[i0] = lo[0];
+            res[i0 + 1] = lo[1];
+        }
+        if (rep + 1 < reps) {
+#pragma unroll
+            for (int i = 0; i < kQ; ++i) qv[i] += (double)(res[i] >> 20);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) clocks[blockIdx.x] = t1 - t0;
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < kQ; ++i) {
+            const int j = tid + i * nthr;
+            if (j < nq) out[j] = res[i];
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 14600, reps = argc > 2 ? atoi(argv[2]) : 20;
     const int nq = 1024 * kQ < n ? 1024 * kQ : n;
@@ -193,5 +286,32 @@ int main(int argc, char** argv) {
                        names[mode], bad ? "WRONG" : "ok   ", mean / reps, nq, nb, ms, reps);
             if (bad) printf("   %d of %d lower bounds differ\n", bad, nq);
         }
+    // ---- lower bound + window start (k = 30)
+    const int k = 30;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    std::vector<int> l0(nq), l1(nq);
+    const char* rnames[2] = {"R0 lower bound + window start by squared distances (the kernels)", "R1 lower bound + window start by x[L] + x[L + k] < 2 q, fixed strides"};
+    for (int round = 0; round < 2; ++round)
+        for (int mode = 0; mode < 2; ++mode) {
+            CHECK(hipEventRecord(e0));
+            if (mode == 0) hipLaunchKernelGGL(refine_kernel<0>, dim3(nb), dim3(1024), lds, 0, dxs, n, dq, nq, k, reps, dout, dclk);
+            if (mode == 1) hipLaunchKernelGGL(refine_kernel<1>, dim3(nb), dim3(1024), lds, 0, dxs, n, dq, nq, k, reps, dout, dclk);
+            CHECK(hipGetLastError());
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            std::vector<unsigned long long> clk(nb);
+            CHECK(hipMemcpy((mode == 0 ? l0 : l1).data(), dout, sizeof(int) * nq, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(clk.data(), dclk, sizeof(unsigned long long) * nb, hipMemcpyDeviceToHost));
+            double mean = 0;
+            for (auto c : clk) mean += (double)c;
+            mean /= nb;
+            if (round == 1) printf("%-75s %9.0f clocks per pass, kernel %.3f ms for %d passes\n", rnames[mode], mean / reps, ms, reps);
+        }
+    int diff = 0;
+    for (int i = 0; i < nq; ++i) diff += l0[i] != l1[i];
+    printf("window starts that differ between R0 and R1: %d of %d (they go to the separation check / exact walk either way)\n", diff, nq);
     return 0;
 }
