@@ -33,9 +33,28 @@
 #include "sd_wave.h"
 #include "sd_wsort.h"
 
+#ifdef SD_PHASE_MARKS
+#define SDPH(name) asm volatile("; SDPHASE " name)
+#else
+#define SDPH(name)
+#endif
+
 namespace sdfx {
 
 using namespace sdw;
+
+// Development library: phase clocks (s_memtime) of sampled workgroups of the FULL temperature kernel (SD_FX_TRACE,
+// tools/dev/trace_fx.py): [kTraceWgs][kTraceSlots], written by wave 0 of every kTraceStride-th workgroup.
+#ifdef SD_DEV
+constexpr int kTraceWgs = 256, kTraceSlots = 16, kTraceStride = 449;
+__device__ long long sd_fx_trace[kTraceWgs * kTraceSlots];
+#define SDT(slot)                                                                                              \
+    do {                                                                                                       \
+        if (traced) tstamp[slot] = (long long)__builtin_amdgcn_s_memtime();                                    \
+    } while (0)
+#else
+#define SDT(slot)
+#endif
 using sdrs::Params;
 
 typedef const Params __attribute__((address_space(4)))* ParamsPtr;
@@ -113,9 +132,95 @@ __device__ __forceinline__ unsigned from_prev_lane(unsigned v, unsigned edge) {
 }
 
 // ---- tile movement with the swizzled row layout ---------------------------------------------------------------
-template <int RPT, int K>
+// one v_cmp_class_f64 per value (NaN or +-inf) instead of the and + compare of finite64
+__device__ __forceinline__ bool nonfinite64(double v) { return __builtin_amdgcn_class(v, 0x207); }
+
+// FULL (template parameter of the kernels): every segment the launch serves has a multiple of K samples -- a lane is all
+// data or all pad -- and at least kRowsPerPass * (K / 2 - 1) + 1 of them -- every thread's first K / 2 - 1 rows of a tile
+// exist, only the last pass is predicated.  10 of the 12 months of a daily series qualify at K = 20 (1 200 / 1 240 samples).
+template <int K>
+constexpr int full_min_len() { return kRowsPerPass * (K / 2 - 1) + 1; }
+
+// slot of row r (< 2 048) without the division by K * P: floor(r / d) = (r * ceil(2^21 / d)) >> 21 for the divisors in use
+// (checked exhaustively by the static_assert below); one 24-bit multiply, one shift
+template <int K>
+struct SlotDiv {
+    static constexpr unsigned D = (unsigned)Lay<K>::KP;
+    static constexpr unsigned M = ((1u << 21) + D - 1) / D;
+    static constexpr bool ok() {
+        for (unsigned r = 0; r < 2048; ++r)
+            if (((r * M) >> 21) != r / D) return false;
+        return true;
+    }
+    __device__ static int slot(int r) { return kFront + r + (int)(__umul24((unsigned)r, M) >> 21); }
+};
+
+// The time indices of a thread's rows (ord[rr + k * kRowsPerPass]) loaded on their own: the tile loads depend on them, so
+// they are requested as early as registers allow (a table of 64-bit row byte offsets instead -- one add per row -- was
+// measured 5 % slower: twice the registers, the compiler no longer hoisted the table loads of the second tile above the
+// loads of the first).
+template <int RPT, bool FULL>
+__device__ __forceinline__ void rows_load(const int32_t* __restrict__ ord, int nrows, int (&ti)[RPT]) {
+    const int rr = tid_now() >> 2;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = rr + k * kRowsPerPass;
+        ti[k] = ord[(FULL && k + 1 < RPT) || r < nrows ? r : 0];
+    }
+}
+template <int RPT>
+__device__ __forceinline__ void tile_issue_ti(const double* __restrict__ src, int64_t ld, const int (&ti)[RPT], int64_t c0, int64_t C,
+                                              bool vec_ok, TileRegs<RPT>& t) {
+    const int cp = tid_now() & 3;
+    const int64_t c = c0 + 2 * cp;
+    const bool full = vec_ok && c + 1 < C;
+    if (full) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const double2 v = *reinterpret_cast<const double2*>(row_of(src + c, ti[k], ld));
+            t.v0[k] = v.x;
+            t.v1[k] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const double* q = row_of(src + c, ti[k], ld);
+            t.v0[k] = c < C ? q[0] : 0.0;
+            t.v1[k] = c + 1 < C ? q[1] : 0.0;
+        }
+    }
+}
+// the tile out through row indices loaded earlier
+template <int K, bool FULL>
+__device__ __forceinline__ void store_tile_ti(double* __restrict__ dst, int64_t ld, const int (&ti)[K / 2], int nrows, int64_t c0, int64_t C,
+                                              bool vec_ok, const double* tile, int RS) {
+    constexpr int RPT = K / 2;
+    const int tid = tid_now();
+    const int cp = tid & 3, rr = tid >> 2;
+    const int64_t c = c0 + 2 * cp;
+    const double* s0 = tile + (2 * cp) * RS;
+    const double* s1 = s0 + RS;
+    const bool full = vec_ok && c + 1 < C;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = rr + k * kRowsPerPass;
+        if ((FULL && k + 1 < RPT) || r < nrows) {
+            double* q = row_of(dst + c, ti[k], ld);
+            const int s = SlotDiv<K>::slot(r);
+            if (full) {
+                *reinterpret_cast<double2*>(q) = make_double2(s0[s], s1[s]);
+            } else {
+                if (c < C) q[0] = s0[s];
+                if (c + 1 < C) q[1] = s1[s];
+            }
+        }
+    }
+}
+
+template <int RPT, int K, bool FULL = false>
 __device__ __forceinline__ void tile_commit_sw(const TileRegs<RPT>& t, int nrows, int64_t c0, int64_t C, double* tile, int RS,
                                                int32_t* status, int* bad_cell) {
+    static_assert(SlotDiv<K>::ok(), "slot multiplier");
     const int tid = tid_now();
     const int cp = tid & 3, rr = tid >> 2;
     const int64_t c = c0 + 2 * cp;
@@ -125,10 +230,11 @@ __device__ __forceinline__ void tile_commit_sw(const TileRegs<RPT>& t, int nrows
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int r = rr + k * kRowsPerPass;
-        if (r < nrows) {
-            bad0 |= !finite64(t.v0[k]);
-            bad1 |= !finite64(t.v1[k]);
-            const int s = Lay<K>::slot(r);
+        // (rows past the segment were loaded from row 0 of the segment: testing them too flags nothing new)
+        bad0 |= nonfinite64(t.v0[k]);
+        bad1 |= nonfinite64(t.v1[k]);
+        if ((FULL && k + 1 < RPT) || r < nrows) {
+            const int s = SlotDiv<K>::slot(r);
             d0[s] = t.v0[k];
             d1[s] = t.v1[k];
         }
@@ -162,11 +268,10 @@ __device__ __forceinline__ void store_tile_sw(double* __restrict__ dst, int64_t 
         }
     }
 }
-
 // column sums of one group's rows for the 8 cells of the tile from issued tile registers, as far as one wave gets: the wave's
 // partial sums go to scratch[wave][cell]; the caller adds the 8 partials of its cell behind its next barrier (sd_wave.h's
 // tile_reduce_mean does the same with two barriers of its own)
-template <int RPT>
+template <int RPT, bool FULL = false>
 __device__ __forceinline__ void tile_reduce_partials(const TileRegs<RPT>& t, int nrows, int64_t c0, int64_t C, double* scratch,
                                                      int32_t* status, int wave, int lane, int* bad_cell) {
     const int tid = tid_now();
@@ -176,11 +281,17 @@ __device__ __forceinline__ void tile_reduce_partials(const TileRegs<RPT>& t, int
     bool bad0 = false, bad1 = false;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const bool in = rr + k * kRowsPerPass < nrows;
-        bad0 |= in && !finite64(t.v0[k]);
-        bad1 |= in && !finite64(t.v1[k]);
-        s0 += in ? t.v0[k] : 0.0;
-        s1 += in ? t.v1[k] : 0.0;
+        // (rows past the segment were loaded from row 0 of the segment: testing them too flags nothing new)
+        bad0 |= nonfinite64(t.v0[k]);
+        bad1 |= nonfinite64(t.v1[k]);
+        if (FULL && k + 1 < RPT) {
+            s0 += t.v0[k];
+            s1 += t.v1[k];
+        } else {
+            const bool in = rr + k * kRowsPerPass < nrows;
+            s0 += in ? t.v0[k] : 0.0;
+            s1 += in ? t.v1[k] : 0.0;
+        }
     }
     if (bad0 && c < C) atomicOr(&status[c], SDI_NONFINITE);
     if (bad1 && c + 1 < C) atomicOr(&status[c + 1], SDI_NONFINITE);
@@ -261,9 +372,9 @@ __device__ __forceinline__ double make_keys_impl(const double (&v)[K], int m, in
     keys_from_range<K, ZC, FULL>(v, m, lane, lo, wave_max_f64(hi), key);
     return lo;
 }
-template <int K, bool ZC = false>
+template <int K, bool ZC = false, bool FULL = false>
 __device__ __forceinline__ double make_keys(const double (&v)[K], int m, int lane, unsigned (&key)[K]) {
-    if (m % K == 0) return make_keys_impl<K, ZC, true>(v, m, lane, key);  // wave-uniform (the whole launch, in fact)
+    if (FULL || m % K == 0) return make_keys_impl<K, ZC, true>(v, m, lane, key);  // wave-uniform (the whole launch, in fact)
     return make_keys_impl<K, ZC, false>(v, m, lane, key);
 }
 
@@ -320,14 +431,22 @@ __device__ __forceinline__ int fix_equal_q(unsigned (&k)[K], unsigned rowb, int 
     return kUnsorted;
 }
 
-template <int K, bool IDENT>
+template <int K, bool IDENT, bool FULL>
 __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
+    static_assert(!FULL || IDENT, "FULL launches serve groups of equal fit / predict length");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();  // Params is the only kernel argument
     constexpr int NR = K / 2;  // rows per thread of a tile (64 K rows, 128 per pass)
     constexpr int CH = K >= 20 ? K / 4 : K >= 14 ? K / 2 : K;  // samples per rolling-mean chunk (bounded register pressure)
     static_assert(K % 2 == 0 && K % CH == 0, "even K");
     using L = Lay<K>;
+    // the row indices of the y tile and of the output tile are requested ahead of the barriers in front of their use (10
+    // registers each, for which only the FULL instantiation has room)
+#ifdef SD_FX_LATEROWS
+    constexpr bool kEarlyRows = false;
+#else
+    constexpr bool kEarlyRows = FULL;
+#endif
 #ifdef SD_DEV
     const int abl = p->dev_flags;  // SD_FZ_ABLATE: 1 no sort of u, 2 no sort of y, 4 no x_hist, 8 no fix-ups, 16 no store, 32 no y load,
                                    // 64 no x_fut load, 128 no rolling mean (timing only: results are wrong)
@@ -344,6 +463,9 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
     if (threadIdx.x >= 32 && threadIdx.x < 32 + kW) bad_cell[threadIdx.x - 32] = 0;
 
 #ifdef SD_DEV
+    const bool traced = FULL && (abl & 0x800) != 0 && blockIdx.x % kTraceStride == 7 && blockIdx.x / kTraceStride < (unsigned)kTraceWgs;  // (uniform)
+    long long tstamp[kTraceSlots] = {};
+    SDT(0);
     if ((abl >> 12) != 0 && blockIdx.x < 512u) {
         // SD_FZ_ABLATE bits 12.. = T: the first generation of workgroups starts spread over ~T microseconds
         const unsigned h = (blockIdx.x * 2654435761u) >> 20;  // 12 bits
@@ -378,30 +500,37 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
     __syncthreads();  // bad_cell zeroed before the commits below may set it
 
     // ---- x climatology (bcsd.py:222) + the x_fut tile ---------------------------------------------------
+    SDPH("x_tiles");
     double xc = 0.0;
     bool xc_from_partials = false;  // (workgroup-uniform)
     {
         SD_LANE();
         TileRegs<NR> xf;
+        int tp[NR];
+        rows_load<NR, FULL>(p->ord_p + begp, m, tp);
         if (p->from_state) {
             if (cell_ok) xc = p->x_climo[seg];
-            tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
+            tile_issue_ti<NR>(p->Xp, p->ld_p, tp, c0, p->C, vec_p, xf);
         } else if (n > 0 && !(abl & 4)) {
             TileRegs<NR> xh;
-            tile_issue<NR>(p->X, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, xh);
-            if (!(abl & 64)) tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
-            tile_reduce_partials<NR>(xh, n, c0, p->C, scratch, p->status_fit, wave, lane, bad_cell);
+            int tf[NR];
+            rows_load<NR, FULL>(p->ord_f + begf, n, tf);
+            tile_issue_ti<NR>(p->X, p->ld, tf, c0, p->C, vec_f, xh);
+            if (!(abl & 64)) tile_issue_ti<NR>(p->Xp, p->ld_p, tp, c0, p->C, vec_p, xf);
+            tile_reduce_partials<NR, FULL>(xh, n, c0, p->C, scratch, p->status_fit, wave, lane, bad_cell);
             xc_from_partials = true;
         } else if (!(abl & 64)) {
-            tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
+            tile_issue_ti<NR>(p->Xp, p->ld_p, tp, c0, p->C, vec_p, xf);
         }
-        if (!(abl & 64)) tile_commit_sw<NR, K>(xf, m, c0, p->C, tile, RS, p->status_p, bad_cell);
+        SDT(1);  // x tiles requested, column sums reduced
+        if (!(abl & 64)) tile_commit_sw<NR, K, FULL>(xf, m, c0, p->C, tile, RS, p->status_p, bad_cell);
         if (lane < kFront) {
             row[lane] = 0.0;
             row[L::slot(m + lane)] = 0.0;
         }
     }
     __syncthreads();
+    SDT(2);  // x_fut tile in the rows
     if (xc_from_partials) {  // x_climo (bcsd.py:222): the waves' partial column sums, in wave order
         double tot = 0.0;
 #pragma unroll
@@ -410,13 +539,16 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
     }
 
     // ---- shift (kept), shifted series -> row, keys -> sort ------------------------------------------------
+    SDPH("rolling");
     double shift[K];
     unsigned ku[K];  // sorted keys of the shifted series: tag = time slot of the sample with that rank
     bool redo = false;
+    int ty[NR];  // time indices of this thread's rows of the y tile
     {
         SD_LANE();
         const bool has = K * lane < m;  // the lane's block starts inside the segment
         const int bl = has ? lane : 0;  // lanes past the segment read lane 0's block (values unused)
+        const bool first_lane = bl == 0, last_lane = K * (bl + 1) == m;  // (FULL: the only lanes with clipped windows)
         const double* ob = row + L::own(bl);
         const double* pb = row + (kFront + K * bl + (bl > 0 ? (bl - 1) / L::P : 0));  // pb[-k] = sample K*bl - k
         const double* nb = row + (kFront + K * (bl + 1) + (bl + 1) / L::P);              // nb[k]  = sample K*(bl+1) + k
@@ -437,12 +569,30 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
                 double s = 0.0;
 #pragma unroll
                 for (int d = 0; d < 9; ++d) s += w[ii + d];
-                const int j = K * bl + cbeg + ii;  // (lanes past the segment redo lane 0's samples: in-range values for the extremes)
-                const int lo = j - 4 > 0 ? j - 4 : 0;
-                const int hi = j + 5 < m ? j + 5 : m;
-                const int cnt = hi - lo > 1 ? (hi - lo < 10 ? hi - lo : 9) : 1;
-                const double cd = (double)cnt;
-                const double rc = rcp[cnt];
+                double cd, rc;
+                if constexpr (FULL) {
+                    // the window is clipped for the first four samples of the first lane and the last four of the last
+                    // lane only (a lane is all data, the segment has more than one lane): constants elsewhere
+                    const int i = cbeg + ii;  // (a constant once the loops are unrolled)
+                    constexpr double kRc[10] = {0.0, 1.0, 0.5, 1.0 / 3.0, 0.25, 0.2, 1.0 / 6.0, 1.0 / 7.0, 0.125, 1.0 / 9.0};  // = fill_rcp_table
+                    cd = 9.0;
+                    rc = kRc[9];
+                    if (i < 4) {
+                        cd = first_lane ? (double)(5 + i) : cd;
+                        rc = first_lane ? kRc[5 + i] : rc;
+                    }
+                    if (i >= K - 4) {  // (K = 4: every sample is in both classes, a lane in at most one)
+                        cd = last_lane ? (double)(K + 4 - i) : cd;
+                        rc = last_lane ? kRc[K + 4 - i] : rc;
+                    }
+                } else {
+                    const int j = K * bl + cbeg + ii;  // (lanes past the segment redo lane 0's samples: in-range values for the extremes)
+                    const int lo = j - 4 > 0 ? j - 4 : 0;
+                    const int hi = j + 5 < m ? j + 5 : m;
+                    const int cnt = hi - lo > 1 ? (hi - lo < 10 ? hi - lo : 9) : 1;
+                    cd = (double)cnt;
+                    rc = rcp[cnt];
+                }
                 const double q = s * rc;
                 const double mean = __builtin_fma(__builtin_fma(-cd, q, s), rc, q);  // correctly rounded s / cnt
                 const double sh = mean - xc;                                           // bcsd.py:253
@@ -452,17 +602,34 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
             __builtin_amdgcn_sched_barrier(0);
         }
         wave_fence();  // every lane has read its window
+        SDT(3);  // rolling mean
+        SDPH("u_store_keys");
         {
             const unsigned a0 = rowb + 8u * (unsigned)L::own(lane);
+            if constexpr (FULL) {
+                if (has) {
 #pragma unroll
-            for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < m ? a0 + 8u * (unsigned)i : spare, u[i]);
+                    for (int i = 0; i < K; ++i) lds_store_f64(a0 + 8u * (unsigned)i, u[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < m ? a0 + 8u * (unsigned)i : spare, u[i]);
+            }
         }
-        make_keys<K>(u, m, lane, ku);
+        make_keys<K, false, FULL>(u, m, lane, ku);
         wave_fence();
+        SDT(4);  // u stored, keys
+        SDPH("u_sort");
         if (!(abl & 1)) sdws::wave_sort<K>(ku, lane, (m + K - 1) / K);
+        SDT(5);  // sort of u
+        SDPH("u_fix");
+        // the rows of the y tile are named while the fix-up runs: the tile loads behind the vote go out at once
+        if (kEarlyRows && !p->from_state && n > 0) rows_load<NR, FULL>(p->ord_f + begf, n, ty);
         const bool tie = (abl & 8) ? false : fix_equal_q<K>(ku, rowb, lane) != 0;
-        redo = tie && cell_live && bad_cell[wave] == 0 && abl == 0;  // wave-uniform
+        redo = tie && cell_live && bad_cell[wave] == 0 && (abl & 0x7ff) == 0;  // wave-uniform
+        SDT(6);  // fix-up of u
     }
+    SDPH("vote");
     // every wave is done with its row; a workgroup with an ambiguous segment leaves the (tile, group) to RANK / APPLY
     // (not __syncthreads_or: its library reduction takes 256 bytes of static LDS, which costs the second workgroup per CU)
     redo_flag[wave] = redo ? 1 : 0;
@@ -477,8 +644,10 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
         }
         return;
     }
+    SDT(7);  // vote
 
     // ---- y: climatology + sorted observations -----------------------------------------------------------------
+    SDPH("y_tile");
     double yc = 0.0;
     double t[K];  // IDENT: the sorted observations of the ranks this lane owns
     bool redo_y = false;  // a run of equal-q observations too long for the fix-up passes: RANK / APPLY take the (tile, group)
@@ -488,9 +657,13 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
             // (requesting this tile ahead of the sort of u, of its fix-up or of the vote keeps 40 registers in flight where the
             // compiler has none to spare: 28 - 30 spilled registers, measured slower)
             TileRegs<NR> yt;
-            if (!(abl & 32)) tile_issue<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, yt);
-            if (!(abl & 32)) tile_commit_sw<NR, K>(yt, n, c0, p->C, tile, RS, p->status_fit, nullptr);
+            if (!kEarlyRows) rows_load<NR, FULL>(p->ord_f + begf, n, ty);
+            if (!(abl & 32)) tile_issue_ti<NR>(p->y, p->ld, ty, c0, p->C, vec_f, yt);
+            SDT(8);  // y tile requested
+            if (!(abl & 32)) tile_commit_sw<NR, K, FULL>(yt, n, c0, p->C, tile, RS, p->status_fit, nullptr);
             __syncthreads();
+            SDT(9);  // y tile in the rows
+            SDPH("y_keys");
             unsigned ky[K];
             {
                 const int bl = K * lane < n ? lane : 0;
@@ -499,15 +672,32 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
 #pragma unroll
                 for (int i = 0; i < K; ++i) v[i] = ob[i];
                 double s = 0.0;
+                if constexpr (FULL) {
 #pragma unroll
-                for (int i = 0; i < K; ++i) s += K * lane + i < n ? v[i] : 0.0;
+                    for (int i = 0; i < K; ++i) s += v[i];
+                    s = K * lane < n ? s : 0.0;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < K; ++i) s += K * lane + i < n ? v[i] : 0.0;
+                }
                 yc = wave_sum_f64(s) / (double)n;  // bcsd.py:223
-                make_keys<K>(v, n, lane, ky);
+                make_keys<K, false, FULL>(v, n, lane, ky);
             }
+            SDT(10);  // y_climo, keys
+            SDPH("y_sort");
             if (!(abl & 2)) sdws::wave_sort<K>(ky, lane, (n + K - 1) / K);
+            SDT(11);  // sort of y
+            SDPH("y_fix");
             if (!(abl & 8)) redo_y = (fix_equal_q<K>(ky, rowb, lane) & kUnsorted) != 0 && cell_live;  // tied observations are interchangeable
+            SDPH("y_gather");
+            if constexpr (FULL) {  // (the pad keys of the lanes past the segment carry slots beyond the row: those lanes read slot 0)
+                const unsigned tm = K * lane < n ? kTagMask : 0u;
 #pragma unroll
-            for (int i = 0; i < K; ++i) t[i] = lds_f64(rowb + 8u * (K * lane + i < n ? (ky[i] & kTagMask) : (unsigned)(RS - 1)));
+                for (int i = 0; i < K; ++i) t[i] = lds_f64(rowb + 8u * (ky[i] & tm));
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; ++i) t[i] = lds_f64(rowb + 8u * (K * lane + i < n ? (ky[i] & kTagMask) : (unsigned)(RS - 1)));
+            }
             if (!IDENT) {
                 wave_fence();  // all reads by tag done: the row becomes the sorted segment, plain indexing
 #pragma unroll
@@ -530,6 +720,9 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
     }
 
     // ---- map ranks through the fitted inverse CDF (quantile.py:523-545), scatter to time slots ------------------
+    SDT(12);  // fix-up of y, sorted observations gathered
+    SDPH("map_scatter");
+    int to[NR];  // time indices of this thread's rows of the output tile
     {
         SD_LANE();
         if (!IDENT) {
@@ -567,24 +760,43 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
             }
         }
         wave_fence();  // every lane has read what it needs of the row
+        const bool has = K * lane < m;
+        if constexpr (FULL) {
+            if (has) {
 #pragma unroll
-        for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < m ? rowb + 8u * (ku[i] & kTagMask) : spare, t[i]);
+                for (int i = 0; i < K; ++i) lds_store_f64(rowb + 8u * (ku[i] & kTagMask), t[i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < m ? rowb + 8u * (ku[i] & kTagMask) : spare, t[i]);
+        }
         wave_fence();
         // ---- restore the climate-trend shift (bcsd.py:263-267), in place ---------------------------------------
-        const bool has = K * lane < m;
+        SDPH("restore");
+        if (kEarlyRows) rows_load<NR, FULL>(p->ord_p + begp, m, to);  // (named ahead of the last barrier: the stores go out behind it at once)
         double* ob = row + L::own(has ? lane : 0);
         double q[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) q[i] = ob[i];
+        const double ycr = p->return_anoms ? yc : 0.0;  // bcsd.py:266-267 (res - 0.0 == res, also for -0.0)
+        if constexpr (FULL) {
+            if (has) {
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-            double res = shift[i] + q[i];         // bcsd.py:253,263
-            if (p->return_anoms) res = res - yc;  // bcsd.py:266-267
-            lds_store_f64(K * lane + i < m ? rowb + 8u * (unsigned)(L::own(lane) + i) : spare, res);
+                for (int i = 0; i < K; ++i) ob[i] = (shift[i] + q[i]) - ycr;  // bcsd.py:253,263
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const double res = (shift[i] + q[i]) - ycr;
+                lds_store_f64(K * lane + i < m ? rowb + 8u * (unsigned)(L::own(lane) + i) : spare, res);
+            }
         }
     }
+    SDPH("store");
+    SDT(13);  // scatter, shift restored
     redo_flag[wave] = redo_y ? 1 : 0;
     __syncthreads();
+    SDT(14);  // last barrier
     any_redo = 0;
 #pragma unroll
     for (int w = 0; w < kW; ++w) any_redo |= redo_flag[w];
@@ -596,7 +808,15 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
         return;
     }
     const bool vec_o = (p->ld_out % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->out) & 15) == 0);
-    if (!(abl & 16)) store_tile_sw<K>(p->out, p->ld_out, p->ord_p + begp, m, c0, p->C, vec_o, tile, RS);
+        if (!kEarlyRows) rows_load<NR, FULL>(p->ord_p + begp, m, to);
+    if (!(abl & 16)) store_tile_ti<K, FULL>(p->out, p->ld_out, to, m, c0, p->C, vec_o, tile, RS);
+#ifdef SD_DEV
+    SDT(15);  // stores issued
+    if (traced && threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < kTraceSlots; ++i) sd_fx_trace[(blockIdx.x / kTraceStride) * kTraceSlots + i] = tstamp[i];
+    }
+#endif
 #undef SD_LANE
 }
 
@@ -817,9 +1037,19 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
 #undef SD_LANE
 }
 
+template <int K, bool IDENT, bool FULL>
+int launch_tas(sd_ctx* ctx, const Params& p, size_t lds) {
+    const int64_t tx = (p.ntiles + 7) / 8;
+    const int64_t nblocks = 8 * tx * (p.gmask ? __builtin_popcountll(p.gmask) : p.G);
+    SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "grid too large");
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fx_kernel<K, IDENT, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    SD_LAUNCH(ctx, FULL ? "bcsd_fx_kernel_full" : "bcsd_fx_kernel", (bcsd_fx_kernel<K, IDENT, FULL>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
+    return SD_OK;
+}
+
 template <int K, bool IDENT>
 int launch_ki(sd_ctx* ctx, Params p, int nmax, const int* group_len) {
-    (void)group_len;
     p.RS = row_slots<K>(nmax);
     const size_t lds = ((size_t)kW * p.RS + kHeadDoubles) * sizeof(double);
     if (lds > ctx->lds_max) return sd_set_error(SD_ERR_UNSUPPORTED, "segment of %d samples needs %zu bytes of LDS", nmax, lds);
@@ -827,9 +1057,26 @@ int launch_ki(sd_ctx* ctx, Params p, int nmax, const int* group_len) {
     const int64_t nblocks = 8 * tx * (p.gmask ? __builtin_popcountll(p.gmask) : p.G);
     SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "grid too large");
     if (p.kind == SD_BCSD_TAS) {
-        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fx_kernel<K, IDENT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-        SD_LAUNCH(ctx, "bcsd_fx_kernel", (bcsd_fx_kernel<K, IDENT>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
+        // Groups whose segments are whole lanes of K samples (10 of the 12 months of a daily series at K = 20) take the
+        // FULL instantiation -- no per-sample predicates --, the others a second launch of the general one.
+        unsigned long long full = 0ull, rest = 0ull;
+#ifndef SD_FX_NOFULL
+        if (IDENT && group_len != nullptr && p.G <= 64 && sd_dev_env("SD_FX_NOFULL") == nullptr) {
+            for (int g = 0; g < p.G; ++g) {
+                const bool f = group_len[g] % K == 0 && group_len[g] >= full_min_len<K>();
+                (f ? full : rest) |= 1ull << g;
+            }
+        }
+#endif
+        if (IDENT && full != 0ull) {
+            Params q = p;
+            q.gmask = full;
+            SD_TRY((launch_tas<K, IDENT, IDENT>(ctx, q, lds)));  // (FULL exists for IDENT only)
+            if (rest == 0ull) return SD_OK;
+            q.gmask = rest;
+            return launch_tas<K, IDENT, false>(ctx, q, lds);
+        }
+        return launch_tas<K, IDENT, false>(ctx, p, lds);
     } else {
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fxp_kernel<K, IDENT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
@@ -844,12 +1091,16 @@ int launch_k(sd_ctx* ctx, const Params& p, int nmax, const int* gl) {
 }
 
 int launch_width(sd_ctx* ctx, const Params& p, int nmax, const int* gl) {
+#ifdef SD_FX_ONLY_K  // development: one width only (fast compiles for ISA inspection)
+    if (true) return launch_k<SD_FX_ONLY_K>(ctx, p, nmax, gl);
+#else
     if (nmax <= 64 * 4) return launch_k<4>(ctx, p, nmax, gl);
     if (nmax <= 64 * 8) return launch_k<8>(ctx, p, nmax, gl);
     if (nmax <= 64 * 12) return launch_k<12>(ctx, p, nmax, gl);
     if (nmax <= 64 * 16) return launch_k<16>(ctx, p, nmax, gl);
     if (nmax <= 64 * 20) return launch_k<20>(ctx, p, nmax, gl);
     if (nmax <= 64 * 24) return launch_k<24>(ctx, p, nmax, gl);
+#endif
     return sd_set_error(SD_ERR_UNSUPPORTED, "segment of %d samples exceeds the fused register-sort path", nmax);
 }
 
@@ -864,5 +1115,17 @@ int sd_bcsd_fx_launch(sd_ctx* ctx, const sdrs::Params& p, int nmax, const int* g
     q.gmask = 0ull;
     q.use_worklist = 0;
     if (q.n_endpoints <= 0) q.n_endpoints = 10;
-    return sdfx::launch_width(ctx, q, nmax, group_len);
+    SD_TRY(sdfx::launch_width(ctx, q, nmax, group_len));
+#ifdef SD_DEV
+    if (const char* path = sd_dev_env("SD_FX_TRACE")) {  // raw phase clocks of the sampled workgroups -> file (tools/dev/trace_fx.py)
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        std::vector<long long> h((size_t)sdfx::kTraceWgs * sdfx::kTraceSlots);
+        SD_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(sdfx::sd_fx_trace), h.size() * sizeof(long long)));
+        if (FILE* f = fopen(path, "wb")) {
+            fwrite(h.data(), sizeof(long long), h.size(), f);
+            fclose(f);
+        }
+    }
+#endif
+    return SD_OK;
 }
