@@ -826,8 +826,9 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
 // exact zeros of a segment are one tie -- np.interp gives every one of them the largest rank among them (quantile.py:488) --
 // so they form key class 0 (sorted in front, in any order, never compared), n0 of them are counted, and sorted position r
 // maps through rank max(r, n0 - 1).  Ties among the wet days, or negative values, send the (tile, group) to RANK / APPLY.
-template <int K, bool IDENT>
+template <int K, bool IDENT, bool FULL>
 __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
+    static_assert(!FULL || IDENT, "FULL launches serve groups of equal fit / predict length");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int NR = K / 2;
@@ -869,15 +870,19 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
     // ---- x side: validation of x_hist, the x_fut tile ------------------------------------------------------------------
     {
         TileRegs<NR> xf;
+        int tp[NR];
+        rows_load<NR, FULL>(p->ord_p + begp, m, tp);
         if (!p->from_state && p->X != nullptr && n > 0) {
             TileRegs<NR> xh;
-            tile_issue<NR>(p->X, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, xh);
-            tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
+            int tf[NR];
+            rows_load<NR, FULL>(p->ord_f + begf, n, tf);
+            tile_issue_ti<NR>(p->X, p->ld, tf, c0, p->C, vec_f, xh);
+            tile_issue_ti<NR>(p->Xp, p->ld_p, tp, c0, p->C, vec_p, xf);
             tile_check_finite<NR>(xh, n, c0, p->C, p->status_fit, bad_cell);
         } else {
-            tile_issue<NR>(p->Xp, p->ld_p, p->ord_p + begp, m, c0, p->C, vec_p, xf);
+            tile_issue_ti<NR>(p->Xp, p->ld_p, tp, c0, p->C, vec_p, xf);
         }
-        tile_commit_sw<NR, K>(xf, m, c0, p->C, tile, RS, p->status_p, bad_cell);
+        tile_commit_sw<NR, K, FULL>(xf, m, c0, p->C, tile, RS, p->status_p, bad_cell);
     }
     __syncthreads();
 
@@ -891,10 +896,20 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
         double v[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) v[i] = ob[i];
+        if constexpr (FULL) {  // (a lane is all data or all pad)
+            const bool has = K * lane < m;
 #pragma unroll
-        for (int i = 0; i < K; ++i) n0 += __popcll(__ballot(K * lane + i < m && v[i] == 0.0));
-        const double lo = make_keys<K, true>(v, m, lane, ku);
-        if (!p->from_state && n > 0) tile_issue<NR>(p->y, p->ld, p->ord_f + begf, n, c0, p->C, vec_f, yt);
+            for (int i = 0; i < K; ++i) n0 += __popcll(__ballot(has && v[i] == 0.0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < K; ++i) n0 += __popcll(__ballot(K * lane + i < m && v[i] == 0.0));
+        }
+        const double lo = make_keys<K, true, FULL>(v, m, lane, ku);
+        if (!p->from_state && n > 0) {
+            int ty[NR];
+            rows_load<NR, FULL>(p->ord_f + begf, n, ty);
+            tile_issue_ti<NR>(p->y, p->ld, ty, c0, p->C, vec_f, yt);
+        }
         sdws::wave_sort<K>(ku, lane, (m + K - 1) / K);
         const bool tie = fix_equal_q<K, true>(ku, rowb, lane) != 0;
         redo = (tie || lo < 0.0) && cell_live && bad_cell[wave] == 0;
@@ -918,7 +933,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
     if (!p->from_state) {
         if (n > 0) {
             SD_LANE();
-            tile_commit_sw<NR, K>(yt, n, c0, p->C, tile, RS, p->status_fit, nullptr);
+            tile_commit_sw<NR, K, FULL>(yt, n, c0, p->C, tile, RS, p->status_fit, nullptr);
             __syncthreads();
             unsigned ky[K];
             {
@@ -927,21 +942,40 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
 #pragma unroll
                 for (int i = 0; i < K; ++i) v[i] = ob[i];
                 double s = 0.0;
+                if constexpr (FULL) {
 #pragma unroll
-                for (int i = 0; i < K; ++i) s += K * lane + i < n ? v[i] : 0.0;
+                    for (int i = 0; i < K; ++i) s += v[i];
+                    s = K * lane < n ? s : 0.0;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < K; ++i) s += K * lane + i < n ? v[i] : 0.0;
+                }
                 yc = wave_sum_f64(s) / (double)n;  // bcsd.py:138
                 if (lane == 0 && cell_ok && p->return_anoms && yc <= 0.0) atomicOr(&p->status_fit[c], SDI_BAD_CLIMO);  // bcsd.py:140-141
-                const double lo = make_keys<K, true>(v, n, lane, ky);
+                const double lo = make_keys<K, true, FULL>(v, n, lane, ky);
                 redo_y = lo < 0.0 && cell_live;
             }
             sdws::wave_sort<K>(ky, lane, (n + K - 1) / K);
             redo_y = (redo_y || (fix_equal_q<K, true>(ky, rowb, lane) & kUnsorted) != 0) && cell_live;  // tied observations are interchangeable
             double t[K];
+            if constexpr (FULL) {  // (the pad keys of the lanes past the segment carry slots beyond the row: those lanes read slot 0)
+                const unsigned tm = K * lane < n ? kTagMask : 0u;
 #pragma unroll
-            for (int i = 0; i < K; ++i) t[i] = lds_f64(rowb + 8u * (K * lane + i < n ? (ky[i] & kTagMask) : (unsigned)(RS - 1)));
+                for (int i = 0; i < K; ++i) t[i] = lds_f64(rowb + 8u * (ky[i] & tm));
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; ++i) t[i] = lds_f64(rowb + 8u * (K * lane + i < n ? (ky[i] & kTagMask) : (unsigned)(RS - 1)));
+            }
             wave_fence();  // all reads by tag done: the row becomes the sorted segment (np.sort, quantile.py:462)
+            if constexpr (FULL) {
+                if (K * lane < n) {
 #pragma unroll
-            for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < n ? rowb + 8u * (unsigned)(K * lane + i) : spare, t[i]);
+                    for (int i = 0; i < K; ++i) lds_store_f64(rowb + 8u * (unsigned)(K * lane + i), t[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < n ? rowb + 8u * (unsigned)(K * lane + i) : spare, t[i]);
+            }
         }
     } else {
         SD_LANE();
@@ -953,6 +987,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
     }
 
     // ---- map sorted position r through rank max(r, n0 - 1) and the fitted inverse CDF (quantile.py:488, 523-545) --------
+    int to[NR];  // time indices of this thread's rows of the output tile
     {
         SD_LANE();
         wave_fence();
@@ -1000,25 +1035,37 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
             }
         }
         wave_fence();  // every lane has read what it needs of the row
+        const bool has = K * lane < m;
+        if constexpr (FULL) {
+            if (has) {
 #pragma unroll
-        for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < m ? rowb + 8u * (ku[i] & kTagMask) : spare, t[i]);
+                for (int i = 0; i < K; ++i) lds_store_f64(rowb + 8u * (ku[i] & kTagMask), t[i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < K; ++i) lds_store_f64(K * lane + i < m ? rowb + 8u * (ku[i] & kTagMask) : spare, t[i]);
+        }
         wave_fence();
         // ---- ratio anomalies (bcsd.py:170-185), in place: q / y_climo by the reciprocal and one correction step ------------
-        double* ob = row + L::own(K * lane < m ? lane : 0);
+        double* ob = row + L::own(has ? lane : 0);
         double q[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) q[i] = ob[i];
         const double rc = 1.0 / yc;
+        if (!FULL || has) {
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-            double res = q[i];
-            if (p->return_anoms) {
-                const double a = q[i] * rc;
-                res = __builtin_fma(__builtin_fma(-yc, a, q[i]), rc, a);
-                res = __builtin_isfinite(res) ? res : q[i] / yc;  // (zero or denormal climatology: the plain quotient)
+            for (int i = 0; i < K; ++i) {
+                double res = q[i];
+                if (p->return_anoms) {
+                    const double a = q[i] * rc;
+                    res = __builtin_fma(__builtin_fma(-yc, a, q[i]), rc, a);
+                    res = __builtin_isfinite(res) ? res : q[i] / yc;  // (zero or denormal climatology: the plain quotient)
+                }
+                if constexpr (FULL) ob[i] = res;
+                else lds_store_f64(K * lane + i < m ? rowb + 8u * (unsigned)(L::own(lane) + i) : spare, res);
             }
-            lds_store_f64(K * lane + i < m ? rowb + 8u * (unsigned)(L::own(lane) + i) : spare, res);
         }
+        if (FULL) rows_load<NR, FULL>(p->ord_p + begp, m, to);  // (named ahead of the last barrier: the stores go out behind it at once)
     }
     redo_flag[wave] = redo_y ? 1 : 0;
     __syncthreads();
@@ -1033,18 +1080,27 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
         return;
     }
     const bool vec_o = (p->ld_out % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->out) & 15) == 0);
-    store_tile_sw<K>(p->out, p->ld_out, p->ord_p + begp, m, c0, p->C, vec_o, tile, RS);
+    if (!FULL) rows_load<NR, FULL>(p->ord_p + begp, m, to);
+    store_tile_ti<K, FULL>(p->out, p->ld_out, to, m, c0, p->C, vec_o, tile, RS);
 #undef SD_LANE
 }
 
 template <int K, bool IDENT, bool FULL>
-int launch_tas(sd_ctx* ctx, const Params& p, size_t lds) {
+int launch_one(sd_ctx* ctx, const Params& p, size_t lds) {
     const int64_t tx = (p.ntiles + 7) / 8;
     const int64_t nblocks = 8 * tx * (p.gmask ? __builtin_popcountll(p.gmask) : p.G);
     SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "grid too large");
-    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fx_kernel<K, IDENT, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-    SD_LAUNCH(ctx, FULL ? "bcsd_fx_kernel_full" : "bcsd_fx_kernel", (bcsd_fx_kernel<K, IDENT, FULL>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
+    if (p.kind == SD_BCSD_TAS) {
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fx_kernel<K, IDENT, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        SD_LAUNCH(ctx, FULL ? "bcsd_fx_kernel_full" : "bcsd_fx_kernel", (bcsd_fx_kernel<K, IDENT, FULL>), dim3((unsigned)nblocks),
+                  dim3(kThreads), lds, p);
+    } else {
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fxp_kernel<K, IDENT, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        SD_LAUNCH(ctx, FULL ? "bcsd_fxp_kernel_full" : "bcsd_fxp_kernel", (bcsd_fxp_kernel<K, IDENT, FULL>), dim3((unsigned)nblocks),
+                  dim3(kThreads), lds, p);
+    }
     return SD_OK;
 }
 
@@ -1053,36 +1109,26 @@ int launch_ki(sd_ctx* ctx, Params p, int nmax, const int* group_len) {
     p.RS = row_slots<K>(nmax);
     const size_t lds = ((size_t)kW * p.RS + kHeadDoubles) * sizeof(double);
     if (lds > ctx->lds_max) return sd_set_error(SD_ERR_UNSUPPORTED, "segment of %d samples needs %zu bytes of LDS", nmax, lds);
-    const int64_t tx = (p.ntiles + 7) / 8;
-    const int64_t nblocks = 8 * tx * (p.gmask ? __builtin_popcountll(p.gmask) : p.G);
-    SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "grid too large");
-    if (p.kind == SD_BCSD_TAS) {
-        // Groups whose segments are whole lanes of K samples (10 of the 12 months of a daily series at K = 20) take the
-        // FULL instantiation -- no per-sample predicates --, the others a second launch of the general one.
-        unsigned long long full = 0ull, rest = 0ull;
+    // Groups whose segments are whole lanes of K samples (10 of the 12 months of a daily series at K = 20) take the FULL
+    // instantiation -- no per-sample predicates --, the others a second launch of the general one.
+    unsigned long long full = 0ull, rest = 0ull;
 #ifndef SD_FX_NOFULL
-        if (IDENT && group_len != nullptr && p.G <= 64 && sd_dev_env("SD_FX_NOFULL") == nullptr) {
-            for (int g = 0; g < p.G; ++g) {
-                const bool f = group_len[g] % K == 0 && group_len[g] >= full_min_len<K>();
-                (f ? full : rest) |= 1ull << g;
-            }
+    if (IDENT && group_len != nullptr && p.G <= 64 && sd_dev_env("SD_FX_NOFULL") == nullptr) {
+        for (int g = 0; g < p.G; ++g) {
+            const bool f = group_len[g] % K == 0 && group_len[g] >= full_min_len<K>();
+            (f ? full : rest) |= 1ull << g;
         }
-#endif
-        if (IDENT && full != 0ull) {
-            Params q = p;
-            q.gmask = full;
-            SD_TRY((launch_tas<K, IDENT, IDENT>(ctx, q, lds)));  // (FULL exists for IDENT only)
-            if (rest == 0ull) return SD_OK;
-            q.gmask = rest;
-            return launch_tas<K, IDENT, false>(ctx, q, lds);
-        }
-        return launch_tas<K, IDENT, false>(ctx, p, lds);
-    } else {
-        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fxp_kernel<K, IDENT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-        SD_LAUNCH(ctx, "bcsd_fxp_kernel", (bcsd_fxp_kernel<K, IDENT>), dim3((unsigned)nblocks), dim3(kThreads), lds, p);
     }
-    return SD_OK;
+#endif
+    if (IDENT && full != 0ull) {
+        Params q = p;
+        q.gmask = full;
+        SD_TRY((launch_one<K, IDENT, IDENT>(ctx, q, lds)));  // (FULL exists for IDENT only)
+        if (rest == 0ull) return SD_OK;
+        q.gmask = rest;
+        return launch_one<K, IDENT, false>(ctx, q, lds);
+    }
+    return launch_one<K, IDENT, false>(ctx, p, lds);
 }
 
 template <int K>
