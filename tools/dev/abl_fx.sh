@@ -1,7 +1,9 @@
 #!/bin/bash
-# ablation sweep of the fused kernel on the development library (SD_FZ_ABLATE bits, see csrc/sd_bcsd_fx.hip)
+# ablation sweep of the fused kernel on the development library (SD_FZ_ABLATE bits, see csrc/sd_bcsd_fx.hip; the persistent
+# kernel has no ablation switches: SD_FX_NOPERSIST=1 selects bcsd_fx_kernel<K, true, true>)
 export SD_DOWNSCALE_LIB=$PWD/scikit-downscale_amd/lib/libsd_downscale_dev.so
+export SD_FX_NOPERSIST=1
 for a in "$@"; do
   SD_FZ_ABLATE=$a timeout 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys;d=json.loads(sys.stdin.readline());print('abl=$a', round(d['roofline']['per_kernel_avg_ms']['bcsd_fx_kernel'],2),'ms')"
+import json,sys;d=json.loads(sys.stdin.readline());r=d['roofline'];print('abl=$a', {k: round(v*r['launches_per_step'][k],2) for k,v in r['per_kernel_avg_ms'].items() if 'fx' in k})"
 done
