@@ -74,6 +74,11 @@ def parse():
     ap.add_argument("--check-cells", type=int, default=32, help="cells verified against the oracle outside the timed region")
     ap.add_argument("--parity-only", action="store_true", help="CPU leg reduced to the parity check of the first cells (no CPU timing, no end_to_end)")
     ap.add_argument("--no-secondary", action="store_true", help="default N=1 run: skip the short config 3 / config 4 runs appended as `secondary`")
+    # config 4 with another estimator / kind / feature count (the `secondary.analog_kinds` / `analog_f3` lines of the default run)
+    ap.add_argument("--analog-kind", default="mean_analogs", choices=["mean_analogs", "best_analog", "weight_analogs"])
+    ap.add_argument("--analog-k", type=int, default=30, help="n_analogs")
+    ap.add_argument("--analog-features", type=int, default=1)
+    ap.add_argument("--analog-estimator", default="pure", choices=["pure", "regression"], help="PureAnalog or AnalogRegression")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)  # internal: one process of the N-process NumPy leg
     return ap.parse_args()
 
@@ -111,10 +116,19 @@ def host_cpu_info():
     return info
 
 
+ANALOG = {"kind": "mean_analogs", "k": 30, "features": 1, "estimator": "pure"}  # config 4 as BASELINE.json words it; main() may change it
+
+
+def analog_is_baseline():
+    return ANALOG == {"kind": "mean_analogs", "k": 30, "features": 1, "estimator": "pure"}
+
+
 def host_fields(kind, seed, T, cells, c_full):
     """the workload's synthetic fields for the given cells on the host (bit-identical mirror of the device generator)"""
     from skdownscale_amd import synth
 
+    if kind == "analog":
+        return synth.analog_fields(seed, T, cells, c_full, n_features=ANALOG["features"])  # X [T,F,C], y [T,C], Xq [T,F,C]
     if kind == "bcsd_tas":
         index = synth.daily_calendar(T)
         return tuple(synth.tas_field(name, seed, index, cells, c_full) for name in ("X_hist", "y_obs", "X_fut"))
@@ -125,6 +139,13 @@ def host_fields(kind, seed, T, cells, c_full):
 
 def numpy_cells(kind, fields, gid, lo, hi):
     """the per-cell NumPy restatement of the reference's loop (core.py:69-143) over cells [lo, hi) of `fields`"""
+    if kind == "analog" and not analog_is_baseline():
+        # the other kinds / AnalogRegression / F > 1: the NumPy restatement of gard.py:152-224, 273-364 (oracle/analog_oracle.py)
+        import analog_oracle
+
+        X, y, Xq = fields
+        return analog_oracle.pointwise_analog(X[:, :, lo:hi], y[:, lo:hi], Xq[:, :, lo:hi], ANALOG["k"], analog_oracle.KIND_NAMES[ANALOG["kind"]],
+                                              regression=ANALOG["estimator"] == "regression")
     if kind == "analog":
         X, y, Xq = fields
         try:  # the reference's own neighbour search (gard.py:58-87: sklearn KDTree, gard.py:292: tree.query(X, k))
@@ -190,7 +211,7 @@ def cpu_baseline(kind, T, seed, c_full, target_seconds, check=None, parity_only=
     try:
         os.sched_setaffinity(0, cores)  # before the OpenMP runtime starts its threads
         # ---- parity of the engine's output for the first cells (small oracle run) ----
-        n_chk = 16 if kind == "analog" else 64
+        n_chk = (16 if analog_is_baseline() else 2) if kind == "analog" else 64
         chk_fields = host_fields(kind, seed, T, np.arange(n_chk), c_full)
         if kind == "analog":
             exp = numpy_cells(kind, chk_fields, gid, 0, n_chk)
@@ -379,7 +400,15 @@ def main():
     from skdownscale_amd.shard import Communicator, Rendezvous
 
     config = args.config or (2 if world == 1 else 5)
-    wl = WORKLOADS[config]
+    wl = dict(WORKLOADS[config])
+    if wl["kind"] == "analog":
+        ANALOG.update(kind=args.analog_kind, k=args.analog_k, features=args.analog_features, estimator=args.analog_estimator)
+        if not analog_is_baseline():
+            F = args.analog_features
+            wl["bytes_per_step"] = 8 * (F + 1 + F + 3)  # X, y, Xq read, the three output columns written
+            est = (f"AnalogRegression(n_analogs={args.analog_k})" if args.analog_estimator == "regression"
+                   else f"PureAnalog(n_analogs={args.analog_k}, kind='{args.analog_kind}')")
+            wl["name"] = est + f" F={F}, {{C}} cells x {{T}} steps per GPU"
     import ctypes
 
     ndev = ctypes.c_int(0)
@@ -434,12 +463,28 @@ def main():
                                              out=out if dst is None else dst)
             return status
     else:  # PureAnalog: X [T, 1, C], y = 2 X + noise, queries Xq
+        from skdownscale_amd.engine import DeviceArray
+
+        F = ANALOG["features"]
         fields["y"] = field(synth.GAUSS, 20, amp=2.0, stream2=21, amp2=1.0)
-        fields["X"] = field(synth.GAUSS, 20, shape=(T, 1, C))
-        fields["Xq"] = field(synth.GAUSS, 22, shape=(T, 1, C))
+        for name, s0 in (("X", 20), ("Xq", 22)):  # [T, F, C]: feature f of time t is row t * F + f (streams as synth.analog_fields)
+            fields[name] = ctx.empty((T, F, C))
+            for f in range(F):
+                view = DeviceArray(ctx, (T, C), dptr=fields[name].ptr + f * C * 8, owner=False, ld=F * C, base=fields[name])
+                ctx.synth_fill(view, synth.GAUSS, args.seed, s0 + 100 * f, c_offset=c_off, c_full=c_full)
         out = ctx.empty((T, 3, C))
+        k_eff = 1 if ANALOG["kind"] == "best_analog" else ANALOG["k"]  # gard.py:291-296: best_analog queries one neighbour
+        kind_code = {"best_analog": _lib.ANALOG_BEST, "weight_analogs": _lib.ANALOG_WEIGHT, "mean_analogs": _lib.ANALOG_MEAN}[ANALOG["kind"]]
 
         def step(cells=None, dst=None):
+            if ANALOG["estimator"] == "regression":  # AnalogBase.fit + AnalogRegression.predict (gard.py:58-87, 152-224)
+                st = ctx.analog_fit(fields["X"], fields["y"])
+                _, status = ctx.analogreg_predict(st, fields["Xq"], ANALOG["k"], out=out)
+                st.close()
+                return status
+            if not analog_is_baseline():
+                _, status = ctx.analog_fit_predict(fields["X"], fields["y"], fields["Xq"], k_eff, kind_code, out=out)
+                return status
             if os.environ.get("SD_BENCH_ANALOG_SPLIT"):  # the two calls (a fitted state written, read back and dropped)
                 st = ctx.analog_fit(fields["X"], fields["y"])
                 _, status = ctx.analog_predict(st, fields["Xq"], 30, _lib.ANALOG_MEAN, out=out)
@@ -686,6 +731,38 @@ def main():
                                                                                        "kernel_ms_per_step", "algorithmic_bytes_per_step")}}
             except Exception as e:  # noqa: BLE001
                 secondary[f"config{c2}"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        # the rest of the analog surface at BASELINE size (F = 1): the reference's default PureAnalog() (kind='best_analog',
+        # n_analogs=200: one neighbour, gard.py:257-271, 291-296), weight_analogs, AnalogRegression; and F = 3 (KDTree-equivalent
+        # neighbour search in three dimensions; cells sized to a few seconds)
+        def analog_line(extra, steps, warmup):
+            o = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "4", "--steps", str(steps), "--warmup", str(warmup),
+                                "--parity-only", "--seed", str(args.seed)] + extra, capture_output=True, text=True, timeout=900)
+            d = json.loads(o.stdout.strip().splitlines()[-1])
+            r = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "ms_per_step": d["ms_per_step"],
+                 "parity_check": d["parity_check"],
+                 "roofline": {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms_per_step",
+                                                            "algorithmic_bytes_per_step")}}
+            return r, d
+
+        kinds = {}
+        for key, extra, steps in (("best_analog_n200", ["--analog-kind", "best_analog", "--analog-k", "200"], 6),
+                                  ("weight_analogs_k30", ["--analog-kind", "weight_analogs"], 4),
+                                  ("analog_regression_k30", ["--analog-estimator", "regression"], 4)):
+            try:
+                kinds[key], _ = analog_line(extra, steps, 1)
+            except Exception as e:  # noqa: BLE001
+                kinds[key] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        secondary["analog_kinds"] = kinds
+        try:
+            f3, d = analog_line(["--analog-features", "3", "--cells", "16384"], 2, 1)
+            cells_s = d["value"]
+            # the brute-force equivalent: 3 F Tf Tq flops per cell at the measured cells per second
+            f3["brute_force_equivalent_tflops"] = cells_s * 3.0 * 3 * args.times * args.times / 1e12
+            f3["note"] = ("KDTree-equivalent exact search (slab scan over feature 0, register / LDS heap per query); flops of a full pairwise scan "
+                          "at this rate are reported for scale, the kernel does not execute them")
+            secondary["analog_f3"] = f3
+        except Exception as e:  # noqa: BLE001
+            secondary["analog_f3"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         line["secondary"] = secondary
     print(json.dumps(line), flush=True)
 

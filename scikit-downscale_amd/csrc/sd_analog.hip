@@ -75,16 +75,25 @@ __global__ void __launch_bounds__(256) analog_status_public_kernel(const int32_t
     }
 }
 
+int launch_prefix_sums(sd_ctx* ctx, const double* yx, int64_t T, int64_t C, double* pq, double* ybar, int keep_ybar) {
+    const int nbp = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 2);
+    const size_t lds = sizeof(double) * (size_t)(T + 1);
+    if (lds + 512 <= ctx->lds_max) {
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_prefix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SD_LAUNCH(ctx, "analog_prefix_kernel", analog_prefix_kernel, dim3(nbp), dim3(1024), lds, yx, T, C, pq, ybar, keep_ybar);
+    } else {
+        SD_LAUNCH(ctx, "analog_prefix_kernel", analog_prefix_direct_kernel, dim3(nbp), dim3(1024), 0, yx, T, C, pq, ybar, keep_ybar);
+    }
+    return SD_OK;
+}
+
 // exclusive prefix sums of the centred analog values (analog_prefix_kernel), built when a kernel that reads them from
 // memory first runs on a state (calls on a context are serialised)
 int ensure_prefix_sums(sd_ctx* ctx, const sd_analog_state* st) {
     if (st->pq != nullptr) return SD_OK;
     sd_analog_state* ms = const_cast<sd_analog_state*>(st);
     SD_HIP(sd_pool_malloc(ctx, (void**)&ms->pq, sizeof(double) * 2 * (size_t)(st->T + 1) * st->C));
-    const int nbp = (int)std::min<int64_t>(st->C, (int64_t)ctx->cu_count * 2);
-    SD_LAUNCH(ctx, "analog_prefix_kernel", analog_prefix_kernel, dim3(nbp), dim3(1024), 0, (const double*)st->yx, st->T, st->C, ms->pq,
-              ms->ybar, 1);
-    return SD_OK;
+    return launch_prefix_sums(ctx, (const double*)st->yx, st->T, st->C, ms->pq, ms->ybar, 1);
 }
 
 int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const double* Xq, int64_t ld, int64_t Tq, int k,
@@ -166,7 +175,8 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean3_kernel<20>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean3));
         }
-        if (mean_only && !phases) SD_TRY(ensure_prefix_sums(ctx, st));
+        // (the prefix sums serve the regression and the plain mean; weights and thresholds read the analog values themselves)
+        if (mean_only && !phases && (mode == 1 || (kind == SD_ANALOG_MEAN && !has_thresh && k > 1))) SD_TRY(ensure_prefix_sums(ctx, st));
         if (mean_only && mode == 1 && st->rx == nullptr) {
             // first regression on this state: the cross-term prefix sums (calls on a context are serialised)
             sd_analog_state* ms = const_cast<sd_analog_state*>(st);
@@ -570,9 +580,7 @@ int sd_analog_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int
                 int nb = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 4);
                 SD_LAUNCH(ctx, "analog_sort_kernel", analog_sort_kernel, dim3(nb), dim3(1024), lds, (const double*)st->X,
                           (const double*)st->y, T, C, st->xs, st->xi, st->yx);
-                const int nbp = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 2);
-                SD_LAUNCH(ctx, "analog_prefix_kernel", analog_prefix_kernel, dim3(nbp), dim3(1024), 0, (const double*)st->yx, T, C,
-                          st->pq, st->ybar, 0);
+                SD_TRY(launch_prefix_sums(ctx, (const double*)st->yx, T, C, st->pq, st->ybar, 0));
             }
             SD_HIP(hipStreamSynchronize(ctx->stream));
         }

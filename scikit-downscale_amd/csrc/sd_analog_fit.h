@@ -680,6 +680,113 @@ int sort2_width(int64_t T, size_t lds_max) {
 __global__ void __launch_bounds__(1024) analog_prefix_kernel(const double* __restrict__ yx_all, int64_t T, int64_t C,
                                                              double* __restrict__ pq_all, double* __restrict__ ybar_all,
                                                              int keep_ybar /* 1: centre on the ybar_all given */) {
+    // The series goes through LDS (coalesced loads and stores; the serial part of the scan reads an odd number of
+    // consecutive elements per thread: conflict-free), once for each of the two sums -- the same partial-sum order as the
+    // version that had every thread walk its 8 * per bytes of global memory (8-byte requests 120 bytes apart: 42 ms per
+    // 100 000 cells x 14 600 where this one is bound by its 35 GB of traffic).
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* e = reinterpret_cast<double*>(smem_raw);  // n + 1 doubles
+    __shared__ double wsum[2][16];
+    const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + nthr - 1) / nthr;  // consecutive elements per thread
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const double* yx = yx_all + c * T;
+        double* pq = pq_all + 2 * c * (T + 1);
+        const int beg = tid * per < n ? tid * per : n, end = beg + per < n ? beg + per : n;
+        __syncthreads();
+        for (int i = tid; i < n; i += nthr) e[i] = yx[i];
+        __syncthreads();
+        // mean of y
+        double s = 0.0;
+        for (int i = beg; i < end; ++i) s += e[i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) wsum[0][wave] = s;
+        __syncthreads();
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += wsum[0][w];
+        const double ybar = keep_ybar ? ybar_all[c] : tot / (double)n;
+        if (tid == 0 && !keep_ybar) ybar_all[c] = ybar;
+        // per-thread totals of d and d^2, exclusive scan across the workgroup
+        double a = 0.0, b = 0.0;
+        for (int i = beg; i < end; ++i) {
+            const double d = e[i] - ybar;
+            a += d;
+            b += d * d;
+        }
+        double ia = a, ib = b;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
+            if (lane >= o) {
+                ia += ta;
+                ib += tb;
+            }
+        }
+        __syncthreads();
+        if (lane == 63) {
+            wsum[0][wave] = ia;
+            wsum[1][wave] = ib;
+        }
+        __syncthreads();
+        double oa = 0.0, ob = 0.0;
+        for (int w = 0; w < wave; ++w) {
+            oa += wsum[0][w];
+            ob += wsum[1][w];
+        }
+        const double ra0 = oa + (ia - a), rb0 = ob + (ib - b);  // exclusive prefixes at this thread's first element
+        // pass 1: sums of d in place of the values, out as pq[i].x; the centred values are kept in registers for pass 2
+        constexpr int kMaxPer = 20;  // (T <= 1024 * 20: what the callers send here; longer series re-read the values)
+        double dk[kMaxPer];
+        double ra = ra0;
+#pragma unroll
+        for (int t = 0; t < kMaxPer; ++t) {
+            const int i = beg + t;
+            const bool in = t < per && i < end;
+            const double d = in ? e[i] - ybar : 0.0;
+            dk[t] = d;
+            if (in) e[i] = ra;
+            ra += d;
+        }
+        if (per > kMaxPer)
+            for (int i = beg + kMaxPer; i < end; ++i) {
+                const double d = e[i] - ybar;
+                e[i] = ra;
+                ra += d;
+            }
+        if (end == n && beg < n) e[n] = ra;
+        if (n == 0 && tid == 0) e[0] = 0.0;
+        __syncthreads();
+        for (int i = tid; i <= n; i += nthr) pq[2 * (int64_t)i] = e[i];
+        __syncthreads();
+        // pass 2: sums of d^2
+        double rb = rb0;
+        if (per <= kMaxPer) {
+#pragma unroll
+            for (int t = 0; t < kMaxPer; ++t) {
+                const int i = beg + t;
+                if (t < per && i < end) e[i] = rb;
+                rb += dk[t] * dk[t];
+            }
+        } else {
+            for (int i = tid; i < n; i += nthr) e[i] = yx[i];
+            __syncthreads();
+            for (int i = beg; i < end; ++i) {
+                const double d = e[i] - ybar;
+                e[i] = rb;
+                rb += d * d;
+            }
+        }
+        if (end == n && beg < n) e[n] = rb;
+        __syncthreads();
+        for (int i = tid; i <= n; i += nthr) pq[2 * (int64_t)i + 1] = e[i];
+    }
+}
+
+// the same without LDS staging (series too long for the LDS: any T)
+__global__ void __launch_bounds__(1024) analog_prefix_direct_kernel(const double* __restrict__ yx_all, int64_t T, int64_t C,
+                                                             double* __restrict__ pq_all, double* __restrict__ ybar_all,
+                                                             int keep_ybar /* 1: centre on the ybar_all given */) {
     __shared__ double wsum[2][16];
     const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int per = (n + nthr - 1) / nthr;  // consecutive elements per thread
@@ -737,6 +844,7 @@ __global__ void __launch_bounds__(1024) analog_prefix_kernel(const double* __res
         if (n == 0 && tid == 0) pq[0] = make_double2(0.0, 0.0);
     }
 }
+
 
 // F == 1, one-feature AnalogRegression: rx[c][i] = sum_{j<i} (xs_j - mean(x)) (yx_j - mean(y)), the cross term of the
 // window regression (analog_f1_mean_kernel), computed on the first regression call on a state.  The products are

@@ -43,6 +43,11 @@ class DeviceArray:
     def vptr(self):
         return C.c_void_p(self.ptr)
 
+    @property
+    def base(self):
+        """the array this view was cut from (None for an array that owns its memory)"""
+        return self._base
+
     def cells(self, c0, c1):
         """View of the cell range [c0, c1) of a [..., C] field: same rows, leading dimension of the parent
         (how a cell shard of a resident grid is handed to the engine without a copy)."""
@@ -552,7 +557,10 @@ class Context:
             check(self.lib.sd_analog_fit_predict_dev(self.handle, X.vptr, y.vptr, y.ld, T, F, Cc, Xq.vptr, Xq.ld, Tq, k, kind, has_t, tv,
                                                      out.vptr, out.ld, ptr(status)))
         else:
-            out = np.empty((Tq, 3, Cc))
+            if out is None:
+                out = np.empty((Tq, 3, Cc))
+            elif not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == (Tq, 3, Cc) and out.flags.c_contiguous):
+                raise ValueError(f"out: expected a C-contiguous float64 array of shape {(Tq, 3, Cc)}")
             check(self.lib.sd_analog_fit_predict(self.handle, ptr(X), ptr(y), T, F, Cc, ptr(Xq), Tq, k, kind, has_t, tv, ptr(out), ptr(status)))
         return out, status
 

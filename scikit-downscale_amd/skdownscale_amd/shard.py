@@ -309,6 +309,22 @@ def local_cells(n_cells: int, world: int, rank: int):
     return cell_partition(n_cells, world)[rank]
 
 
+def _cell_block(values, n_lead, s, e):
+    """Cells [s, e) of the flattened spatial axes of ``values`` ([*lead, *spatial], any strides) as a contiguous [*lead, e - s]
+    array.  Only the slab of the first spatial axis that holds the block is ever made contiguous: flattening a transposed
+    (or memory-mapped) field first would copy the whole grid on every rank (117 GB per field at 1 M cells x 14 600 steps)."""
+    lead_shape, sp_shape = values.shape[:n_lead], values.shape[n_lead:]
+    if e <= s:
+        return np.empty(lead_shape + (0,), dtype=values.dtype)
+    if not sp_shape:
+        return np.ascontiguousarray(values.reshape(lead_shape + (1,))[..., s:e])
+    inner = int(np.prod(sp_shape[1:], dtype=np.int64))  # cells per step of the first spatial axis
+    i0, i1 = s // inner, (e - 1) // inner + 1
+    slab = values[(slice(None),) * n_lead + (slice(i0, i1),)]  # a view
+    slab = np.ascontiguousarray(slab).reshape(lead_shape + ((i1 - i0) * inner,))
+    return np.ascontiguousarray(slab[..., s - i0 * inner:e - i0 * inner])
+
+
 class ShardedPointWiseDownscaler:
     """``PointWiseDownscaler`` over the GPUs of one node: every rank (one process per GPU, same script, same inputs) fits and
     predicts a contiguous block of the grid's cells (``cell_partition`` of the flattened spatial dims, in the spatial dim order
@@ -355,9 +371,8 @@ class ShardedPointWiseDownscaler:
             raise ValueError(f"spatial shape {tuple(sp_shape)} does not match the fitted grid {tuple(layout[1])}")
         C = int(np.prod(sp_shape, dtype=np.int64)) if sp_shape else 1
         s, e = cell_partition(C, self.world)[self.rank]
-        flat = np.asarray(g.values).reshape(g.shape[:len(lead)] + (C,))
         coords = {k: v for k, v in g.coords.items() if k in lead}
-        local = GridArray(np.ascontiguousarray(flat[..., s:e]), tuple(lead) + ("cell",), coords)
+        local = GridArray(_cell_block(np.asarray(g.values), len(lead), s, e), tuple(lead) + ("cell",), coords)
         return local, (tuple(spatial), tuple(sp_shape), C, {k: v for k, v in g.coords.items() if k in spatial})
 
     def fit(self, X, *args, **kwargs):
@@ -419,7 +434,8 @@ class ShardedPointWiseDownscaler:
             if on_gpu:
                 # one download of the root's [rank][T][C_r] buffer; the per-rank blocks are views of the host copy
                 rows = int(views[0].shape[0])
-                host = views[0].base.to_host().reshape(-1) if getattr(views[0], "base", None) is not None else None
+                root = views[0].base  # the root buffer [rank][T][C_r] every per-rank view was cut from
+                host = root.to_host().reshape(-1) if root is not None and root.nbytes == 8 * rows * int(cells.sum()) else None
                 if host is None:
                     views = [v.to_host() for v in views]
                 else:

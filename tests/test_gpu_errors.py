@@ -157,7 +157,16 @@ def test_sharded_downscaler_on_a_one_rank_rccl_communicator(ctx):
     calls = []
     orig = sharded._resident_bcsd
     sharded._resident_bcsd = lambda *a, **k: calls.append(1) or orig(*a, **k)
-    got = sharded.predict(Xg)
+    from skdownscale_amd.engine import DeviceArray
+
+    downloads = []
+    to_host = DeviceArray.to_host
+    DeviceArray.to_host = lambda self: downloads.append(self.base is None) or to_host(self)
+    try:
+        got = sharded.predict(Xg)
+    finally:
+        DeviceArray.to_host = to_host
+    assert downloads == [True], downloads  # one download, of the root buffer itself (not one per rank view)
     plain = PointWiseDownscaler(BcsdTemperature())
     plain.fit(Xg, yg)
     want = plain.predict(Xg)

@@ -125,6 +125,39 @@ dist.destroy_process_group()
 '''
 
 
+def test_shard_cut_copies_only_its_slab(tmp_path):
+    """ShardedPointWiseDownscaler cuts a rank's cell block out of the flattened spatial axes without flattening the grid first: a
+    field whose spatial dims arrive in another order (a transposed view, here of a memory-mapped file) would otherwise be copied
+    whole on every rank (core.py:86-93 iterates cells of the caller's array; nothing there copies the grid)."""
+    import tracemalloc
+
+    from skdownscale_amd.shard import _cell_block, cell_partition
+
+    rng = np.random.default_rng(3)
+    for shape, n_lead in (((5, 6, 7), 1), ((4, 2, 9, 5), 2), ((6, 11), 1), ((3, 4, 5, 6), 1), ((7,), 1)):
+        a = rng.standard_normal(shape)
+        perm = list(range(n_lead)) + list(range(len(shape) - 1, n_lead - 1, -1))  # spatial axes reversed: a strided view
+        v = a.transpose(perm)
+        C = int(np.prod(v.shape[n_lead:], dtype=np.int64)) if v.ndim > n_lead else 1
+        flat = np.ascontiguousarray(v).reshape(v.shape[:n_lead] + (C,))
+        for world in (1, 3, 8):
+            for s, e in cell_partition(C, world):
+                got = _cell_block(v, n_lead, s, e)
+                assert got.flags.c_contiguous and np.array_equal(got, flat[..., s:e])
+    # the full field is never materialised: 64 MB on disk, spatial axes transposed, one eighth of the cells
+    T, ny, nx = 16, 512, 1024
+    mm = np.lib.format.open_memmap(tmp_path / "field.npy", mode="w+", dtype=np.float64, shape=(T, nx, ny))
+    mm[:] = np.arange(T * nx * ny, dtype=np.float64).reshape(T, nx, ny)
+    v = mm.transpose(0, 2, 1)  # [T, ny, nx]
+    s, e = cell_partition(ny * nx, 8)[5]
+    tracemalloc.start()
+    got = _cell_block(v, 1, s, e)
+    peak = tracemalloc.get_traced_memory()[1]
+    tracemalloc.stop()
+    assert np.array_equal(got, np.ascontiguousarray(v).reshape(T, -1)[:, s:e])
+    assert peak < 0.4 * mm.nbytes, (peak, mm.nbytes)  # slab + block (2/8 of the field), not the field
+
+
 def test_sharded_gather_world_size_2_gloo(tmp_path):
     """N > 1 path on CPU: cells sharded over 2 ranks, ragged blocks, gather to root == unsharded result."""
     script = tmp_path / "worker.py"
