@@ -477,6 +477,8 @@ struct RsWorkspace {
     int64_t* worklist = nullptr;
     int* work_count = nullptr;
     int work_cap = 0;
+    int64_t* worklist2 = nullptr;  // second list of the compacting precipitation kernel (same capacity)
+    int* work_count2 = nullptr;
 };
 int carve_workspace(sd_ctx* ctx, int nmax, int64_t C, int G, bool fused, bool want_x_climo, bool want_trend, RsWorkspace* w) {
     size_t rank_bytes = 0, shift_bytes = 0;
@@ -488,7 +490,7 @@ int carve_workspace(sd_ctx* ctx, int nmax, int64_t C, int G, bool fused, bool wa
     SD_CHECK_ARG(items < ((int64_t)1 << 31), "too many (tile, group) items");
     const size_t list_bytes = fused ? ((sizeof(int64_t) * (size_t)items + 255) / 256) * 256 : 0;
     void* ws = nullptr;
-    SD_TRY(sd_workspace(ctx, rank_bytes + shift_bytes + xc_bytes + list_bytes + 256, &ws));
+    SD_TRY(sd_workspace(ctx, rank_bytes + shift_bytes + xc_bytes + 2 * list_bytes + 256, &ws));
     char* base = static_cast<char*>(ws);
     w->ranks = reinterpret_cast<uint32_t*>(base);
     w->shift = shift_bytes ? reinterpret_cast<double*>(base + rank_bytes) : nullptr;
@@ -498,7 +500,9 @@ int carve_workspace(sd_ctx* ctx, int nmax, int64_t C, int G, bool fused, bool wa
         w->worklist = reinterpret_cast<int64_t*>(base + rank_bytes + shift_bytes + xc_bytes);
         w->work_count = reinterpret_cast<int*>(base + rank_bytes + shift_bytes + xc_bytes + list_bytes);
         w->work_cap = (int)items;
-        SD_HIP(hipMemsetAsync(w->work_count, 0, sizeof(int), ctx->stream));
+        w->worklist2 = reinterpret_cast<int64_t*>(base + rank_bytes + shift_bytes + xc_bytes + list_bytes + 256);
+        w->work_count2 = w->work_count + 1;  // (the 256 bytes behind the first list hold both counters)
+        SD_HIP(hipMemsetAsync(w->work_count, 0, 2 * sizeof(int), ctx->stream));
     }
     return SD_OK;
 }
@@ -992,6 +996,7 @@ static int predict_with_table(sd_ctx* ctx, const sd_bcsd_state* st, const double
         SD_TRY(carve_workspace(ctx, nmax_all, C, st->G, fused, false, st->detrend != 0, &w));
         p.ranks = w.ranks; p.shift = w.shift; p.trend_u = w.trend_u;
         p.worklist = w.worklist; p.work_count = w.work_count; p.work_cap = w.work_cap;
+        p.worklist2 = w.worklist2; p.work_count2 = w.work_count2;
         const std::vector<int> glen = group_lengths(st->goff, &gt.host_off, st->G);
         SD_TRY(run_predict_kernels(ctx, p, fused, nmax_all, glen));
         SD_HIP(hipStreamSynchronize(ctx->stream));  // the inverse-CDF tables go back to the block cache
@@ -1187,6 +1192,7 @@ int sd_bcsd_fit_predict_dev(sd_ctx* ctx, int kind, const double* X_dev, const do
         SD_TRY(carve_workspace(ctx, nmax_all, C, G, fused, true, detrend, &w));
         p.ranks = w.ranks; p.shift = w.shift; p.x_climo = w.x_climo; p.trend_u = w.trend_u;
         p.worklist = w.worklist; p.work_count = w.work_count; p.work_cap = w.work_cap;
+        p.worklist2 = w.worklist2; p.work_count2 = w.work_count2;
         const std::vector<int> glen = group_lengths(gf.host_off, &gp.host_off, G);
         SD_TRY(run_predict_kernels(ctx, p, fused, nmax_all, glen));
     }

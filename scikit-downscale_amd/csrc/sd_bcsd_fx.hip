@@ -123,6 +123,19 @@ __device__ __forceinline__ double wave_sum_f64(double v) {  // the same six step
     v += dpp0_f64<0x143, 0xC>(v);
     return lane63_f64(v);
 }
+// inclusive prefix sums over the 64 lanes (DPP row shifts, then the two row broadcasts)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp0_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, false); }
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    v += dpp0_i32<0x111, 0xF>(v);
+    v += dpp0_i32<0x112, 0xF>(v);
+    v += dpp0_i32<0x114, 0xF>(v);
+    v += dpp0_i32<0x118, 0xF>(v);
+    v += dpp0_i32<0x142, 0xA>(v);
+    v += dpp0_i32<0x143, 0xC>(v);
+    return v;
+}
+
 // the keys of the neighbouring lanes: wave shifts by one lane (lanes without a neighbour get `edge`)
 __device__ __forceinline__ unsigned from_next_lane(unsigned v, unsigned edge) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xF, 0xF, false);  // wave_shl:1: lane i <- lane i + 1
@@ -340,12 +353,13 @@ __device__ __forceinline__ void tile_check_finite(const TileRegs<RPT>& t, int nr
 // them in -- and every other sample gets q >= 1 (lo must not be negative: the caller hands such segments back).
 // FULL: the segment length is a multiple of K, so a lane is all data or all pad: one select per key instead of a compare
 // and a select, and no masking in the search for the extremes (lanes past the segment hold a copy of lane 0's block).
-template <int K, bool ZC, bool FULL>
+// PLAIN: the samples sit in the row without the skipped slots (compacted wet days: slot = sample index).
+template <int K, bool ZC, bool FULL, bool PLAIN = false>
 __device__ __forceinline__ void keys_from_range(const double (&v)[K], int m, int lane, double lo, double hi, unsigned (&key)[K]) {
     const int j0 = K * lane;
     const double sc = (double)(kQD - (ZC ? 1u : 0u)) / (hi - lo);  // +inf when every sample is equal: all keys tie, the fix-up sorts it out
     const double off = -lo * sc + (ZC ? 1.0 : 0.0);
-    const unsigned tag0 = (unsigned)Lay<K>::own(lane);
+    const unsigned tag0 = PLAIN ? (unsigned)j0 : (unsigned)Lay<K>::own(lane);
     const unsigned pad0 = ((kQD + 1u + tag0) << kTagBits) | tag0;
     const bool lane_in = j0 < m;
 #pragma unroll
@@ -358,7 +372,7 @@ __device__ __forceinline__ void keys_from_range(const double (&v)[K], int m, int
         key[i] = (FULL ? lane_in : j0 + i < m) ? dk : pk;
     }
 }
-template <int K, bool ZC, bool FULL>
+template <int K, bool ZC, bool FULL, bool PLAIN = false>
 __device__ __forceinline__ double make_keys_impl(const double (&v)[K], int m, int lane, unsigned (&key)[K]) {
     const int j0 = K * lane;
     double lo = __builtin_inf(), hi = -__builtin_inf();
@@ -369,8 +383,13 @@ __device__ __forceinline__ double make_keys_impl(const double (&v)[K], int m, in
         hi = vmax(hi, in ? v[i] : hi);
     }
     lo = wave_min_f64(lo);
-    keys_from_range<K, ZC, FULL>(v, m, lane, lo, wave_max_f64(hi), key);
+    keys_from_range<K, ZC, FULL, PLAIN>(v, m, lane, lo, wave_max_f64(hi), key);
     return lo;
+}
+// keys of a compacted series of m samples, K consecutive ones per lane at row[K * lane ..] (tags = sample indices)
+template <int K>
+__device__ __forceinline__ double make_keys_plain(const double (&v)[K], int m, int lane, unsigned (&key)[K]) {
+    return make_keys_impl<K, false, false, true>(v, m, lane, key);
 }
 template <int K, bool ZC = false, bool FULL = false>
 __device__ __forceinline__ double make_keys(const double (&v)[K], int m, int lane, unsigned (&key)[K]) {
@@ -827,10 +846,8 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
 // so they form key class 0 (sorted in front, in any order, never compared), n0 of them are counted, and sorted position r
 // maps through rank max(r, n0 - 1).  Ties among the wet days, or negative values, send the (tile, group) to RANK / APPLY.
 template <int K, bool IDENT, bool FULL>
-__global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
+__device__ __forceinline__ void fxp_segment(ParamsPtr p, int64_t tile_id, int g, char* smem_raw) {
     static_assert(!FULL || IDENT, "FULL launches serve groups of equal fit / predict length");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int NR = K / 2;
     constexpr int CH = K >= 20 ? K / 4 : K >= 14 ? K / 2 : K;
     using L = Lay<K>;
@@ -840,12 +857,6 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
     double* const tile = scratch + kHeadDoubles;
     const int RS = p->RS;
     if (threadIdx.x >= 32 && threadIdx.x < 32 + kW) bad_cell[threadIdx.x - 32] = 0;
-
-    int64_t tile_id;
-    int g;
-    xcd_tile_of_block(blockIdx.x, p->ntiles, &tile_id, &g);
-    if (p->gmask != 0ull) g = nth_set_bit(p->gmask, g);
-    if (tile_id >= p->ntiles || g < 0 || g >= p->G) return;
 
     const int64_t c0 = tile_id * kW;
     const int wave = __builtin_amdgcn_readfirstlane(tid_now() / kWave);
@@ -1086,6 +1097,307 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
 }
 
 template <int K, bool IDENT, bool FULL>
+__global__ void __launch_bounds__(kThreads, 4) bcsd_fxp_kernel(const Params) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    if (p->use_worklist == 2) {  // the segments the compacting kernel handed over (too many wet days): a fixed grid walks the list
+        int count = *p->work_count2;
+        if (count > p->work_cap) count = p->work_cap;
+#pragma unroll 1
+        for (int i = (int)blockIdx.x; i < count; i += (int)gridDim.x) {
+            const int64_t item = p->worklist2[i];
+            fxp_segment<K, IDENT, FULL>(p, item / p->G, (int)(item % p->G), smem_raw);
+            __syncthreads();  // the tile is reused by the next item
+        }
+        return;
+    }
+    int64_t tile_id;
+    int g;
+    xcd_tile_of_block(blockIdx.x, p->ntiles, &tile_id, &g);
+    if (p->gmask != 0ull) g = nth_set_bit(p->gmask, g);
+    if (tile_id >= p->ntiles || g < 0 || g >= p->G) return;
+    fxp_segment<K, IDENT, FULL>(p, tile_id, g, smem_raw);
+}
+
+// ---- BcsdPrecipitation, fit + predict, whole lanes, equal group lengths: only the wet days are sorted ---------------------
+// A zero-inflated segment (45 - 60 % exact zeros) needs no order among its zeros: every one of them takes the largest rank
+// among them (quantile.py:488).  Once a lane holds its K samples the row is dead until results are scattered, so the wet
+// values are compacted into its front (ballot-free: per-lane counts, one wave scan, K conditional stores), read back KC
+// consecutive ones per lane and sorted with the KC-wide network (KC = 12 for K = 20: 800 instead of 1 520 instructions per
+// sort); rank = zeros + rank among the wet days.  The same for y_obs, whose sorted wet values stay at the front of the row
+// (the zeros in front of them are implied).  The mapped values go back through the compacted positions: the lane that owns a
+// time slot re-walks its wet flags.  A wave whose segment has more than 64 * KC wet days -- or a tie among them, or a negative
+// value -- hands the (tile, group) over: too many wet days to `worklist2` (bcsd_fxp_kernel<K, true, true> in list mode), the
+// others to RANK / APPLY as before.
+template <int K>
+constexpr int compact_width() { return K == 20 ? 12 : K == 24 ? 16 : 0; }
+
+template <int K, int KC, bool FULL>
+__global__ void __launch_bounds__(kThreads, 4) bcsd_fxc_kernel(const Params) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int NR = K / 2;
+    using L = Lay<K>;
+    double* const scratch = reinterpret_cast<double*>(smem_raw);
+    int* const bad_cell = reinterpret_cast<int*>(scratch + 64 + 16);
+    int* const redo_flag = bad_cell + kW;
+    double* const tile = scratch + kHeadDoubles;
+    const int RS = p->RS;
+    if (threadIdx.x >= 32 && threadIdx.x < 32 + kW) bad_cell[threadIdx.x - 32] = 0;
+
+    int64_t tile_id;
+    int g;
+    xcd_tile_of_block(blockIdx.x, p->ntiles, &tile_id, &g);
+    g = nth_set_bit(p->gmask, g);
+    if (tile_id >= p->ntiles || g < 0 || g >= p->G) return;
+
+    const int64_t c0 = tile_id * kW;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_now() / kWave);
+#define SD_LANE() const int lane = tid_now() % kWave
+    const int64_t c = c0 + wave;
+    const bool cell_ok = c < p->C;
+    double* const row = tile + wave * RS;
+    const unsigned rowb = lds_addr(row);
+    const int begf = p->off_f[g];
+    const int n = p->off_f[g + 1] - begf;  // == m (equal group lengths)
+    const int begp = p->off_p[g];
+    const int m = n;
+    const bool vec_f = (p->ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->y) & 15) == 0) &&
+                       (p->X == nullptr || (reinterpret_cast<uintptr_t>(p->X) & 15) == 0);
+    const bool vec_p = (p->ld_p % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->Xp) & 15) == 0);
+    const bool cell_live = cell_ok && p->status_fit[cell_ok ? c : 0] == 0;
+    const unsigned spare = rowb + 8u * (unsigned)(RS - 1);
+    __syncthreads();
+
+    // ---- x side: validation of x_hist, the x_fut tile ------------------------------------------------------------------
+    {
+        TileRegs<NR> xf;
+        int tp[NR];
+        rows_load<NR, FULL>(p->ord_p + begp, m, tp);
+        if (p->X != nullptr) {
+            TileRegs<NR> xh;
+            int tf[NR];
+            rows_load<NR, FULL>(p->ord_f + begf, n, tf);
+            tile_issue_ti<NR>(p->X, p->ld, tf, c0, p->C, vec_f, xh);
+            tile_issue_ti<NR>(p->Xp, p->ld_p, tp, c0, p->C, vec_p, xf);
+            tile_check_finite<NR>(xh, n, c0, p->C, p->status_fit, bad_cell);
+        } else {
+            tile_issue_ti<NR>(p->Xp, p->ld_p, tp, c0, p->C, vec_p, xf);
+        }
+        tile_commit_sw<NR, K, FULL>(xf, m, c0, p->C, tile, RS, p->status_p, bad_cell);
+    }
+    __syncthreads();
+
+    // Compaction of the lane's K samples v[] (all data or all pad) into row[0 .. wet): returns the wet count of the segment;
+    // *zmask = the lane's zero flags (bit i: sample i is an exact zero), *base = wet samples in the lanes below
+    auto compact = [&](const double (&v)[K], int len, int lane, unsigned* zmask, int* base) -> int {
+        unsigned zm = 0u;
+#pragma unroll
+        for (int i = 0; i < K; ++i) zm |= v[i] == 0.0 ? 1u << i : 0u;
+        // (positions past the segment count as dry: whole lanes, or -- not FULL -- the tail of the last lane)
+        const int valid = len - K * lane;  // samples of this lane inside the segment (<= 0: none, >= K: all)
+        zm |= valid >= K ? 0u : valid <= 0 ? (1u << K) - 1u : ((1u << K) - 1u) & ~((1u << valid) - 1u);
+        const int cnt = K - __popc(zm);
+        const int incl = wave_incl_scan_i32(cnt);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        *zmask = zm;
+        *base = incl - cnt;
+        if (total <= kWave * KC) {  // (wave-uniform) else the caller hands the segment over: nothing is moved
+            wave_fence();  // every lane holds its samples: the row is free
+            unsigned a = rowb + 8u * (unsigned)(incl - cnt);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const bool wet = ((zm >> i) & 1u) == 0u;
+                lds_store_f64(wet ? a : spare, v[i]);
+                a += wet ? 8u : 0u;
+            }
+            wave_fence();
+        }
+        return total;
+    };
+
+    unsigned kx[KC] = {};  // sorted keys of the wet x_fut samples: tag = compacted position of the sample with that rank
+    unsigned zm_x = 0u;
+    int base_x = 0, nw_x = 0;
+    bool redo = false, many = false;
+    TileRegs<NR> yt;  // the y_obs tile is requested ahead of the sort
+    {
+        SD_LANE();
+        const bool has = K * lane < m;
+        const double* ob = row + L::own(has ? lane : 0);
+        double v[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) v[i] = ob[i];
+        nw_x = compact(v, m, lane, &zm_x, &base_x);
+        many = nw_x > kWave * KC;
+        if (many && !(cell_live && bad_cell[wave] == 0)) {  // (a masked or non-finite cell: nothing of it is used; treat it as all dry)
+            many = false;
+            nw_x = 0;
+            zm_x = (1u << K) - 1u;
+        }
+        {
+            int ty[NR];
+            rows_load<NR, FULL>(p->ord_f + begf, n, ty);
+            tile_issue_ti<NR>(p->y, p->ld, ty, c0, p->C, vec_f, yt);
+        }
+        if (!many && nw_x > 0) {
+            const double* cb = row + (KC * lane < nw_x ? KC * lane : 0);
+            double vc[KC];
+#pragma unroll
+            for (int i = 0; i < KC; ++i) vc[i] = cb[i];
+            const double lo = make_keys_plain<KC>(vc, nw_x, lane, kx);
+            sdws::wave_sort<KC>(kx, lane, (nw_x + KC - 1) / KC);
+            const bool tie = fix_equal_q<KC>(kx, rowb, lane) != 0;
+            redo = (tie || lo < 0.0) && cell_live && bad_cell[wave] == 0;
+        }
+    }
+    redo_flag[wave] = (redo ? 1 : 0) | (many ? 2 : 0);
+    __syncthreads();
+    int any_redo = 0;
+#pragma unroll
+    for (int w = 0; w < kW; ++w) any_redo |= redo_flag[w];
+    if (any_redo) {
+        if (threadIdx.x == 0) {
+            if (any_redo & 1) {  // ties or negative values: RANK / APPLY
+                const int slot = atomicAdd(p->work_count, 1);
+                if (slot < p->work_cap) p->worklist[slot] = tile_id * p->G + g;
+            } else {  // too many wet days for the narrow sort: the K-wide kernel
+                const int slot = atomicAdd(p->work_count2, 1);
+                if (slot < p->work_cap) p->worklist2[slot] = tile_id * p->G + g;
+            }
+        }
+        return;
+    }
+
+    // ---- y: climatology + sorted wet observations at the front of the row --------------------------------------------
+    double yc = 0.0;
+    int n0_y = 0;
+    bool redo_y = false, many_y = false;
+    {
+        SD_LANE();
+        tile_commit_sw<NR, K, FULL>(yt, n, c0, p->C, tile, RS, p->status_fit, nullptr);
+        __syncthreads();
+        const bool has = K * lane < n;
+        const double* ob = row + L::own(has ? lane : 0);
+        double v[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) v[i] = ob[i];
+        double s = 0.0;
+        if constexpr (FULL) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) s += v[i];
+            s = has ? s : 0.0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < K; ++i) s += K * lane + i < n ? v[i] : 0.0;
+        }
+        yc = wave_sum_f64(s) / (double)n;  // bcsd.py:138 (the same order of additions as bcsd_fxp_kernel)
+        if (lane == 0 && cell_ok && p->return_anoms && yc <= 0.0) atomicOr(&p->status_fit[c], SDI_BAD_CLIMO);  // bcsd.py:140-141
+        unsigned zm_y;
+        int base_y;
+        const int nw_y = compact(v, n, lane, &zm_y, &base_y);
+        n0_y = n - nw_y;
+        many_y = nw_y > kWave * KC && cell_live;
+        if (nw_y <= kWave * KC) {
+            unsigned ky[KC];
+            const double* cb = row + (KC * lane < nw_y ? KC * lane : 0);
+            double vc[KC];
+#pragma unroll
+            for (int i = 0; i < KC; ++i) vc[i] = cb[i];
+            const double lo = make_keys_plain<KC>(vc, nw_y, lane, ky);
+            sdws::wave_sort<KC>(ky, lane, (nw_y + KC - 1) / KC);
+            redo_y = (lo < 0.0 || (fix_equal_q<KC>(ky, rowb, lane) & kUnsorted) != 0) && cell_live;  // tied observations are interchangeable
+            double t[KC];
+            const unsigned tm = KC * lane < nw_y ? kTagMask : 0u;  // (lanes past the wet days: pad keys, slot 0)
+#pragma unroll
+            for (int i = 0; i < KC; ++i) t[i] = lds_f64(rowb + 8u * (ky[i] & tm));
+            wave_fence();  // all reads by tag done: row[r] = r-th smallest wet observation (np.sort, quantile.py:462)
+            if (KC * lane < nw_y) {
+#pragma unroll
+                for (int i = 0; i < KC; ++i) lds_store_f64(KC * lane + i < nw_y ? rowb + 8u * (unsigned)(KC * lane + i) : spare, t[i]);
+            }
+            wave_fence();
+        }
+    }
+
+    // ---- rank r of the predict sample -> r-th sorted observation (equal lengths: the inverse CDF at its own positions,
+    //      quantile.py:523-545), zeros through rank n0 - 1 (quantile.py:488); ratio anomalies (bcsd.py:170-185) -------------
+    int to[NR];
+    {
+        SD_LANE();
+        const int n0_x = m - nw_x;
+        // sorted observation of rank r: zero below n0_y, else the wet one at row[r - n0_y]
+        auto ys = [&](int r) -> double {
+            const double w = row[r >= n0_y ? r - n0_y : 0];
+            return r >= n0_y ? w : 0.0;
+        };
+        double t[KC];
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+            const int rw = KC * lane + i;  // rank among the wet days
+            t[i] = ys(rw < nw_x ? n0_x + rw : 0);
+        }
+        const double val0 = ys(n0_x > 0 ? n0_x - 1 : 0);  // what every exact zero maps to
+        wave_fence();  // every lane has read what it needs of the sorted observations
+        if (KC * lane < nw_x) {
+#pragma unroll
+            for (int i = 0; i < KC; ++i) lds_store_f64(KC * lane + i < nw_x ? rowb + 8u * (kx[i] & kTagMask) : spare, t[i]);
+        }
+        wave_fence();
+        // the lane that owns the time slots walks its wet flags through the compacted positions
+        double q[K];
+        {
+            const double* cp = row + base_x;
+            int pos = 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const bool wet = ((zm_x >> i) & 1u) == 0u;
+                const double wv = cp[wet ? pos : 0];
+                q[i] = wet ? wv : val0;
+                pos += wet ? 1 : 0;
+            }
+        }
+        wave_fence();  // the compacted values are in registers: the time slots may be written
+        const bool has = K * lane < m;
+        rows_load<NR, FULL>(p->ord_p + begp, m, to);
+        if (has) {
+            double* ob = row + L::own(lane);
+            const double rc = 1.0 / yc;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                double res = q[i];
+                if (p->return_anoms) {
+                    const double a = q[i] * rc;
+                    res = __builtin_fma(__builtin_fma(-yc, a, q[i]), rc, a);
+                    res = __builtin_isfinite(res) ? res : q[i] / yc;  // (zero or denormal climatology: the plain quotient)
+                }
+                ob[i] = res;
+            }
+        }
+    }
+    redo_flag[wave] = (redo_y ? 1 : 0) | (many_y ? 2 : 0);
+    __syncthreads();
+    any_redo = 0;
+#pragma unroll
+    for (int w = 0; w < kW; ++w) any_redo |= redo_flag[w];
+    if (any_redo) {  // nothing has been written
+        if (threadIdx.x == 0) {
+            if (any_redo & 1) {
+                const int slot = atomicAdd(p->work_count, 1);
+                if (slot < p->work_cap) p->worklist[slot] = tile_id * p->G + g;
+            } else {
+                const int slot = atomicAdd(p->work_count2, 1);
+                if (slot < p->work_cap) p->worklist2[slot] = tile_id * p->G + g;
+            }
+        }
+        return;
+    }
+    const bool vec_o = (p->ld_out % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->out) & 15) == 0);
+    store_tile_ti<K, FULL>(p->out, p->ld_out, to, m, c0, p->C, vec_o, tile, RS);
+#undef SD_LANE
+}
+
+template <int K, bool IDENT, bool FULL>
 int launch_one(sd_ctx* ctx, const Params& p, size_t lds) {
     const int64_t tx = (p.ntiles + 7) / 8;
     const int64_t nblocks = 8 * tx * (p.gmask ? __builtin_popcountll(p.gmask) : p.G);
@@ -1117,6 +1429,38 @@ int launch_ki(sd_ctx* ctx, Params p, int nmax, const int* group_len) {
         for (int g = 0; g < p.G; ++g) {
             const bool f = group_len[g] % K == 0 && group_len[g] >= full_min_len<K>();
             (f ? full : rest) |= 1ull << g;
+        }
+    }
+#endif
+#ifndef SD_FX_NOCOMPACT
+    if constexpr (IDENT && compact_width<K>() != 0) {
+        if (p.kind == SD_BCSD_PR && !p.from_state && p.work_count2 != nullptr && p.G <= 64 && group_len != nullptr &&
+            sd_dev_env("SD_FX_NOCOMPACT") == nullptr) {
+            // BcsdPrecipitation fit + predict: only the wet days are sorted; segments with too many of them for the narrow
+            // network come back on the second list and take the K-wide kernel
+            constexpr int KC = compact_width<K>();
+            Params q = p;
+            if ((full | rest) == 0ull) rest = p.G == 64 ? ~0ull : (1ull << p.G) - 1ull;  // (no split into whole-lane groups: all of them)
+            if (full != 0ull) {
+                q.gmask = full;
+                const int64_t nb = 8 * ((p.ntiles + 7) / 8) * __builtin_popcountll(full);
+                SD_CHECK_ARG(nb < ((int64_t)1 << 31), "grid too large");
+                SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fxc_kernel<K, KC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                SD_LAUNCH(ctx, "bcsd_fxc_kernel_full", (bcsd_fxc_kernel<K, KC, true>), dim3((unsigned)nb), dim3(kThreads), lds, q);
+            }
+            if (rest != 0ull) {  // the months that are not whole lanes: the same kernel with its per-sample predicates
+                q.gmask = rest;
+                const int64_t nb = 8 * ((p.ntiles + 7) / 8) * __builtin_popcountll(rest);
+                SD_CHECK_ARG(nb < ((int64_t)1 << 31), "grid too large");
+                SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fxc_kernel<K, KC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                SD_LAUNCH(ctx, "bcsd_fxc_kernel", (bcsd_fxc_kernel<K, KC, false>), dim3((unsigned)nb), dim3(kThreads), lds, q);
+            }
+            Params r = p;
+            r.use_worklist = 2;  // (the general instantiation: segments of either kind may come back)
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fxp_kernel<K, IDENT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SD_LAUNCH(ctx, "bcsd_fxp_kernel_list", (bcsd_fxp_kernel<K, IDENT, false>), dim3((unsigned)(2 * (ctx->cu_count > 0 ? ctx->cu_count : 256))),
+                      dim3(kThreads), lds, r);
+            return SD_OK;
         }
     }
 #endif

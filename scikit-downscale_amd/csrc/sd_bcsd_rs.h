@@ -38,6 +38,10 @@ struct Params {
     int* work_count;  // device counter (items appended, may exceed work_cap: the excess is lost and reported)
     int work_cap;
     int use_worklist;
+    // second list of the compacting precipitation kernel (segments with too many wet days for its narrow sort): served by
+    // bcsd_fxp_kernel<K, true, true> launched with use_worklist = 2
+    int64_t* worklist2;
+    int* work_count2;
     // QuantileMapper(detrend=True) (quantile.py:95-98, 128-145): both series lose their least-squares line over the sample
     // index before the CDFs; the predict line comes back afterwards, re-based on the fitted intercept.  RANK / APPLY / FIT
     // only (the fused kernel is bypassed).

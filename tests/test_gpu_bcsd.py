@@ -69,6 +69,39 @@ def test_bcsd_precipitation_bad_climatology(ctx):
     assert_close(out, g["out_abs"], what="badclimo/abs")
 
 
+@pytest.mark.parametrize("p_dry", [0.0, 0.3, 0.6, 0.95, 1.0])
+def test_bcsd_precipitation_dry_fraction_sweep(ctx, p_dry):
+    """BcsdPrecipitation fit + predict on whole-lane months (40-year daily series: the kernel that sorts only the wet days,
+    bcsd_fxc_kernel) for series that are all wet, mostly wet (more wet days than its narrow sort holds: the segments come back on
+    the second list and take the K-wide kernel), zero-inflated, almost dry and entirely dry, per cell mixed: against the NumPy
+    oracle (bcsd.py:115-185, quantile.py:488: every zero takes the largest rank among the zeros)."""
+    import bcsd_oracle
+    from skdownscale_amd import synth
+
+    T, C = 14600, 19  # (a partly filled last tile)
+    index = synth.daily_calendar(T)
+    gid = month_gid(index)
+    cells = np.arange(C)
+    fields = []
+    for name, stream in (("X_hist", 10), ("y_obs", 11), ("X_fut", 12)):
+        f = synth.fill(synth.PRECIP, 77, stream, np.arange(T), cells, C, amp=40.0 + stream, p_dry=p_dry)
+        if p_dry == 0.6:  # cells of other regimes beside it in the same tiles
+            f[:, 3] = synth.fill(synth.PRECIP, 78, stream, np.arange(T), cells[:1], C, amp=30.0, p_dry=0.1)[:, 0]
+            f[:, 11] = synth.fill(synth.PRECIP, 79, stream, np.arange(T), cells[:1], C, amp=30.0, p_dry=0.99)[:, 0]
+        fields.append(f)
+    X, y, Xp = fields
+    if p_dry == 1.0:
+        y[5::7, :] = 1.5  # (an all-zero climatology is the reference's ValueError: keep the observations positive somewhere)
+    exp, est = bcsd_oracle.pointwise_fit_predict(1, X, y, Xp, gid, gid, return_anoms=True)
+    out, st = ctx.bcsd_fit_predict(1, ctx.to_device(X), ctx.to_device(y), gid, 12, ctx.to_device(Xp), gid, True)
+    assert np.array_equal(st, est)
+    assert_close(out.to_host(), exp, what=f"p_dry={p_dry}")
+    exp, est = bcsd_oracle.pointwise_fit_predict(1, X, y, Xp, gid, gid, return_anoms=False)
+    out, st = ctx.bcsd_fit_predict(1, ctx.to_device(X), ctx.to_device(y), gid, 12, ctx.to_device(Xp), gid, False)
+    assert np.array_equal(st, est)
+    assert_close(out.to_host(), exp, what=f"p_dry={p_dry} abs")
+
+
 QT_VARIANTS = [dict(n_endpoints=5), dict(n_endpoints=3, extrapolate="both"), dict(extrapolate="min"), dict(extrapolate="max"),
                dict(extrapolate=None), dict(extrapolate="1to1"), dict(alpha=0.3, beta=0.2), dict(n_endpoints=40)]
 
