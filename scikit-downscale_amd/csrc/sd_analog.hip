@@ -458,7 +458,8 @@ int fit_predict_dev(sd_ctx* ctx, const double* X, const double* y, int64_t ld, i
     if (nw == 0) return SD_OK;
     // cells handed back (ties among the training values or on a window boundary): the split path answers them.  Few: on packed
     // copies of their columns; many: the whole grid in place (the same numbers either way).
-    if ((int64_t)nw * 2 > C) return fit_predict_split(ctx, X, y, ld, T, F, C, Xq, ld_q, Tq, k, kind, has_thresh, thresh, out, ld_out, nullptr);
+    // (what the split path finds for the cells it recomputes replaces what the fused pass reported for them)
+    if ((int64_t)nw * 2 > C) return fit_predict_split(ctx, X, y, ld, T, F, C, Xq, ld_q, Tq, k, kind, has_thresh, thresh, out, ld_out, cell_status);
     sd_scratch Xw, yw, Qw, Ow;
     SD_HIP(Xw.alloc(ctx, sizeof(double) * (size_t)T * nw));
     SD_HIP(yw.alloc(ctx, sizeof(double) * (size_t)T * nw));
@@ -468,10 +469,15 @@ int fit_predict_dev(sd_ctx* ctx, const double* X, const double* y, int64_t ld, i
     SD_LAUNCH(ctx, "analog_gather_cells_kernel", analog_gather_cells_kernel, blocks(T * nw), dim3(256), 0, X, ld, T, (const int32_t*)worklist, (int64_t)nw, Xw.as<double>());
     SD_LAUNCH(ctx, "analog_gather_cells_kernel", analog_gather_cells_kernel, blocks(T * nw), dim3(256), 0, y, ld, T, (const int32_t*)worklist, (int64_t)nw, yw.as<double>());
     SD_LAUNCH(ctx, "analog_gather_cells_kernel", analog_gather_cells_kernel, blocks(Tq * nw), dim3(256), 0, Xq, ld_q, Tq, (const int32_t*)worklist, (int64_t)nw, Qw.as<double>());
-    SD_TRY(fit_predict_split(ctx, Xw.as<double>(), yw.as<double>(), nw, T, 1, nw, Qw.as<double>(), nw, Tq, k, kind, has_thresh, thresh, Ow.as<double>(), nw, nullptr));
+    std::vector<int32_t> st_w((size_t)nw), cells_w((size_t)nw);
+    SD_TRY(fit_predict_split(ctx, Xw.as<double>(), yw.as<double>(), nw, T, 1, nw, Qw.as<double>(), nw, Tq, k, kind, has_thresh, thresh, Ow.as<double>(), nw,
+                             cell_status ? st_w.data() : nullptr));
     SD_LAUNCH(ctx, "analog_scatter_cells_kernel", analog_scatter_cells_kernel, blocks(3 * Tq * nw), dim3(256), 0, (const double*)Ow.p, 3 * Tq, (const int32_t*)worklist,
               (int64_t)nw, out, ld_out);
+    if (cell_status) SD_HIP(hipMemcpyAsync(cells_w.data(), worklist, sizeof(int32_t) * (size_t)nw, hipMemcpyDeviceToHost, ctx->stream));
     SD_HIP(hipStreamSynchronize(ctx->stream));
+    if (cell_status)  // the recomputed cells report what the split path found for them
+        for (int32_t j = 0; j < nw; ++j) cell_status[cells_w[(size_t)j]] = st_w[(size_t)j];
     return SD_OK;
 }
 

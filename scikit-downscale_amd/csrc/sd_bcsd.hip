@@ -25,7 +25,6 @@
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kEndpoints = 10;  // quantile.py:426
 constexpr double kAlpha = 0.4;  // quantile.py:423
 constexpr double kBeta = 0.4;   // quantile.py:424
 
@@ -161,6 +160,7 @@ __global__ void __launch_bounds__(64 * W) bcsd_fit_kernel(int kind, const double
 // ------------------------------------------------------------------------------------------------
 struct TailFit {
     double slope_lo, icpt_lo, slope_hi, icpt_hi;
+    int tails;  // SD_QT_TAIL_LOWER | SD_QT_TAIL_UPPER: which sides continue along their line (the other takes np.interp's end value)
 };
 
 // 10-endpoint OLS lines for the CDF tails (quantile.py:532-543; sklearn LinearRegression = centred LS)
@@ -187,8 +187,8 @@ __device__ void ols_line(const double* __restrict__ ysg, int first, int e, doubl
 __device__ __forceinline__ double inverse_cdf(double p, const double* __restrict__ ysg, int n, double denom,
                                               const TailFit& tf) {
     const double pp0 = pp_at(0, denom), ppl = pp_at(n - 1, denom);
-    if (p < pp0) return p * tf.slope_lo + tf.icpt_lo;
-    if (p > ppl) return p * tf.slope_hi + tf.icpt_hi;
+    if (p < pp0) return (tf.tails & SD_QT_TAIL_LOWER) ? p * tf.slope_lo + tf.icpt_lo : ysg[0];      // quantile.py:527-545
+    if (p > ppl) return (tf.tails & SD_QT_TAIL_UPPER) ? p * tf.slope_hi + tf.icpt_hi : ysg[n - 1];
     // pp is an affine grid: analytic guess, then guard against rounding of the guess
     int i = (int)floor(p * denom + kAlpha) - 1;
     i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(64 * W) bcsd_predict_kernel(
     const int32_t* __restrict__ goff_p, const int32_t* __restrict__ goff_f, int G, int64_t Tf, int64_t C, int stride,
     int return_anoms, const double* __restrict__ ys, const double* __restrict__ x_climo,
     const double* __restrict__ y_climo, const int32_t* __restrict__ fit_status, int32_t* status,
-    double* __restrict__ out, int64_t ld_out) {
+    double* __restrict__ out, int64_t ld_out, int qt_tails, int qt_endpoints) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* tile_x = reinterpret_cast<double*>(smem_raw);
     double* tile_s = tile_x + W * stride;
@@ -249,10 +249,10 @@ __global__ void __launch_bounds__(64 * W) bcsd_predict_kernel(
 
     const double* ysg = ys + (cell_ok ? c : 0) * Tf + begf;
     const double dn = pp_denom(n), dm = pp_denom(m);
-    TailFit tf = {0.0, 0.0, 0.0, 0.0};
+    TailFit tf = {0.0, 0.0, 0.0, 0.0, qt_tails};
     const bool active = cell_ok && n > 0 && fit_status[c] == 0;
     if (active && m > n) {  // p can leave [pp_0, pp_{n-1}] only when the predict segment is longer
-        const int e = n < kEndpoints ? n : kEndpoints;
+        const int e = n < qt_endpoints ? n : qt_endpoints;
         ols_line(ysg, 0, e, dn, &tf.slope_lo, &tf.icpt_lo);
         ols_line(ysg, n - e, e, dn, &tf.slope_hi, &tf.icpt_hi);
     }
@@ -610,7 +610,7 @@ int launch_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, int64
     SD_LAUNCH(ctx, "bcsd_predict_kernel", bcsd_predict_kernel<W>, grid, dim3(64 * W), lds, st->kind, Xp, ld,
               (const int32_t*)gt.order.p, (const int32_t*)gt.off.p, (const int32_t*)st->goff_dev, st->G, st->T, st->C,
               stride, st->return_anoms, (const double*)st->ys, (const double*)st->x_climo, (const double*)st->y_climo,
-              (const int32_t*)st->status, status_p, out, ld_out);
+              (const int32_t*)st->status, status_p, out, ld_out, st->qt_tails, st->qt_endpoints);
     return SD_OK;
 }
 
@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(1024) bcsd_long_predict_kernel(
     const int32_t* __restrict__ goff_p, const int32_t* __restrict__ goff_f, int G, int64_t Tf, int64_t C, int return_anoms,
     const double* __restrict__ ys, const double* __restrict__ x_climo, const double* __restrict__ y_climo,
     const int32_t* __restrict__ fit_status, int32_t* status, double* __restrict__ out, int64_t ld_out, int detrend,
-    const double* __restrict__ y_trend) {
+    const double* __restrict__ y_trend, int qt_tails, int qt_endpoints) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int64_t c = blockIdx.x;
     const int g = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
@@ -760,9 +760,9 @@ __global__ void __launch_bounds__(1024) bcsd_long_predict_kernel(
     const double* ysg = ys + c * Tf + begf;
     const double dn = pp_denom(n), dm = pp_denom(m);
     if (tid == 0) {
-        TailFit tf = {0.0, 0.0, 0.0, 0.0};
+        TailFit tf = {0.0, 0.0, 0.0, 0.0, qt_tails};
         if (active && m > n) {  // p can leave [pp_0, pp_{n-1}] only when the predict segment is longer
-            const int e = n < kEndpoints ? n : kEndpoints;
+            const int e = n < qt_endpoints ? n : qt_endpoints;
             ols_line(ysg, 0, e, dn, &tf.slope_lo, &tf.icpt_lo);
             ols_line(ysg, n - e, e, dn, &tf.slope_hi, &tf.icpt_hi);
         }
@@ -869,7 +869,7 @@ int launch_long_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, 
     SD_LAUNCH(ctx, "bcsd_long_predict_kernel", bcsd_long_predict_kernel<K>, dim3((unsigned)st->C, (unsigned)st->G), dim3(1024), lds,
               st->kind, Xp, ld, (const int32_t*)gt.order.p, (const int32_t*)gt.off.p, (const int32_t*)st->goff_dev, st->G, st->T,
               st->C, st->return_anoms, (const double*)st->ys, (const double*)st->x_climo, (const double*)st->y_climo,
-              (const int32_t*)st->status, status_p, out, ld_out, st->detrend, (const double*)st->y_trend);
+              (const int32_t*)st->status, status_p, out, ld_out, st->detrend, (const double*)st->y_trend, st->qt_tails, st->qt_endpoints);
     return SD_OK;
 }
 
@@ -966,9 +966,6 @@ static int predict_with_table(sd_ctx* ctx, const sd_bcsd_state* st, const double
     int W = 0, stride = 0;
     const int nmax_all = gt.nmax > st->nmax ? gt.nmax : st->nmax;
     const bool rs = use_rs_path(nmax_all, ld > ld_out ? ld : ld_out);
-    if (!rs && (st->qt_tails != (SD_QT_TAIL_LOWER | SD_QT_TAIL_UPPER) || st->qt_endpoints != 10))
-        return sd_set_error(SD_ERR_UNSUPPORTED, "non-default extrapolate / n_endpoints serve group segments of up to %d samples (longest here: %d)",
-                            64 * 33, nmax_all);
     const bool lng = !rs && use_long_path(nmax_all, ctx->lds_max) && long_width(gt.nmax, ctx->lds_max) != 0;
     if (st->detrend && !rs && !lng)
         return sd_set_error(SD_ERR_UNSUPPORTED, "detrended quantile mapping serves group segments of up to %d samples (longest here: %d)",
@@ -1273,7 +1270,8 @@ int sd_bcsd_predict(sd_ctx* ctx, const sd_bcsd_state* st, const double* Xp, cons
         if (st->y_climo) view.y_climo = st->y_climo + c0 * st->G;
         if (st->y_trend) view.y_trend = st->y_trend + c0 * st->G * 2;
         view.status = st->status + c0;
-        if (blk >= 2 && drain.joinable()) drain.join();  // the drain of block blk - 2 used this result buffer (joined below anyway)
+        // (dout[blk & 1] is free: the drain of block blk - 2 was joined in iteration blk - 1, after that block's kernels; the drain
+        // of block blk - 1 -- the other buffer -- keeps running beside this block's kernels)
         double* res = dout[blk & 1].as<double>();
         rc = sd_bcsd_predict_dev(ctx, &view, dX.as<double>(), cw, group_id_p, Tp, res, cw,
                                  cell_status ? cell_status + c0 : nullptr);  // (returns when the block's kernels are done)

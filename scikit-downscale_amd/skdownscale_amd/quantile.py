@@ -63,8 +63,23 @@ class QuantileMapper(TransformerMixin, BaseEstimator):
     def _check(self):
         if self.detrend and self.lt_kwargs:
             raise NotImplementedError("QuantileMapper(lt_kwargs=...): only the LinearTrendTransformer defaults run on the HIP engine")
-        if self.qt_kwargs:
-            raise NotImplementedError("QuantileMapper(qt_kwargs=...): only the CunnaneTransformer defaults run on the HIP engine")
+        self._tails()
+
+    def _tails(self):
+        """(extrapolate, n_endpoints) of ``qt_kwargs`` (quantile.py:92, 136: the CunnaneTransformer of both directions gets them):
+        which tails of the fitted inverse CDF continue along the least-squares line through their ``n_endpoints`` outermost
+        points.  ``alpha`` / ``beta`` are accepted and, as in the reference, without effect (quantile.py:462)."""
+        qt = self.qt_kwargs or {}
+        for k in qt:
+            if k not in ("alpha", "beta", "extrapolate", "n_endpoints"):
+                raise TypeError(f"CunnaneTransformer.__init__() got an unexpected keyword argument {k!r}")
+        extrapolate = qt.get("extrapolate", "both")
+        if extrapolate not in ("min", "max", "both", "1to1", None):
+            extrapolate = None  # (the reference only tests membership, quantile.py:527-528: anything else is np.interp's end values)
+        n_endpoints = qt.get("n_endpoints", 10)
+        if not isinstance(n_endpoints, (int, np.integer)) or n_endpoints < 1:
+            raise NotImplementedError(f"CunnaneTransformer(n_endpoints={n_endpoints!r}): a positive integer is needed on the HIP engine")
+        return extrapolate, int(n_endpoints)
 
     def fit(self, X, y=None):
         self._check()
@@ -73,6 +88,7 @@ class QuantileMapper(TransformerMixin, BaseEstimator):
         Xv = np.asarray(X, dtype=np.float64).reshape(-1, 1)
         ctx = default_context()
         self._state = ctx.bcsd_fit(_lib.BCSD_PR, None, Xv, np.zeros(len(Xv), dtype=np.int32), 1, False, detrend=bool(self.detrend))
+        self._state.set_tails(*self._tails())
         e = self._state.export()
         vals = e["y_sorted"][0]
         self.x_cdf_fit_ = FittedCunnane(Cdf(plotting_positions(len(vals)), vals))
@@ -92,7 +108,9 @@ class QuantileMapper(TransformerMixin, BaseEstimator):
         if self.detrend:
             line = self.x_trend_fit_.lr_model_
             exported["y_trend"] = np.array([float(np.ravel(line.coef_)[0]), float(np.ravel(line.intercept_)[0])]).reshape(1, 1, 2)
-        return ctx.bcsd_import(exported)
+        state = ctx.bcsd_import(exported)
+        state.set_tails(*self._tails())
+        return state
 
     def transform(self, X):
         if not hasattr(self, "x_cdf_fit_"):

@@ -161,6 +161,29 @@ def test_estimators_reference_surface():
     assert_close(out.values, exp, what="PointWiseDownscaler ecm")
 
 
+def test_quantile_mapper_qt_kwargs_golden():
+    """Stand-alone QuantileMapper(qt_kwargs=...) against g20_qm_qt_kwargs.npz from the real reference (quantile.py:92, 136: the
+    keywords reach the CunnaneTransformer of the fitted CDF): every `extrapolate`, several `n_endpoints`, `alpha` / `beta`
+    without effect; a fit of 800 samples (fused kernels) and one of 3 000 (one group beyond 2 112 samples: the workgroup-sort
+    kernels take the same tail settings); the fitted object survives pickling with them."""
+    import ast
+    import pickle
+
+    from skdownscale_amd import QuantileMapper
+
+    g = load("g20_qm_qt_kwargs")
+    for tag in ("s", "l"):
+        fit, new = g[f"{tag}_fit"], g[f"{tag}_new"]
+        for i in range(int(g["n_variants"])):
+            kw = dict(ast.literal_eval(str(g["variants"][i])))
+            m = QuantileMapper(qt_kwargs=kw).fit(fit)
+            assert_close(m.transform(new), g[f"{tag}{i}"], what=f"QuantileMapper(qt_kwargs={kw}) {tag}")
+            if i in (2, 4):
+                assert_close(pickle.loads(pickle.dumps(m)).transform(new), g[f"{tag}{i}"], what=f"unpickled {kw} {tag}")
+    with pytest.raises(TypeError):
+        QuantileMapper(qt_kwargs={"gamma": 1}).fit(g["s_fit"])
+
+
 def test_quantile_mapper_transformer():
     """The reference's only numeric test of this path (test_pointwise_models.py:81-90) and its golden output; longer /
     shorter series than the fitted one (tail OLS and table paths) vs the BCSD oracle's mapping; series beyond the

@@ -385,3 +385,21 @@ def test_pointwise_transformer_loop_oracle_matches_golden():
         assert_close(out, g["qm_fwd"][:, c], what=f"QuantileMapper.transform cell {c}")
         stt, _ = bo.bcsd_fit_cell(bo.TAS, X[:, c], y[:, c], gid)
         np.testing.assert_allclose(stt["y_climo"], g["y_climo"][:, c], rtol=1e-12)
+
+
+def test_quantile_mapper_qt_kwargs_oracle_matches_golden():
+    """g20_qm_qt_kwargs.npz (stand-alone QuantileMapper(qt_kwargs=...) of the real reference, transform series longer than the
+    fitted one, fits of 800 and 3 000 samples): the oracle's qm_segment with the same `extrapolate` / `n_endpoints`
+    (quantile.py:92, 136, 418-431, 523-545)."""
+    import ast
+
+    import bcsd_oracle
+
+    g = load("g20_qm_qt_kwargs")
+    for tag in ("s", "l"):
+        fit, new = g[f"{tag}_fit"][:, 0], g[f"{tag}_new"][:, 0]
+        for i in range(int(g["n_variants"])):
+            kw = dict(ast.literal_eval(str(g["variants"][i])))
+            got = bcsd_oracle.qm_segment(new, np.sort(fit), None, kw.get("extrapolate", "both"), kw.get("n_endpoints", 10))
+            exp = g[f"{tag}{i}"][:, 0]
+            assert np.allclose(got, exp, rtol=1e-12, atol=1e-12), (tag, kw, np.abs(got - exp).max())
