@@ -78,6 +78,7 @@ int main(int argc, char** argv) {
     printf("stream_read      : %8.3f ms  %8.1f GB/s\n", ms, 1.0 * T * C * 8 / ms / 1e6);
     for (int mapping = 0; mapping < 3; ++mapping) {
         run<4, 1>(x, C, dorder, doff, G, C, T, sink, mapping);
+        run<4, 2>(x, C, dorder, doff, G, C, T, sink, mapping);
         run<8, 1>(x, C, dorder, doff, G, C, T, sink, mapping);
         run<8, 2>(x, C, dorder, doff, G, C, T, sink, mapping);
         run<16, 1>(x, C, dorder, doff, G, C, T, sink, mapping);
