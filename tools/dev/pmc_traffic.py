@@ -18,8 +18,13 @@ FETCH_CORRECTION = 2.0
 
 def short(name):
     n = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    n = n.split("(")[0].split("<")[0]
-    return n.split("::")[-1]
+    n = n.split("(")[0]
+    base = n.split("<")[0].split("::")[-1]
+    # the whole-lane instantiations of the fused BCSD kernels (last template argument FULL = true) are launched -- and named
+    # by SD_LAUNCH -- separately from the general ones
+    if base in ("bcsd_fx_kernel", "bcsd_fxp_kernel", "bcsd_fxc_kernel") and "<" in n and n.rstrip().rstrip(">").rstrip().endswith("true"):
+        base += "_full"
+    return base
 
 
 def per_kernel(path):
@@ -44,7 +49,7 @@ def main():
         for kname, launches in roof["launches_per_step"].items():
             # bench.py names (SD_LAUNCH) are prefixes / variants of the symbol names: bcsd_rs_rank_kernel = bcsd_rs_kernel<K, 3, ...>
             sym = {"bcsd_rs_rank_kernel": "bcsd_rs_kernel", "bcsd_rs_apply_kernel": "bcsd_rs_kernel", "bcsd_rs_fit_kernel": "bcsd_rs_kernel",
-                   "analog_sort2_exact_kernel": "analog_sort2_kernel"}.get(kname, kname)
+                   "analog_sort2_exact_kernel": "analog_sort2_kernel", "bcsd_fxp_kernel_list": "bcsd_fxp_kernel"}.get(kname, kname)
             f, w = fetch.get(sym, 0.0) * FETCH_CORRECTION, write.get(sym, 0.0)
             detail[kname] = {"symbol": sym, "fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "launches_per_step": launches}
             total += (f + w) * launches

@@ -54,11 +54,8 @@ sq)
   done
   ;;
 extra)
+  # (the analog kinds / AnalogRegression / F = 3 are part of the default bench line since round 5: secondary.analog_kinds, analog_f3)
   rm -f $O/bench_extra.json
-  for kind in mean_analogs best_analog weight_analogs; do timeout 200 python tools/bench_extra.py --workload analog --kind $kind --cells 16384 --out $O/bench_extra.json > /dev/null 2>&1; done
-  timeout 200 python tools/bench_extra.py --workload analogreg --cells 16384 --out $O/bench_extra.json > /dev/null 2>&1
-  for f in 2 3 4; do timeout 200 python tools/bench_extra.py --workload analog --features $f --cells 2048 --out $O/bench_extra.json > /dev/null 2>&1; done
-  timeout 200 python tools/bench_extra.py --workload analogreg --features 3 --cells 2048 --out $O/bench_extra.json > /dev/null 2>&1
   timeout 200 python tools/bench_extra.py --workload pure_regression --cells 100000 --out $O/bench_extra.json > /dev/null 2>&1
   for w in qmr ecm; do timeout 200 python tools/bench_extra.py --workload $w --cells 100000 --out $O/bench_extra.json > /dev/null 2>&1; done
   wc -l $O/bench_extra.json
