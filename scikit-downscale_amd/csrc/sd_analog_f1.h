@@ -140,6 +140,7 @@ __device__ void f1_walk_query(int mode, const PredictArgs& pa, int n, int64_t T,
     finish_query(mode, pa, 1, T, c, tq, &q, Xc_cell, yc_cell, sd, si, nthr, true);
 }
 
+typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));  // a pair of doubles at any 8-byte boundary
 constexpr int kWinQ = 2;      // queries a thread answers together (independent dependency chains)
 constexpr int kWinBatch = 8;  // analog values read together per query
 
@@ -536,9 +537,20 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                         double s1 = 0.0, s2 = 0.0, wsum = 0.0, awsum = 0.0;
                         int nexc = 0;
                         for (int i0 = 0; i0 < k; i0 += kWinBatch) {
+                            // two analog values per load (a lane's window is contiguous; the texture path is the limit of
+                            // this branch: half the load instructions, half the line requests)
                             double ab[kWinBatch];
 #pragma unroll
-                            for (int b = 0; b < kWinBatch; ++b) ab[b] = i0 + b < k ? yl[i0 + b] : 0.0;
+                            for (int b = 0; b < kWinBatch; b += 2) {
+                                if (i0 + b + 1 < k) {
+                                    const f64x2_a8 v = *reinterpret_cast<const f64x2_a8*>(yl + i0 + b);
+                                    ab[b] = v.x;
+                                    ab[b + 1] = v.y;
+                                } else {
+                                    ab[b] = i0 + b < k ? yl[i0 + b] : 0.0;
+                                    ab[b + 1] = 0.0;
+                                }
+                            }
 #pragma unroll
                             for (int b = 0; b < kWinBatch; ++b) {
                                 const int i = i0 + b;

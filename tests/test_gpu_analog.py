@@ -103,6 +103,26 @@ def test_window_path_full_length_series(ctx, data):
     assert_close(out[:250], exp, what=f"window {data} regression")
 
 
+@pytest.mark.parametrize("k", [2, 3, 7, 8, 9, 17, 29, 31])
+def test_window_reads_any_window_length(ctx, k):
+    """weight_analogs and the thresholded kinds read the k analog values of a window two per load (pairs at any 8-byte
+    boundary, a single load for the last value of an odd k): window lengths on either side of the batches of 8, windows that
+    start at odd and even positions, at both ends of the sorted series"""
+    rng = np.random.default_rng(400 + k)
+    T, Tq, C = 1201, 600, 3
+    X = rng.standard_normal((T, 1, C))
+    Xq = np.concatenate([1.4 * rng.standard_normal((Tq - 4, 1, C)), np.array([-9.0, 9.0, -8.0, 8.0])[:, None, None] * np.ones((1, 1, C))])
+    y = 0.5 * X[:, 0, :] + rng.standard_normal((T, C))
+    st = ctx.analog_fit(X, y)
+    for kind, thresh in (("weight_analogs", None), ("weight_analogs", 0.2), ("mean_analogs", 0.2)):
+        out, status = ctx.analog_predict(st, Xq, k, KINDS[kind], thresh)
+        assert (status == 0).all()
+        assert_close(out, ao.pointwise_analog(X, y, Xq, k, KINDS[kind], thresh), what=f"k={k} {kind} thresh={thresh}")
+        # the fused fit + predict entry point answers the same call
+        both, _ = ctx.analog_fit_predict(X, y, Xq, k, KINDS[kind], thresh)
+        assert np.array_equal(both, out, equal_nan=True), (k, kind, thresh)
+
+
 @pytest.mark.parametrize("case", ["exact_line", "constant_y", "dry_spells", "k2", "short"])
 def test_regression_prefix_path_edges(ctx, case):
     """One-feature AnalogRegression takes the prefix-sum kernel (k >= 3): noise-free lines and constant analog sets
