@@ -353,6 +353,10 @@ __global__ void __launch_bounds__(1024) analog_f1_window_kernel(int mode, const 
     }
 }
 
+#ifndef SD_MEANQ
+#define SD_MEANQ 2
+#endif
+constexpr int kMeanQ = SD_MEANQ;  // queries a thread of analog_f1_mean_kernel searches together (independent bisection chains)
 // F == 1, single pass over the queries with only the sorted training values LDS-resident.  'mean_analogs' without a
 // threshold, a single analog and AnalogRegression (mode 1, k >= 3) take the window statistics from the prefix sums
 // pq / rx (analog_prefix_kernel): the window search plus two (regression: three) pairs of prefix loads per query.
@@ -411,11 +415,11 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
             for (int i = tid; i < n; i += nthr) xs[i] = xg[i];
         if (tid == 0) xs[n] = inf;
         __syncthreads();
-        for (int64_t tq0 = q_beg + tid; tq0 < q_end; tq0 += (int64_t)nthr * kWinQ) {
-            double q[kWinQ];
-            bool has[kWinQ], ok[kWinQ];
+        for (int64_t tq0 = q_beg + tid; tq0 < q_end; tq0 += (int64_t)nthr * kMeanQ) {
+            double q[kMeanQ];
+            bool has[kMeanQ], ok[kMeanQ];
 #pragma unroll
-            for (int j = 0; j < kWinQ; ++j) {
+            for (int j = 0; j < kMeanQ; ++j) {
                 const int64_t tq = tq0 + (int64_t)j * nthr;
                 has[j] = tq < q_end;
                 q[j] = has[j] ? Xq[c * Tq + tq] : 0.0;
@@ -428,21 +432,21 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
             // [L, L + k) with p - k <= L <= p: the smallest L of that range with rdist(L) <= rdist(L + k), log2(k + 1)
             // more steps of two reads (rdist is unimodal along xs).  With ties the separation test below sends the query
             // to the exact walk.
-            int lo[kWinQ], hi[kWinQ];
+            int lo[kMeanQ], hi[kMeanQ];
             {
-                int pos[kWinQ];
+                int pos[kMeanQ];
 #pragma unroll
-                for (int j = 0; j < kWinQ; ++j) pos[j] = -1;  // index of the last value known to be < q
+                for (int j = 0; j < kMeanQ; ++j) pos[j] = -1;  // index of the last value known to be < q
 #pragma unroll 1
                 for (int len = n; len > 1;) {
                     int half = len >> 1;
                     if ((half & 15) == 0) --half;
                     len -= half;
 #pragma unroll
-                    for (int j = 0; j < kWinQ; ++j) pos[j] += xs[pos[j] + half] < q[j] ? half : 0;
+                    for (int j = 0; j < kMeanQ; ++j) pos[j] += xs[pos[j] + half] < q[j] ? half : 0;
                 }
 #pragma unroll
-                for (int j = 0; j < kWinQ; ++j) {
+                for (int j = 0; j < kMeanQ; ++j) {
                     const int p = pos[j] + 1 + (xs[pos[j] + 1] < q[j] ? 1 : 0);
                     lo[j] = p - k > 0 ? p - k : 0;
                     hi[j] = p < n - k ? p : n - k;
@@ -451,7 +455,7 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
 #pragma unroll 1
             for (int s = 0; s < nsteps; ++s) {
 #pragma unroll
-                for (int j = 0; j < kWinQ; ++j) {
+                for (int j = 0; j < kMeanQ; ++j) {
                     const int mid = (lo[j] + hi[j]) >> 1;
                     const bool act = lo[j] < hi[j];
                     const bool right = sq_dist(q[j], xs[mid]) > sq_dist(q[j], xs[mid + k]);
@@ -459,19 +463,34 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                     hi[j] = (act && !right) ? mid : hi[j];
                 }
             }
+            // the statistics of one query at a time, as a rolled loop (its body is long: unrolled over the queries of the
+            // thread it no longer fits the instruction cache); the query in turn sits in slot 0, the others move down
+            unsigned hasm = 0u, okm = 0u;
 #pragma unroll
-            for (int j = 0; j < kWinQ; ++j) {
-                if (!has[j]) continue;
-                const int64_t tq = tq0 + (int64_t)j * nthr;
+            for (int j = 0; j < kMeanQ; ++j) {
+                hasm |= has[j] ? 1u << j : 0u;
+                okm |= ok[j] ? 1u << j : 0u;
+            }
+#pragma unroll 1
+            for (int jr = 0; jr < kMeanQ; ++jr) {
+                const double qj = q[0];
+                const int L = lo[0];
+                const bool has_j = (hasm >> jr) & 1u, ok_j = (okm >> jr) & 1u;
+#pragma unroll
+                for (int i = 0; i + 1 < kMeanQ; ++i) {
+                    q[i] = q[i + 1];
+                    lo[i] = lo[i + 1];
+                }
+                if (!has_j) continue;
+                const int64_t tq = tq0 + (int64_t)jr * nthr;
                 double pred = nan, prob = nan, err = nan;
-                if (ok[j]) {
-                    const int L = lo[j];
-                    const double dL = sq_dist(q[j], xs[L]), dR = sq_dist(q[j], xs[L + k - 1]);
+                if (ok_j) {
+                    const double dL = sq_dist(qj, xs[L]), dR = sq_dist(qj, xs[L + k - 1]);
                     const double worst = dL > dR ? dL : dR;
-                    const bool sep_l = L == 0 || sq_dist(q[j], xs[L - 1]) > worst;
-                    const bool sep_r = L + k == n || sq_dist(q[j], xs[L + k]) > worst;
+                    const bool sep_l = L == 0 || sq_dist(qj, xs[L - 1]) > worst;
+                    const bool sep_r = L + k == n || sq_dist(qj, xs[L + k]) > worst;
                     if (!(sep_l && sep_r)) {
-                        f1_walk_query(mode, pa, n, T, c, tq, q[j], xg, xi_all + c * T, Xc + c * T, yc + c * T, sd, si, nthr);
+                        f1_walk_query(mode, pa, n, T, c, tq, qj, xg, xi_all + c * T, Xc + c * T, yc + c * T, sd, si, nthr);
                         continue;
                     }
                     if (mode == 1) {
@@ -491,7 +510,7 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                         const double vxy = (rx[L + k] - rx[L]) + (xbar - xm) * s1;
                         const double slope = vxx > 0.0 ? vxy / vxx : 0.0;
                         double ss = vyy - slope * vxy;
-                        pred = (ybar + m1) + (q[j] - xm) * slope;
+                        pred = (ybar + m1) + (qj - xm) * slope;
                         if (!(ss > ss_floor)) {
                             // (nearly) exact fit or constant analogs: the sums directly, as analog_f1_window_kernel
                             const double* yl = yx_all + c * T + L;
@@ -506,7 +525,7 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                             const double wxy = txy - kk * mx * n1;
                             const double sl = vxx > 0.0 ? wxy / vxx : 0.0;
                             const double icpt = (a0 + n1) - xm * sl;
-                            pred = icpt + q[j] * sl;
+                            pred = icpt + qj * sl;
                             ss = 0.0;
                             for (int i = 0; i < k; ++i) {
                                 const double r = yl[i] - (icpt + xs[L + i] * sl);
@@ -561,7 +580,7 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                                     nexc += (!pa.has_thresh || ai > pa.thresh) ? 1 : 0;  // gard.py:307
                                     if (pa.kind == SD_ANALOG_WEIGHT) {
                                         // w = 1 / distance (gard.py:322-323): v_rcp_f64 + two Newton steps (< 1 ulp)
-                                        double d = __builtin_fabs(q[j] - xs[L + i]);
+                                        double d = __builtin_fabs(qj - xs[L + i]);
                                         d = d == 0.0 ? 1e-20 : d;
                                         double r = __builtin_amdgcn_rcp(d);
                                         r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);

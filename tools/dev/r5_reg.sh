@@ -1,0 +1,13 @@
+#!/bin/bash
+# AnalogRegression / weight_analogs / thresholded mean at BASELINE size, per-kernel times: tools/dev/r5_reg.sh lib.so ...
+run() { timeout 600 python bench.py --config 4 --parity-only --steps 3 --warmup 1 "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); r=d['roofline']
+print('%-60s %9.0f cells/s %8.2f ms parity %s' % (d['config']['workload'][:60], d['value'], d['ms_per_step'], d['parity_check']))
+print('      ', {k: round(v*r['launches_per_step'][k],2) for k,v in r['per_kernel_avg_ms'].items() if v*r['launches_per_step'][k] > 0.3})"; }
+for L in "$@"; do
+  export SD_DOWNSCALE_LIB=$PWD/scikit-downscale_amd/lib/$L
+  echo "== $L"
+  run --analog-estimator regression
+  run --analog-kind weight_analogs
+done
