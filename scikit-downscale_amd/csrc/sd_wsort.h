@@ -114,6 +114,13 @@ __device__ __forceinline__ unsigned med3(unsigned a, unsigned b, unsigned c) { r
 // the value lane (l ^ X) holds in v
 template <int X>
 __device__ __forceinline__ unsigned lane_xor(unsigned v, int addr63) {
+#ifdef SD_WSORT_SWZ
+    // A/B: partners below lane ^ 32 through the LDS crossbar instead of DPP moves (one vector instruction per key and stage less,
+    // one LDS-pipe instruction more); SD_WSORT_SWZ is a bit mask over X
+    if constexpr (X < 32 && ((SD_WSORT_SWZ >> (X == 1 ? 0 : X == 2 ? 1 : X == 3 ? 2 : X == 7 ? 3 : X == 8 ? 4 : X == 15 ? 5 : 6)) & 1))
+        return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (X << 10) | 0x1F);
+    else
+#endif
     if constexpr (X == 1) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
     else if constexpr (X == 2) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
     else if constexpr (X == 3) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
