@@ -147,6 +147,10 @@ def main(n_cases=40, seed=0):
             kind = int(rng.integers(0, 2))
             detrend = bool(rng.random() < 0.4)
             T, Tp = len(index), len(index_p)
+            # the residuals of three equally spaced samples about their least-squares line are always (r, -2r, r): a predict group of
+            # exactly three samples has a tie between its first and last sample that rounding decides (unpinned in the reference too)
+            if detrend and 3 in np.bincount(np.asarray(index_p.day)):
+                detrend = False
             X, y, Xp = (12 + 6 * rng.standard_normal((n, C)) for n in (T, T, Tp))
             if kind == 1:
                 X, y, Xp = np.abs(X) * (rng.random(X.shape) > 0.3), np.abs(y) + 0.2, np.abs(Xp) * (rng.random(Xp.shape) > 0.3)
@@ -162,7 +166,13 @@ def main(n_cases=40, seed=0):
                     exp, _ = bo.bcsd_predict_trend_cell(s1, Xp[:, c], gq, gt, return_anoms=False)
                 else:
                     exp, _ = bo.bcsd_predict_cell(s1, Xp[:, c], gq, return_anoms=False)
-                assert_close(out[:, c], exp, what=f"case {it} nasanex kind={kind} T={T} Tp={Tp} detrend={detrend} cell {c}")
+                try:
+                    assert_close(out[:, c], exp, what=f"case {it} nasanex kind={kind} T={T} Tp={Tp} detrend={detrend} cell {c}")
+                except AssertionError:
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    np.savez(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{seed}_{it}.npz"), X=X[:, c], y=y[:, c], Xp=Xp[:, c], out=out[:, c], exp=exp,
+                             kind=kind, detrend=detrend, start=str(start), pstart=str(pstart), T=T, Tp=Tp)
+                    raise
         elif what == "linreg_thresh":
             # PureRegression(thresh): logistic exceedance model + linear model on the exceeding samples (gard.py:416-470)
             F = int(rng.integers(1, 6))
