@@ -149,7 +149,9 @@ def main(n_cases=40, seed=0):
             T, Tp = len(index), len(index_p)
             # the residuals of three equally spaced samples about their least-squares line are always (r, -2r, r): a predict group of
             # exactly three samples has a tie between its first and last sample that rounding decides (unpinned in the reference too)
-            if detrend and 3 in np.bincount(np.asarray(index_p.day)):
+            # (groups of one or two samples are all-zero residuals likewise: DESIGN.md 2 (iii); >= 4 samples per detrended group)
+            counts = np.bincount(np.asarray(index_p.day))
+            if detrend and (counts[counts > 0] < 4).any():
                 detrend = False
             X, y, Xp = (12 + 6 * rng.standard_normal((n, C)) for n in (T, T, Tp))
             if kind == 1:
