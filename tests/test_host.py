@@ -347,6 +347,26 @@ def test_bcsd_qt_kwargs_are_validated_like_the_reference():
         qt_settings(BcsdTemperature(qm_kwargs={"qt_kwargs": {"n_endpoints": 0}}))
 
 
+def test_quantile_mapper_qt_kwargs_are_validated_like_the_reference():
+    """the stand-alone QuantileMapper(qt_kwargs=...) (quantile.py:92, 136): the same checks and defaults as through
+    BcsdTemperature(qm_kwargs=...), before anything touches the GPU; `lt_kwargs` of a detrended mapping is refused"""
+    from skdownscale_amd import QuantileMapper
+
+    assert QuantileMapper()._tails() == ("both", 10)
+    assert QuantileMapper(qt_kwargs={"alpha": 0.3, "beta": 0.1})._tails() == ("both", 10)
+    assert QuantileMapper(qt_kwargs={"extrapolate": "max", "n_endpoints": np.int64(7)})._tails() == ("max", 7)
+    assert QuantileMapper(qt_kwargs={"extrapolate": "1to1"})._tails() == ("1to1", 10)
+    assert QuantileMapper(qt_kwargs={"extrapolate": None})._tails() == (None, 10)
+    assert QuantileMapper(qt_kwargs={"extrapolate": "sideways"})._tails() == (None, 10)  # quantile.py:527-528
+    with pytest.raises(TypeError, match="unexpected keyword argument 'gamma'"):
+        QuantileMapper(qt_kwargs={"gamma": 1}).fit(np.arange(10.0).reshape(-1, 1))
+    for bad in (0, -3, 2.5, None):
+        with pytest.raises(NotImplementedError, match="n_endpoints"):
+            QuantileMapper(qt_kwargs={"n_endpoints": bad}).fit(np.arange(10.0).reshape(-1, 1))
+    with pytest.raises(NotImplementedError, match="lt_kwargs"):
+        QuantileMapper(detrend=True, lt_kwargs={"fit_intercept": False}).fit(np.arange(10.0).reshape(-1, 1))
+
+
 def test_pure_regression_argument_checks():
     """PureRegression behaviour that needs no GPU (gard.py:402-412): parameters, refused configurations, fit state."""
     from sklearn.base import clone
