@@ -53,8 +53,12 @@ WORKLOADS = {
             name="BcsdPrecipitation (zero-inflated), {C} cells x {T} steps per GPU (BASELINE configs[2])"),
     4: dict(kind="analog", cells=100_000, bytes_per_step=48,
             name="PureAnalog(n_analogs=30, kind='mean_analogs') F=1, {C} cells x {T} steps per GPU (BASELINE configs[3])"),
-    5: dict(kind="bcsd_tas", cells=125_000, bytes_per_step=32,
-            name="BcsdTemperature quantile mapping, {C} cells x {T} steps per GPU: {Ct} cells over {N} GPUs (BASELINE configs[4] at N=8)"),
+    # N > 1: the per-GPU workload of the N = 1 line (configs[1]: 100 000 cells), so that value(N) / value(1) is a weak-scaling
+    # curve over identical per-GPU work; BASELINE configs[4] itself (1 M cells over 8 GPUs = 125 000 per GPU) is timed as a second
+    # leg of the same run (`baseline_config5` in the line)
+    5: dict(kind="bcsd_tas", cells=100_000, bytes_per_step=32, cells_config5=125_000,
+            name="BcsdTemperature quantile mapping, {C} cells x {T} steps per GPU: {Ct} cells over {N} GPUs (the N = 1 workload per GPU; "
+                 "BASELINE configs[4] -- 125 000 per GPU -- in `baseline_config5`)"),
 }
 
 
@@ -117,6 +121,8 @@ def host_cpu_info():
 
 
 ANALOG = {"kind": "mean_analogs", "k": 30, "features": 1, "estimator": "pure"}  # config 4 as BASELINE.json words it; main() may change it
+if os.environ.get("SD_BENCH_ANALOG"):  # the --cpu-worker children of a run with other analog options time the same workload
+    ANALOG.update(json.loads(os.environ["SD_BENCH_ANALOG"]))
 
 
 def analog_is_baseline():
@@ -260,7 +266,9 @@ def cpu_baseline(kind, T, seed, c_full, target_seconds, check=None, parity_only=
             numpy_cells(kind, f1, gid, done, done + 1)
             done += 1
         dt1 = time.perf_counter() - t0
-        what = ("per-cell sklearn KDTree.query(k=30) + NumPy mean / std of the analogs (what gard.py:58-87, 273-346 does per cell)" if kind == "analog"
+        what = ("per-cell sklearn KDTree.query(k=30) + NumPy mean / std of the analogs (what gard.py:58-87, 273-346 does per cell)"
+                if kind == "analog" and analog_is_baseline()
+                else f"oracle/analog_oracle.py per cell ({ANALOG['estimator']}, kind={ANALOG['kind']}, k={ANALOG['k']}, F={ANALOG['features']})" if kind == "analog"
                 else "oracle/bcsd_oracle.py (per-cell NumPy loop: np.sort, np.searchsorted, np.interp per month)")
         numpy_1 = {"value": done / dt1, "unit": "cells/s", "cores": 1, "kind": "port", "cpu": cpu["model"],
                    "sample": f"{done} cells x {T} steps, {what}, {dt1:.1f} s"}
@@ -288,6 +296,36 @@ def cpu_baseline(kind, T, seed, c_full, target_seconds, check=None, parity_only=
     return port, numpy_1, numpy_n, parity, c_port
 
 
+def oracle_parity(X, y, Xp, gid, results, statuses=None):
+    """the host-path results (each [T, n] for the first n cells) against the oracle's fit + predict of the same cells (C port when
+    built, else the NumPy restatement): 'ok' or a failure note; outside every timed region"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import c_oracle
+
+        if c_oracle.available():
+            exp, _ = c_oracle.bcsd_fit_predict(0, X, y, Xp, gid, gid, nthreads=min(8, c_oracle.max_threads()))
+        else:
+            import bcsd_oracle
+
+            exp, _ = bcsd_oracle.pointwise_fit_predict(0, X, y, Xp, gid, gid)
+        tol = 1e-6 * np.nanstd(exp) + 1e-6 * np.abs(exp)
+        worst = 0.0
+        for i, got in enumerate(results):
+            got = np.asarray(got, dtype=np.float64)
+            if got.shape != exp.shape:
+                return f"FAILED shape {got.shape} != {exp.shape}"
+            err = np.abs(got - exp)
+            if not bool((err <= tol).all()):
+                return f"FAILED max_err={np.nanmax(err):.3e} (result {i})"
+            if statuses is not None and not bool((np.asarray(statuses[i]) == 0).all()):
+                return f"FAILED cell status (result {i})"
+            worst = max(worst, float(np.nanmax(err)))
+        return f"ok ({exp.shape[1]} cells x {exp.shape[0]} steps, max abs err {worst:.2e})"
+    except Exception as e:  # noqa: BLE001
+        return f"not run: {type(e).__name__}: {e}"
+
+
 def end_to_end(ctx, index, seed, c_full, n_cells=8192):
     """The drop-in path on host buffers (sd_bcsd_fit + sd_bcsd_predict on NumPy arrays): H2D of three fields, kernels, D2H
     of the result -- PCIe inclusive.  Bounded sample; never the headline value."""
@@ -296,14 +334,19 @@ def end_to_end(ctx, index, seed, c_full, n_cells=8192):
     cells = np.arange(n_cells)
     X, y, Xp = (synth.tas_field(name, seed, index, cells, c_full) for name in ("X_hist", "y_obs", "X_fut"))
     gid = (np.asarray(index.month) - 1).astype(np.int32)
+    n_chk = min(16, n_cells)
+    checked = {}
+
     def passes(n, reuse):
         times, buf = [], (np.empty_like(Xp) if reuse else None)
         for it in range(n):
             t0 = time.perf_counter()
             st = ctx.bcsd_fit(_lib.BCSD_TAS, X, y, gid, 12, True)
-            out, _ = ctx.bcsd_predict(st, Xp, gid, out=buf)
+            out, status = ctx.bcsd_predict(st, Xp, gid, out=buf)
             dt = time.perf_counter() - t0
             st.close()
+            if it == n - 1:  # (outside the timed region) the last pass's result for the first cells, for the parity check below
+                checked["reuse" if reuse else "fresh"] = (np.array(out[:, :n_chk]), np.array(status[:n_chk]))
             del out
             if it >= 2:  # the first passes create the staging buffers, the device blocks and (reuse) touch the result buffer
                 times.append(dt)
@@ -326,13 +369,15 @@ def end_to_end(ctx, index, seed, c_full, n_cells=8192):
     fresh, fresh_best = passes(5, False)   # a new NumPy result array every pass: its first-touch page faults are in the time
     reused, reused_best = passes(7, True)  # the caller's result buffer, reused (a pipeline writing one slab after the other)
     moved = 4 * X.nbytes
+    parity = oracle_parity(X[:, :n_chk], y[:, :n_chk], Xp[:, :n_chk], gid, [checked[k][0] for k in ("fresh", "reuse")],
+                           [checked[k][1] for k in ("fresh", "reuse")])
     try:
         f32 = passes32(5)
         f32 = {"value": n_cells / f32, "seconds": f32, "note": "float32 host grids: float32 over PCIe (half the bytes), float64 arithmetic on the device"}
     except Exception as e:  # noqa: BLE001
         f32 = {"value": None, "error": str(e)}
     return {"value": n_cells / reused, "unit": "cells/s", "cells": n_cells, "seconds": reused, "best_seconds": reused_best, "float32_grids": f32,
-            "host_bytes_moved": moved, "effective_GBps": moved / reused / 1e9,
+            "parity_check": parity, "host_bytes_moved": moved, "effective_GBps": moved / reused / 1e9,
             "fresh_result_array": {"value": n_cells / fresh, "seconds": fresh, "best_seconds": fresh_best, "effective_GBps": moved / fresh / 1e9},
             "path": "sd_bcsd_fit + sd_bcsd_predict on pageable NumPy arrays (H2D of X_hist, y_obs, X_fut; D2H of the result), median of "
                     "the timed passes; value: result buffer reused across passes; fresh_result_array: np.empty per pass (first-touch "
@@ -363,6 +408,8 @@ def pointwise_end_to_end(index, seed, c_full, n_cells=8192):
         res = model.predict(Xpg)
         field = np.asarray(res.values if hasattr(res, "values") else res)
         dt = time.perf_counter() - t0
+        if it == 4:  # (outside the timed region) the first cells of the last pass, for the parity check below
+            first = np.array(field.reshape(len(index), -1)[:, :16])
         # (released outside the timed region, like `out` in end_to_end: until round 4 the rebinding of a throw-away name freed the
         # previous pass's 1 GB result *inside* it -- 42 ms of munmap per pass, profiles/r04/prof_pointwise2.log)
         del model, res, field
@@ -370,8 +417,11 @@ def pointwise_end_to_end(index, seed, c_full, n_cells=8192):
             times.append(dt)
     med = sorted(times)[len(times) // 2]
     moved = 4 * X.nbytes
+    T = len(index)
+    gid = (np.asarray(index.month) - 1).astype(np.int32)
+    parity = oracle_parity(*(np.ascontiguousarray(a.reshape(T, -1)[:, :16]) for a in (X, y, Xp)), gid, [first])
     return {"value": n_cells / med, "unit": "cells/s", "cells": n_cells, "seconds": med, "best_seconds": min(times),
-            "effective_GBps": moved / med / 1e9,
+            "parity_check": parity, "effective_GBps": moved / med / 1e9,
             "path": "PointWiseDownscaler(BcsdTemperature()).fit(X, y) + .predict(X_fut) on host GridArrays [time, 64, 128] "
                     "(estimator wrappers, validation, H2D of three fields, fitted state, D2H of the result), median of 3 timed passes"}
 
@@ -403,6 +453,7 @@ def main():
     wl = dict(WORKLOADS[config])
     if wl["kind"] == "analog":
         ANALOG.update(kind=args.analog_kind, k=args.analog_k, features=args.analog_features, estimator=args.analog_estimator)
+        os.environ["SD_BENCH_ANALOG"] = json.dumps(ANALOG)  # inherited by the --cpu-worker processes of cpu_baseline
         if not analog_is_baseline():
             F = args.analog_features
             wl["bytes_per_step"] = 8 * (F + 1 + F + 3)  # X, y, Xq read, the three output columns written
@@ -433,9 +484,10 @@ def main():
     index = synth.daily_calendar(T)
     gid = (np.asarray(index.month) - 1).astype(np.int32)
 
-    def field(kind, stream, shape=(T, C), **kw):
+    def field(kind, stream, shape=(T, C), offs=None, **kw):
         d = ctx.empty(shape)
-        ctx.synth_fill(ctx.wrap(d.ptr, (int(np.prod(shape[:-1])), shape[-1])), kind, args.seed, stream, c_offset=c_off, c_full=c_full, **kw)
+        o, f = (c_off, c_full) if offs is None else offs
+        ctx.synth_fill(ctx.wrap(d.ptr, (int(np.prod(shape[:-1])), shape[-1])), kind, args.seed, stream, c_offset=o, c_full=f, **kw)
         return d
 
     fields = {}
@@ -618,6 +670,57 @@ def main():
         return "ok" if ok else f"FAILED max_err={np.nanmax(err):.3e}"
 
     parity = baseline = numpy_1 = numpy_n = e2e = pw_e2e = c_port = None
+    rccl = None
+    if world > 1:  # what RCCL itself says it is running on (ncclCommCount: the ranks IT sees, not WORLD_SIZE)
+        if comm is not None:
+            try:
+                rccl = dict(comm.rccl_info(), world_size_env=world)
+            except Exception as e:  # noqa: BLE001
+                rccl = {"ranks": None, "error": f"{type(e).__name__}: {e}", "world_size_env": world}
+        else:
+            rccl = {"ranks": 0, "error": comm_error, "world_size_env": world}
+    if rank == 0 and world > 1 and not args.no_cpu_baseline:
+        # N > 1: rank 0's shard (cells 0 .. C-1 of the C * world grid) against the oracle, outside every timed region; the
+        # cpu_baseline legs themselves stay with the N = 1 line
+        try:
+            step()
+            ctx.synchronize()
+            _, _, _, parity, _ = cpu_baseline(wl["kind"], T, args.seed, c_full, 0.0, check_parity, parity_only=True)
+        except Exception as e:  # noqa: BLE001
+            parity = f"not run: {type(e).__name__}: {e}"
+    config5 = None
+    if world > 1 and wl.get("cells_config5") and not args.cells and wl["kind"] == "bcsd_tas":
+        # BASELINE configs[4] at its own size: 125 000 cells per GPU (1 M cells at N = 8), shards resident
+        try:
+            if rdv is not None:
+                rdv.barrier()  # (rank 0 has finished its parity check)
+            C5 = int(wl["cells_config5"])
+            for d in list(fields.values()) + [out]:
+                d.free()
+            ctx.release_cached()
+            tabs = synth.tas_tables(index)
+            f5 = {name: field(synth.GAUSS, tabs[name]["stream"], shape=(T, C5), offs=(C5 * rank, C5 * world), base=tabs[name]["base"],
+                              amp=tabs[name]["amp"], cell_scale=tabs[name]["cell_scale"]) for name in ("X_hist", "y_obs", "X_fut")}
+            out5 = ctx.empty((T, C5))
+            fields, out = f5, out5  # (released with the rest below)
+
+            def step5():
+                ctx.bcsd_fit_predict(_lib.BCSD_TAS, f5["X_hist"], f5["y_obs"], gid, 12, f5["X_fut"], gid, True, out=out5)
+
+            n5 = max(1, min(args.steps, 20))
+            for _ in range(2):
+                step5()
+            barrier()
+            t5 = time.perf_counter()
+            for _ in range(n5):
+                step5()
+            barrier()
+            dt5 = rdv.allreduce_max(time.perf_counter() - t5)
+            config5 = {"value": C5 * world * n5 / dt5, "unit": "cells/s", "cells_per_gpu": C5, "total_cells": C5 * world, "steps": n5,
+                       "ms_per_step": dt5 * 1e3 / n5, "workload": "BASELINE configs[4]: BcsdTemperature, 125 000 cells per GPU "
+                       f"({C5 * world} cells over {world} GPUs; 1 M at N = 8), shards resident"}
+        except Exception as e:  # noqa: BLE001
+            config5 = {"value": None, "error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             step()  # `out` holds the full-grid result again
@@ -698,6 +801,8 @@ def main():
     if gather is not None:
         line.update(gather)
     if world > 1:
+        line["rccl"] = rccl
+        line["baseline_config5"] = config5
         line["scaling_claim"] = ("north_star's '>= 7x at 8 GPUs vs 1' is claimed on `value`: fit + predict of every rank's shard with the "
                                  "predicted shards left resident on their GPUs (how a regridder or chunked writer consumes them); "
                                  "`value_with_gather` (all shards into rank 0's HBM over xGMI, bound by the root's 7 links) and "

@@ -299,6 +299,8 @@ int sd_comm_unique_id(char* id /* [SD_COMM_ID_BYTES] */);
 int sd_comm_create(sd_ctx* ctx, const char* id /* [SD_COMM_ID_BYTES] */, int rank, int world, sd_comm** out);
 int sd_comm_destroy(sd_comm* comm);
 int sd_comm_info(const sd_comm* comm, int* rank, int* world);
+/* what RCCL reports about the communicator: ncclGetVersion's code, ncclCommCount (the ranks RCCL sees) and its device */
+int sd_comm_rccl_info(const sd_comm* comm, int* version, int* ranks, int* device);
 int sd_comm_barrier(sd_comm* comm);
 int sd_comm_allreduce_max(sd_comm* comm, double value, double* result);
 int sd_comm_gather_field(sd_comm* comm, const double* local_dev, int64_t T, const int64_t* cells /* [world] */,

@@ -47,8 +47,9 @@ static int* tl_workspace(int need) {
     return tl_ints;
 }
 static inline int bucket_of(const bucket_index* bi, double v) {
-    const int b = (int)((v - bi->lo) * bi->sc);
-    return b < bi->nb - 1 ? b : bi->nb - 1;
+    const double x = (v - bi->lo) * bi->sc; /* compared as a double: an overflowing or NaN product never reaches the cast */
+    if (!(x > 0.0)) return 0;
+    return x < (double)(bi->nb - 1) ? (int)x : bi->nb - 1;
 }
 static void sort_doubles_idx(double* a, int n, double* tmp, bucket_index* bi) {
     int nb = 64;
@@ -63,6 +64,7 @@ static void sort_doubles_idx(double* a, int n, double* tmp, bucket_index* bi) {
     bi->nb = nb;
     bi->lo = lo;
     bi->sc = hi > lo ? (double)(nb - 1) / (hi - lo) : 0.0;
+    if (!(bi->sc <= 1.7e308)) bi->sc = 0.0; /* a denormal range overflows the quotient: one bucket, the insertion pass sorts it */
     bi->start = start;
     memset(start, 0, sizeof(int) * (size_t)(nb + 1));
     for (int i = 0; i < n; ++i) {

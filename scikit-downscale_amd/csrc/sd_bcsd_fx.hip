@@ -839,6 +839,526 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
 #undef SD_LANE
 }
 
+// ---- round 6: the tiles land by LDS-DMA, time-major ------------------------------------------------------------------------
+// bcsd_fd_kernel<K>: the whole-lane BcsdTemperature fit + predict pass of bcsd_fx_kernel<K, true, true> (same reference
+// semantics, bcsd.py:197-269, quantile.py:81-147, 438-545; same keys, sort and work list) with a different life of the tile:
+//
+//   landing   global_load_lds_dwordx4: one wave instruction fetches 16 rows x 64 B (the 8 cells of the tile) and the hardware
+//             writes them lane-linear into LDS -- a 1 KB chunk of a TIME-MAJOR tile [t][8 cells].  No tile registers, no
+//             ds_write pass, and a request in flight owns no VGPR: half of the y tile is requested BEFORE the sort of u and
+//             lands while the wave sorts (the old kernel could not afford the 40 registers).  The base of every
+//             chunk is skewed by 16 B (chunk stride 1 040 B): a wave reads a COLUMN of the tile (its cell; lane l owns rows
+//             K l .. K l + K - 1), and without the skew the lane stride K x 64 B would put every lane on the same bank.
+//   u side    the shifted series is not written back as float64: the key generation (one v_add_f64 with 2^21: q and 31
+//             further bits of the fixed-point quotient come out of the mantissa) leaves a 32-bit SECOND-LEVEL key u2 per
+//             sample, stored cell-major in the first 39 KB of the tile once every wave has read its windows; the fix-up of
+//             equal-q neighbours compares u2 (equal u2 = equal or indistinguishable values: work list).  The rest of the
+//             tile is free during the sort of u: that is where the early half of the y tile lands.
+//   y side    the late half of y is requested behind the vote barrier (the u2 area is dead then); column reads, keys, sort,
+//             fix-up on the float64 observations by tag, gather, scatter to the tags of u, shift restored in place.
+//   output    the tile is already time-major: ds_read_b128 of a chunk, lane-linear, and 64-byte row fragments to memory.
+//
+// Row indices of the requests: loaded once per order table into registers (element 16 k + i of a wave's chunk list in register
+// (16 k + i) / 64, lane (16 k + i) % 64) and fetched per request by ds_bpermute -- an ordinary global load between two requests
+// would make the compiler wait for vmcnt(0), i.e. for the DMA queue.  The requests themselves are inline assembly for the same
+// reason: the compiler treats a pending __builtin_amdgcn_global_load_lds as an LDS write and puts s_waitcnt vmcnt(0) in front of
+// every DS instruction -- the ds_swizzle / ds_bpermute partner fetches of the sort included.  Waits are counted by hand.
+namespace tmj {
+constexpr int kChunkRows = 16, kChunkStride = 1024 + 16;
+__host__ __device__ constexpr int chunks_of(int n) { return (n + kChunkRows - 1) / kChunkRows; }
+__device__ __forceinline__ unsigned row_off(unsigned j) { return (j << 6) + ((j >> 4) << 4); }  // row j of the tile, cell 0
+
+template <int NREG>
+struct RowIdx {
+    int v[NREG];
+};
+// rows of the chunks q0 + wave + 8 k, k = 0 .. 4 NREG - 1
+template <int NREG>
+__device__ __forceinline__ RowIdx<NREG> rows_of_wave(const int32_t* __restrict__ ord, int n, int q0, int wave, int lane) {
+    RowIdx<NREG> t;
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) {
+        const int e = 64 * j + lane;
+        const int r = kChunkRows * (q0 + wave + kW * (e >> 4)) + (e & 15);
+        t.v[j] = ord[r < n ? r : n - 1];
+    }
+    return t;
+}
+// The indices are "used" here, so the compiler's wait for their loads sits here -- ahead of the requests -- and not between
+// them, where it would count only its own loads and drain the DMA queue with them.
+template <int NREG>
+__device__ __forceinline__ void rows_ready(RowIdx<NREG>& t) {
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) asm volatile("" : "+v"(t.v[j]));
+}
+template <int NREG>
+__device__ __forceinline__ int row_of_request(const RowIdx<NREG>& rows, int k, int lane) {
+    return __builtin_amdgcn_ds_bpermute(4 * (16 * (k & 3) + (lane >> 2)), rows.v[k >> 2]);
+}
+// requests for the chunks q = q0 + wave + 8 k < q1 of a tile (NK = requests per wave at most)
+template <int NK, int NREG>
+__device__ __forceinline__ void dma_chunks(const double* __restrict__ src, int64_t ld, const RowIdx<NREG>& rows, int q0, int q1,
+                                           int64_t c0, unsigned tile_b, int wave, int lane) {
+    static_assert(NK <= 4 * NREG, "row registers");
+    const char* colp = reinterpret_cast<const char*>(src + c0) + 16 * (lane & 3);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int q = q0 + wave + kW * k;
+        if (q < q1) {  // (wave-uniform)
+            const int ti = row_of_request(rows, k, lane);
+            const char* g = colp + (uint64_t)(uint32_t)ti * (uint64_t)(uint32_t)((uint32_t)ld * 8u);
+            const int dst = __builtin_amdgcn_readfirstlane((int)(tile_b + (unsigned)q * (unsigned)kChunkStride));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(g), "s"(dst)
+                         : "memory");
+        }
+    }
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Column access of lane block bl (rows K bl + idx, idx = -4 .. K + 3) of the wave's cell: K bl = 16 chunk0 + 4 p4, so row
+// K bl + idx sits (p4 + floor(idx / 4)) / 4 chunks further on -- one base per zone of four rows (two instructions, shared by the
+// zone's reads), immediate offsets inside.  fresh() hides p4 from the optimiser: the zone bases are rebuilt where they are
+// needed instead of living in seven registers across the phases.
+template <int K>
+struct ColBase {
+    unsigned base2;
+    int p4;
+    // address of the first row of zone z (rows 4 z .. 4 z + 3 of the block, z = -1 .. K / 4): the rows of a zone follow at the
+    // immediate offsets 0, 64, 128, 192
+    __device__ __forceinline__ unsigned zone(int z) const {
+        return base2 + (unsigned)(16 * ((p4 + z) >> 2) + 256 * z);  // (arithmetic shift: zone -1 of p4 = 0 lies one chunk back)
+    }
+    __device__ __forceinline__ unsigned at(int idx) const {  // idx: compile-time after unrolling
+        const int z = (idx + 4) / 4 - 1;                      // floor(idx / 4) for idx >= -4
+        return zone(z) + (unsigned)(64 * (idx - 4 * z));
+    }
+    // the value at row idx: pointer arithmetic on the zone's address (an in-bounds element offset becomes the DS instruction's
+    // immediate; an unsigned sum does not -- it may wrap)
+    __device__ __forceinline__ double get(int idx) const {
+        const int z = (idx + 4) / 4 - 1;
+        return reinterpret_cast<lds_cdouble_t*>((uintptr_t)zone(z))[8 * (idx - 4 * z)];
+    }
+    __device__ __forceinline__ void put(int idx, double x) const {
+        const int z = (idx + 4) / 4 - 1;
+        reinterpret_cast<lds_double_t*>((uintptr_t)zone(z))[8 * (idx - 4 * z)] = x;
+    }
+    __device__ __forceinline__ void fresh() { asm volatile("" : "+v"(p4)); }
+};
+template <int K>
+__device__ __forceinline__ ColBase<K> col_base(unsigned tile_b, int col, int bl) {
+    static_assert(K % 4 == 0, "lane blocks start on multiples of four rows");
+    const int a = K * bl;
+    ColBase<K> c;
+    c.p4 = (a & 15) >> 2;
+    c.base2 = tile_b + 8u * (unsigned)col + (unsigned)(a >> 4) * (unsigned)kChunkStride + (unsigned)((a & 15) * 64);
+    return c;
+}
+
+// keys + second-level keys of the shifted series: t = (v - lo) * sc + 1 in [1, kQD - 1]; t + 2^21 has the exponent of 2^21, so its
+// mantissa is t in units of 2^-31: 21 bits of q above 31 further bits.  Monotone in v (fma, add: correctly rounded).
+// key = (q << 11) | sample index; u2 = the low mantissa word (bit 31 = the lowest bit of q: equal wherever q is).
+template <int K, class GetU>
+__device__ __forceinline__ void keys_u2(const GetU& u_of, double lo, double hi, int m, int lane, unsigned (&key)[K], unsigned (&u2)[K]) {
+    const double sc = (double)(kQD - 2u) / (hi - lo);  // +inf when every sample is equal: t = NaN everywhere, all keys and u2 tie
+    const double off = -lo * sc + 1.0;
+    const unsigned tag0 = (unsigned)(K * lane);
+    const unsigned pad0 = ((kQD + 1u + tag0) << kTagBits) | tag0;
+    const bool lane_in = K * lane < m;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const double t = __builtin_fma(u_of(i), sc, off) + 2097152.0;
+        const unsigned w0 = (unsigned)__double2loint(t), w1 = (unsigned)__double2hiint(t);
+        unsigned q = __builtin_amdgcn_alignbit(w1, w0, 31) & 0x1fffffu;
+        q = q < kQD ? q : kQD;
+        const unsigned dk = (q << kTagBits) | (tag0 + (unsigned)i);
+        const unsigned pk = pad0 + (unsigned)i * ((1u << kTagBits) + 1u);
+        key[i] = lane_in ? dk : pk;
+        u2[i] = w0;
+    }
+}
+
+// exact order inside runs of equal q (see fix_equal_q): the values behind two tags are fetched and compared by `cmp`
+// (tag_a, tag_b, &greater, &equal)
+template <int K, class Cmp>
+__device__ __forceinline__ int fix_equal_q_by(unsigned (&k)[K], int lane, const Cmp& cmp) {
+    constexpr unsigned kQ = 1u << kTagBits;
+    bool tie = false;
+#pragma unroll 1
+    for (int pass = 0; pass < 6; ++pass) {
+        bool swapped = false;
+        const unsigned knext = from_next_lane(k[0], 0xffffffffu);
+        const bool eqx = (k[K - 1] ^ knext) < kQ;
+        const unsigned long long bx = __ballot(eqx);
+        if (bx != 0ull) {  // wave-uniform, rare
+            bool gt, eq;
+            cmp(k[K - 1] & kTagMask, knext & kTagMask, &gt, &eq);
+            const bool sw = eqx && gt;
+            tie |= eqx && eq;
+            const unsigned d = sw ? (k[K - 1] ^ knext) : 0u;
+            k[K - 1] ^= d;
+            k[0] ^= from_prev_lane(d, 0u);
+            swapped |= sw;
+        }
+        unsigned long long prev = 0ull, b0 = 0ull, multi = 0ull;
+#pragma unroll
+        for (int i = 0; i + 1 < K; ++i) {
+            const bool e = (k[i] ^ k[i + 1]) < kQ;
+            const unsigned long long b = __ballot(e);
+            multi |= b & prev;
+            if (i == 0) b0 = b;
+            prev = b;
+            if (b != 0ull) {
+                bool gt, eq;
+                cmp(k[i] & kTagMask, k[i + 1] & kTagMask, &gt, &eq);
+                const bool sw = e && gt;
+                tie |= e && eq;
+                const unsigned d = sw ? (k[i] ^ k[i + 1]) : 0u;
+                k[i] ^= d;
+                k[i + 1] ^= d;
+                swapped |= sw;
+            }
+        }
+        multi |= (bx & prev) | ((bx << 1) & b0);
+        if (multi == 0ull || !__any(swapped)) return __any(tie) ? kTie : 0;
+    }
+    return kUnsorted;
+}
+}  // namespace tmj
+
+// LDS of a workgroup: [head: kHeadDoubles][tile: chunks_of(nmax) x 1 040 B]; the u2 area (8 cells x RSU 32-bit words) overlays
+// the first chunks of the tile
+__host__ __device__ constexpr int fd_u2_stride(int nmax) { return (nmax + 3) / 4 * 4; }
+__host__ __device__ constexpr int fd_late_chunks(int nmax) { return (kW * 4 * fd_u2_stride(nmax) + tmj::kChunkStride - 1) / tmj::kChunkStride; }
+inline size_t fd_lds_bytes(int nmax) { return (size_t)kHeadDoubles * sizeof(double) + (size_t)tmj::chunks_of(nmax) * tmj::kChunkStride; }
+
+template <int K>
+__global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int NR = K / 2;
+    constexpr int CH = K >= 20 ? K / 4 : K >= 14 ? K / 2 : K;
+    constexpr int NKX = 10;  // requests per wave and tile at most: 80 chunks = 1 280 rows
+    static_assert(K % 4 == 0 && K % CH == 0 && 64 * K <= 1280, "tile of at most 80 chunks");
+#ifdef SD_DEV
+    const int abl = p->dev_flags;
+#else
+    constexpr int abl = 0;
+#endif
+    double* const scratch = reinterpret_cast<double*>(smem_raw);
+    int* const bad_cell = reinterpret_cast<int*>(scratch + 64 + 16);
+    int* const redo_flag = bad_cell + kW;
+    const unsigned tile_b = lds_addr(smem_raw) + (unsigned)(kHeadDoubles * sizeof(double));
+    if (threadIdx.x >= 32 && threadIdx.x < 32 + kW) bad_cell[threadIdx.x - 32] = 0;
+#ifdef SD_DEV
+    const bool traced = (abl & 0x800) != 0 && blockIdx.x % kTraceStride == 7 && blockIdx.x / kTraceStride < (unsigned)kTraceWgs;
+    long long tstamp[kTraceSlots] = {};
+    SDT(0);
+#endif
+    int64_t tile_id;
+    int g;
+    xcd_tile_of_block(blockIdx.x, p->ntiles, &tile_id, &g);
+    if (p->gmask != 0ull) g = nth_set_bit(p->gmask, g);
+    if (tile_id >= p->ntiles || g < 0 || g >= p->G) return;
+
+    const int64_t c0 = tile_id * kW;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_now() / kWave);
+#define SD_LANE() const int lane = tid_now() % kWave
+    const int64_t c = c0 + wave;
+    const bool cell_ok = c < p->C;
+    const int begf = p->off_f[g];
+    const int m = p->off_f[g + 1] - begf;  // == the predict segment's length (whole-lane groups of equal length)
+    const int begp = p->off_p[g];
+    if (m == 0) return;
+    const int nch = tmj::chunks_of(m);
+    const int RSU = p->RS;                    // 32-bit words per cell of the u2 area
+    const int nlate = fd_late_chunks(RSU) < nch ? fd_late_chunks(RSU) : nch;  // chunks under the u2 area: the late half of y
+    const bool cell_live = cell_ok && p->status_fit[cell_ok ? c : 0] == 0;
+    // a tile whose last cells lie past the grid (C is even: pairs of cells are whole) fetches its last whole pair instead
+    const int64_t cfetch = c0 + kW <= p->C ? c0 : p->C - kW;  // (C >= 8: the launcher's condition)
+    const int cshift = (int)(c0 - cfetch);                     // cells the fetched tile is shifted by: wave w's cell sits in column w + cshift
+    const int col = wave + cshift < kW ? wave + cshift : wave + cshift - kW;  // (waves past the grid get the columns in front: cells of the previous tile, nothing of them is kept)
+    __syncthreads();  // bad_cell zeroed before the checks below may set it
+
+    // ---- x climatology (bcsd.py:222) from registers; the x_fut tile by DMA ------------------------------------------------
+    SDPH("x_tiles");
+    double xc = 0.0;
+    tmj::RowIdx<2> ry_late, ry_early;
+    {
+        SD_LANE();
+        tmj::RowIdx<3> rp = tmj::rows_of_wave<3>(p->ord_p + begp, m, 0, wave, lane);  // (in one batch with the rows of the x_hist tile)
+        TileRegs<NR> xh;
+        int tf[NR];
+        rows_load<NR, true>(p->ord_f + begf, m, tf);
+        // the DMA requests first, the register loads of x_hist behind them (the compiler's waits for the latter then cover both;
+        // in the other order it drains its own loads before the first request goes out)
+        tmj::rows_ready(rp);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) asm volatile("" : "+v"(tf[k]));  // (likewise: the wait for these sits ahead of the requests)
+        if (!(abl & 64)) tmj::dma_chunks<NKX, 3>(p->Xp, p->ld_p, rp, 0, nch, cfetch, tile_b, wave, lane);
+        if (!(abl & 4)) {
+            // (tile_issue_ti without its scalar branch for cells at an odd boundary: the launcher admits whole pairs only, a pair
+            // past the grid re-reads the tile's first one -- its sums belong to no cell.  The sibling branch's un-waited loads would
+            // make the compiler drain vmcnt -- the DMA queue -- on the way into this one.)
+            const int cp = lane & 3;
+            const double* src = p->X + (c0 + 2 * cp + 1 < p->C ? c0 + 2 * cp : c0);
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const double2 v = *reinterpret_cast<const double2*>(row_of(src, tf[k], p->ld));
+                xh.v0[k] = v.x;
+                xh.v1[k] = v.y;
+            }
+        }
+        if (!(abl & 4)) tile_reduce_partials<NR, true>(xh, m, c0, p->C, scratch, p->status_fit, wave, lane, bad_cell);
+        SDT(1);  // x_hist summed, x_fut requested
+        tmj::dma_wait_all();
+    }
+    __syncthreads();
+    SDT(2);  // x_fut tile landed
+    {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < kW; ++w) tot += scratch[w * kW + wave];
+        xc = tot / (double)m;
+    }
+
+    // ---- shift (kept), second-level keys -> u2 area, keys -> sort ---------------------------------------------------------
+    SDPH("rolling");
+    double shift[K];
+    unsigned ku[K];
+    bool redo = false;
+    {
+        SD_LANE();
+        const bool has = K * lane < m;
+        const int bl = has ? lane : 0;
+        const bool first_lane = bl == 0, last_lane = K * (bl + 1) == m;
+        tmj::ColBase<K> cz = tmj::col_base<K>(tile_b, col, bl);
+        // (the shifted samples themselves are not kept -- 40 registers beside the 40 of the shifts --: their extremes are taken
+        // here, the key generation below re-reads the samples from the column and subtracts the kept shifts again)
+        double ulo = __builtin_inf(), uhi = -__builtin_inf();
+        bool bad = false;
+#pragma unroll
+        for (int cbeg = 0; cbeg < K; cbeg += CH) {
+            double w[CH + 8];
+            cz.fresh();
+#pragma unroll
+            for (int t = 0; t < CH + 8; ++t) {
+                const int idx = cbeg - 4 + t;  // row K * bl + idx of the cell's column
+                // (every lane reads, also where the row lies before or behind the segment -- the head of the LDS block, the rest
+                // of the last chunk or nothing at all: an LDS read past the allocation returns 0 -- and drops the value: a select
+                // on the address made the compiler wrap every such read in a divergent branch)
+                const double x = cz.get(idx);
+                w[t] = idx < 0 ? (first_lane ? 0.0 : x) : idx >= K ? (last_lane ? 0.0 : x) : x;
+            }
+#pragma unroll
+            for (int ii = 0; ii < CH; ++ii) {
+                double s = 0.0;  // the nine samples in time order, like the oracle and every other path
+#pragma unroll
+                for (int d = 0; d < 9; ++d) s += w[ii + d];
+                const int i = cbeg + ii;
+                constexpr double kRc[10] = {0.0, 1.0, 0.5, 1.0 / 3.0, 0.25, 0.2, 1.0 / 6.0, 1.0 / 7.0, 0.125, 1.0 / 9.0};
+                double cd = 9.0, rc = kRc[9];
+                if (i < 4) {
+                    cd = first_lane ? (double)(5 + i) : cd;
+                    rc = first_lane ? kRc[5 + i] : rc;
+                }
+                if (i >= K - 4) {
+                    cd = last_lane ? (double)(K + 4 - i) : cd;
+                    rc = last_lane ? kRc[K + 4 - i] : rc;
+                }
+                const double q = s * rc;
+                const double mean = __builtin_fma(__builtin_fma(-cd, q, s), rc, q);  // correctly rounded s / count
+                const double sh = mean - xc;                                           // bcsd.py:253
+                shift[i] = sh;
+                bad |= nonfinite64(w[ii + 4]);
+                const double ui = (w[ii + 4] - sh) + 0.0;  // bcsd.py:256; -0.0 -> +0.0
+                ulo = vmin(ulo, ui);
+                uhi = vmax(uhi, ui);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (__any(bad && has)) {  // (the x_fut tile is validated by the wave that owns the cell: bcsd.py:244)
+            if (lane == 0) {
+                if (cell_ok) atomicOr(&p->status_p[c], SDI_NONFINITE);
+                bad_cell[wave] = 1;
+            }
+        }
+        SDT(3);  // rolling mean
+        // the rows of the y requests (the loads return under the key generation)
+        ry_late = tmj::rows_of_wave<2>(p->ord_f + begf, m, 0, wave, lane);
+        ry_early = tmj::rows_of_wave<2>(p->ord_f + begf, m, nlate, wave, lane);
+        SDPH("u_keys");
+        unsigned u2[K];
+        {
+            ulo = wave_min_f64(ulo);
+            uhi = wave_max_f64(uhi);
+            cz.fresh();
+            const auto u_of = [&](int i) { return (cz.get(i) - shift[i]) + 0.0; };
+            tmj::keys_u2<K>(u_of, ulo, uhi, m, lane, ku, u2);
+        }
+        // every wave has read its column for the last time: the tile is dead, the y requests and the u2 area may overwrite it
+        tmj::rows_ready(ry_early);
+        tmj::rows_ready(ry_late);
+        __syncthreads();
+        if (!(abl & 32)) tmj::dma_chunks<5, 2>(p->y, p->ld, ry_early, nlate, nch, cfetch, tile_b, wave, lane);
+        const unsigned ub = tile_b + 4u * (unsigned)(col * RSU);
+        if (has) {
+#pragma unroll
+            for (int i = 0; i < K; i += 4) {
+                typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+                *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((uintptr_t)(ub + 4u * (unsigned)(K * lane + i))) =
+                    u32x4{u2[i], u2[i + 1], u2[i + 2], u2[i + 3]};
+            }
+        }
+        wave_fence();
+        SDT(4);  // u2 stored, keys
+        SDPH("u_sort");
+        if (!(abl & 1)) sdws::wave_sort<K>(ku, lane, (m + K - 1) / K);
+        SDT(5);  // sort of u
+        SDPH("u_fix");
+        const auto cmp_u2 = [ub](unsigned ta, unsigned tb, bool* gt, bool* eq) {
+            const unsigned a = lds_u32(ub + 4u * ta), b = lds_u32(ub + 4u * tb);
+            *gt = a > b;
+            *eq = a == b;
+        };
+        const bool tie = (abl & 8) ? false : tmj::fix_equal_q_by<K>(ku, lane, cmp_u2) != 0;
+        redo = tie && cell_live && bad_cell[wave] == 0 && (abl & 0x7ff) == 0;  // wave-uniform
+        SDT(6);  // fix-up of u
+    }
+    SDPH("vote");
+    redo_flag[wave] = redo ? 1 : 0;
+    __syncthreads();
+    int any_redo = 0;
+#pragma unroll
+    for (int w = 0; w < kW; ++w) any_redo |= redo_flag[w];
+    if (any_redo) {
+        tmj::dma_wait_all();  // (no request of this workgroup may land in the LDS of its successor)
+        if (threadIdx.x == 0) {
+            const int slot = atomicAdd(p->work_count, 1);
+            if (slot < p->work_cap) p->worklist[slot] = tile_id * p->G + g;
+        }
+        return;
+    }
+    SDT(7);  // vote
+
+    // ---- y: the late half of the tile, climatology, sorted observations ---------------------------------------------------
+    SDPH("y_tile");
+    double yc = 0.0;
+    double t[K];
+    bool redo_y = false;
+    {
+        SD_LANE();
+        if (!(abl & 32)) tmj::dma_chunks<5, 2>(p->y, p->ld, ry_late, 0, nlate, cfetch, tile_b, wave, lane);
+        SDT(8);  // late half requested
+        tmj::dma_wait_all();
+        __syncthreads();
+        SDT(9);  // y tile landed
+        SDPH("y_keys");
+        const bool has = K * lane < m;
+        const int bl = has ? lane : 0;
+        tmj::ColBase<K> cz = tmj::col_base<K>(tile_b, col, bl);
+        const unsigned colb = tile_b + 8u * (unsigned)col;
+        unsigned ky[K];
+        {
+            double v[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) v[i] = cz.get(i);
+            double s = 0.0;
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                s += v[i];
+                bad |= nonfinite64(v[i]);
+            }
+            s = has ? s : 0.0;
+            yc = wave_sum_f64(s) / (double)m;  // bcsd.py:223
+            if (__any(bad && has) && lane == 0 && cell_ok) atomicOr(&p->status_fit[c], SDI_NONFINITE);
+            make_keys_impl<K, false, true, true>(v, m, lane, ky);  // tags = sample indices
+        }
+        SDT(10);  // y_climo, keys
+        SDPH("y_sort");
+        if (!(abl & 2)) sdws::wave_sort<K>(ky, lane, (m + K - 1) / K);
+        SDT(11);  // sort of y
+        SDPH("y_fix");
+        const auto cmp_y = [colb](unsigned ta, unsigned tb, bool* gt, bool* eq) {
+            const double a = lds_f64(colb + tmj::row_off(ta)), b = lds_f64(colb + tmj::row_off(tb));
+            *gt = a > b;
+            *eq = a == b;
+        };
+        if (!(abl & 8)) redo_y = (tmj::fix_equal_q_by<K>(ky, lane, cmp_y) & kUnsorted) != 0 && cell_live;  // tied observations are interchangeable
+        SDPH("y_gather");
+        {
+            const unsigned tm = has ? kTagMask : 0u;  // (pad keys carry indices past the segment: those lanes read row 0)
+#pragma unroll
+            for (int i = 0; i < K; ++i) t[i] = lds_f64(colb + tmj::row_off(ky[i] & tm));
+        }
+        SDT(12);  // fix-up of y, sorted observations gathered
+        // ---- identity map (equal group lengths): rank r of u takes the r-th smallest observation; scatter to the time slots ----
+        SDPH("map_scatter");
+        wave_fence();  // every lane has read what it needs of the column
+        if (has) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) lds_store_f64(colb + tmj::row_off(ku[i] & kTagMask), t[i]);
+        }
+        wave_fence();
+        SDPH("restore");
+        cz.fresh();
+        double q[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) q[i] = cz.get(i);
+        const double ycr = p->return_anoms ? yc : 0.0;  // bcsd.py:266-267
+        if (has) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) cz.put(i, (shift[i] + q[i]) - ycr);  // bcsd.py:253, 263
+        }
+    }
+    SDPH("store");
+    SDT(13);  // scatter, shift restored
+    redo_flag[wave] = redo_y ? 1 : 0;
+    tmj::RowIdx<3> ro = tmj::rows_of_wave<3>(p->ord_p + begp, m, 0, wave, tid_now() % kWave);  // (named ahead of the last barrier)
+    __syncthreads();
+    tmj::rows_ready(ro);
+    SDT(14);  // last barrier
+    any_redo = 0;
+#pragma unroll
+    for (int w = 0; w < kW; ++w) any_redo |= redo_flag[w];
+    if (any_redo) {  // nothing has been written yet
+        if (threadIdx.x == 0) {
+            const int slot = atomicAdd(p->work_count, 1);
+            if (slot < p->work_cap) p->worklist[slot] = tile_id * p->G + g;
+        }
+        return;
+    }
+    if (!(abl & 16)) {
+        SD_LANE();
+        // the tile is time-major already: a chunk is read lane-linear and leaves as 16 row fragments of 64 bytes
+        const int pair = 2 * (lane & 3);                     // cells pair, pair + 1 of the fetched tile
+        const bool keep = pair >= cshift;                    // (a tile shifted back over its predecessor stores its own cells only)
+        char* colp = reinterpret_cast<char*>(p->out + cfetch) + 16 * (lane & 3);
+#pragma unroll
+        for (int k = 0; k < NKX; ++k) {
+            const int qc = wave + kW * k;
+            const int r = tmj::kChunkRows * qc + (lane >> 2);
+            const int ti = tmj::row_of_request(ro, k, lane);
+            if (qc < nch && r < m && keep) {
+                typedef double __attribute__((ext_vector_type(2))) f64x2;
+                const f64x2 v = *reinterpret_cast<__attribute__((address_space(3))) const f64x2*>((uintptr_t)(tile_b + (unsigned)qc * (unsigned)tmj::kChunkStride + 16u * (unsigned)lane));
+                *reinterpret_cast<f64x2*>(colp + (uint64_t)(uint32_t)ti * (uint64_t)(uint32_t)((uint32_t)p->ld_out * 8u)) = v;
+            }
+        }
+    }
+#ifdef SD_DEV
+    SDT(15);  // stores issued
+    if (traced && threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < kTraceSlots; ++i) sd_fx_trace[(blockIdx.x / kTraceStride) * kTraceSlots + i] = tstamp[i];
+    }
+#endif
+#undef SD_LANE
+}
+
 // ---- BcsdPrecipitation (bcsd.py:115-185) --------------------------------------------------------------------------
 // The same pass without a climate-trend shift: x_hist is only validated (bcsd.py:130-147), the raw x_fut series is ranked
 // (bcsd.py:167), the result is the mapped value over y_climo (ratio anomalies, bcsd.py:170-185).  Zero-inflated series: the
@@ -1162,6 +1682,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fxc_kernel(const Params) {
     const int n = p->off_f[g + 1] - begf;  // == m (equal group lengths)
     const int begp = p->off_p[g];
     const int m = n;
+    if (m == 0) return;  // an empty group (workgroup-uniform, like bcsd_fx_kernel / fxp_segment): its order-table entries belong to the next group
     const bool vec_f = (p->ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->y) & 15) == 0) &&
                        (p->X == nullptr || (reinterpret_cast<uintptr_t>(p->X) & 15) == 0);
     const bool vec_p = (p->ld_p % 2 == 0) && ((reinterpret_cast<uintptr_t>(p->Xp) & 15) == 0);
@@ -1464,6 +1985,31 @@ int launch_ki(sd_ctx* ctx, Params p, int nmax, const int* group_len) {
         }
     }
 #endif
+    if constexpr (IDENT && K == 20) {
+        // Round 6: the whole-lane months of BcsdTemperature fit + predict take the kernel whose tiles land by LDS-DMA
+        // (bcsd_fd_kernel) when the fields allow 16-byte requests of whole cell pairs and two workgroups still fit a CU
+        int nfull = 0;
+        for (int g = 0; g < p.G && group_len != nullptr && p.G <= 64; ++g)
+            if ((full >> g) & 1ull) nfull = group_len[g] > nfull ? group_len[g] : nfull;
+        const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        const size_t lds_fd = fd_lds_bytes(nfull);
+        const bool ok = full != 0ull && p.kind == SD_BCSD_TAS && !p.from_state && p.X != nullptr && p.C >= kW && p.C % 2 == 0 && p.ld % 2 == 0 &&
+                        p.ld_p % 2 == 0 && p.ld_out % 2 == 0 && al16(p.X) && al16(p.y) && al16(p.Xp) && al16(p.out) && 2 * lds_fd <= ctx->lds_max &&
+                        tmj::chunks_of(nfull) - fd_late_chunks(nfull) <= 40 && fd_late_chunks(nfull) <= 40 && sd_dev_env("SD_FX_NODMA") == nullptr;
+        if (ok) {
+            Params q = p;
+            q.gmask = full;
+            q.RS = fd_u2_stride(nfull);
+            const int64_t nb = 8 * ((p.ntiles + 7) / 8) * __builtin_popcountll(full);
+            SD_CHECK_ARG(nb < ((int64_t)1 << 31), "grid too large");
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fd_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fd));
+            SD_LAUNCH(ctx, "bcsd_fd_kernel", (bcsd_fd_kernel<K>), dim3((unsigned)nb), dim3(kThreads), lds_fd, q);
+            if (rest == 0ull) return SD_OK;
+            q = p;
+            q.gmask = rest;
+            return launch_one<K, IDENT, false>(ctx, q, lds);
+        }
+    }
     if (IDENT && full != 0ull) {
         Params q = p;
         q.gmask = full;

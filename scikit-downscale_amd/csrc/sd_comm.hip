@@ -30,6 +30,9 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;             // optional: what the line of an N > 1 run reports about its transport
+    int (*CommCount)(const ncclComm_t, int*) = nullptr;
+    int (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
 };
 
 Rccl g_rccl;
@@ -58,6 +61,9 @@ int load_rccl() {
     SD_SYM(GroupEnd, "ncclGroupEnd");
     SD_SYM(GetErrorString, "ncclGetErrorString");
 #undef SD_SYM
+    *reinterpret_cast<void**>(&g_rccl.GetVersion) = dlsym(h, "ncclGetVersion");
+    *reinterpret_cast<void**>(&g_rccl.CommCount) = dlsym(h, "ncclCommCount");
+    *reinterpret_cast<void**>(&g_rccl.CommCuDevice) = dlsym(h, "ncclCommCuDevice");
     g_rccl.handle = h;
     return SD_OK;
 }
@@ -135,6 +141,20 @@ int sd_comm_info(const sd_comm* c, int* rank, int* world) {
     SD_CHECK_ARG(c, "sd_comm_info: NULL argument");
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
+    return SD_OK;
+}
+
+// What RCCL itself says about the communicator: its version code, the number of ranks IT counts (ncclCommCount -- not the
+// world the caller passed in) and the device it is bound to; -1 where the loaded library lacks the query.
+int sd_comm_rccl_info(const sd_comm* c, int* version, int* ranks, int* device) {
+    SD_CHECK_ARG(c && c->comm, "sd_comm_rccl_info: NULL argument");
+    int v = -1, n = -1, d = -1;
+    if (g_rccl.GetVersion) SD_NCCL(g_rccl.GetVersion(&v));
+    if (g_rccl.CommCount) SD_NCCL(g_rccl.CommCount(c->comm, &n));
+    if (g_rccl.CommCuDevice) SD_NCCL(g_rccl.CommCuDevice(c->comm, &d));
+    if (version) *version = v;
+    if (ranks) *ranks = n;
+    if (device) *device = d;
     return SD_OK;
 }
 

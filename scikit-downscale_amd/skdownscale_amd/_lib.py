@@ -102,6 +102,7 @@ SIGNATURES = {
     "sd_comm_create": [_p, _p, _int, _int, C.POINTER(_p)],
     "sd_comm_destroy": [_p],
     "sd_comm_info": [_p, C.POINTER(_int), C.POINTER(_int)],
+    "sd_comm_rccl_info": [_p, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)],
     "sd_comm_barrier": [_p],
     "sd_comm_allreduce_max": [_p, _dbl, C.POINTER(_dbl)],
     "sd_comm_gather_field": [_p, _p, _i64, _p, _p, _int, _int],

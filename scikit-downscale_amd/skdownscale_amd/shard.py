@@ -257,6 +257,14 @@ class Communicator(_GatherLayout):
         except Exception:  # noqa: BLE001
             pass
 
+    def rccl_info(self):
+        """what RCCL itself reports: ``{"version", "ranks", "device"}`` (ncclGetVersion / ncclCommCount / ncclCommCuDevice)"""
+        from ._lib import check
+
+        v, n, d = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+        check(self.ctx.lib.sd_comm_rccl_info(self.handle, ctypes.byref(v), ctypes.byref(n), ctypes.byref(d)))
+        return {"version": v.value, "ranks": n.value, "device": d.value}
+
     def barrier(self):
         from ._lib import check
 
@@ -434,7 +442,7 @@ class ShardedPointWiseDownscaler:
             if on_gpu:
                 # one download of the root's [rank][T][C_r] buffer; the per-rank blocks are views of the host copy
                 rows = int(views[0].shape[0])
-                root = views[0].base  # the root buffer [rank][T][C_r] every per-rank view was cut from
+                root = getattr(views[0], "base", None)  # the root buffer [rank][T][C_r] every per-rank view was cut from
                 host = root.to_host().reshape(-1) if root is not None and root.nbytes == 8 * rows * int(cells.sum()) else None
                 if host is None:
                     views = [v.to_host() for v in views]

@@ -881,3 +881,58 @@ def test_float32_fields_cross_pcie_as_float32():
     pw.fit(mk(X32), mk(y32))
     res = pw.predict(mk(X32))
     assert res.values.dtype == np.float32 and np.array_equal(res.values.reshape(T, C), exp.astype(np.float32))
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_config1_grid_through_pointwise_downscaler(masked):
+    """BASELINE configs[0]: BcsdTemperature on the 16 x 16 synthetic grid, 40-year daily series (14 600 steps), through the drop-in
+    surface PointWiseDownscaler.fit / .predict (core.py:225-338) -- all 256 cells against the C oracle's per-cell loop
+    (core.py:86-96, 137-141 around bcsd.py:197-269); the masked variant blanks cells at t = 0 (core.py:35-37) and expects NaN
+    columns there (core.py:119)."""
+    import c_oracle
+    from skdownscale_amd import BcsdTemperature, GridArray, PointWiseDownscaler, synth
+
+    if not c_oracle.available():
+        pytest.skip("C oracle not built")
+    T, ny, nx = 14600, 16, 16
+    C = ny * nx
+    index = synth.daily_calendar(T)
+    gid = month_gid(index)
+    cells = np.arange(C)
+    X, y, Xp = (synth.tas_field(n, 11, index, cells, C) for n in ("X_hist", "y_obs", "X_fut"))
+    dead = np.array([0, 17, 100, 255]) if masked else np.array([], dtype=np.int64)
+    X[0, dead] = np.nan
+    y[0, dead] = np.nan
+    mk = lambda a: GridArray(a.reshape(T, ny, nx), ("time", "lat", "lon"), {"time": index, "lat": np.arange(ny), "lon": np.arange(nx)})  # noqa: E731
+    pw = PointWiseDownscaler(BcsdTemperature(return_anoms=False))
+    pw.fit(mk(X), mk(y))
+    out = pw.predict(mk(Xp))
+    assert out.dims == ("time", "lat", "lon") and out.values.shape == (T, ny, nx) and out.values.dtype == np.float64
+    got = out.values.reshape(T, C)
+    live = np.setdiff1d(cells, dead)
+    exp, st = c_oracle.bcsd_fit_predict(0, X[:, live], y[:, live], Xp[:, live], gid, gid, return_anoms=False, nthreads=8)
+    assert (st == 0).all()
+    assert np.isnan(got[:, dead]).all() and not np.isnan(got[:, live]).any()
+    assert_close(got[:, live], exp, what="config 1: 16 x 16 x 14 600 through PointWiseDownscaler vs C oracle")
+
+
+def test_precipitation_fit_predict_with_empty_groups(ctx):
+    """BcsdPrecipitation fit + predict with group ids that leave a middle group and the last group empty (G larger than the
+    populated ids): the kernel that sorts only the wet days must skip them like the other fused kernels do (their order-table
+    entries belong to the next group, or lie past the table)."""
+    from skdownscale_amd import synth
+
+    T, C = 14600, 11
+    index = synth.daily_calendar(T)
+    gid = month_gid(index).copy()
+    gid[gid >= 5] += 1  # group 5 stays empty; 13 groups populated of G = 14: the last one is empty as well
+    G = 14
+    cells = np.arange(C)
+    X, y, Xp = (synth.fill(synth.PRECIP, 5, s, np.arange(T), cells, C, amp=30.0, p_dry=0.5) for s in (20, 21, 22))
+    y = y + 0.0
+    y[3::5, :] += 0.25
+    for ra in (False, True):
+        exp, est = bo.pointwise_fit_predict(1, X, y, Xp, gid, gid, G=G, return_anoms=ra)
+        out, st = ctx.bcsd_fit_predict(1, ctx.to_device(X), ctx.to_device(y), gid, G, ctx.to_device(Xp), gid, ra)
+        assert np.array_equal(st, est) and (st == 0).all()
+        assert_close(out.to_host(), exp, what=f"empty groups, return_anoms={ra}")

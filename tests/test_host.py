@@ -630,3 +630,29 @@ def test_bench_cpu_legs_run_for_every_config():
         assert numpy_n["cores"] >= numpy_1["cores"]
         if kind != "analog":
             assert c_port is not None and "sd_oracle.c" in c_port["sample"]
+
+
+def test_bench_scaling_curve_uses_one_per_gpu_workload_and_checks_its_host_legs():
+    """bench.py: the N > 1 default runs the N = 1 line's cells per GPU (value(N) / value(1) is then a weak-scaling curve over identical
+    per-GPU work; BASELINE configs[4]'s own 125 000 per GPU is a second leg), and the parity helper of the host-path legs
+    (end_to_end / pointwise_end_to_end) accepts the oracle's own field and rejects a perturbed one."""
+    import importlib.util
+
+    import bcsd_oracle as bo
+    from skdownscale_amd import synth
+
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.WORKLOADS[5]["cells"] == bench.WORKLOADS[2]["cells"] and bench.WORKLOADS[5]["cells_config5"] == 125_000
+    T, n = 731, 5
+    index = synth.daily_calendar(T)
+    gid = (np.asarray(index.month) - 1).astype(np.int32)
+    X, y, Xp = (synth.tas_field(name, 0, index, np.arange(n), 64) for name in ("X_hist", "y_obs", "X_fut"))
+    exp, _ = bo.pointwise_fit_predict(0, X, y, Xp, gid, gid)
+    assert bench.oracle_parity(X, y, Xp, gid, [exp, exp.copy()], [np.zeros(n, np.int32)] * 2).startswith("ok")
+    bad = exp.copy()
+    bad[100, 2] += 1e-3
+    assert bench.oracle_parity(X, y, Xp, gid, [exp, bad]).startswith("FAILED")
+    assert bench.oracle_parity(X, y, Xp, gid, [exp], [np.array([0, 0, 4, 0, 0])]).startswith("FAILED")
+    assert bench.oracle_parity(X, y, Xp, gid, [exp[:, :3]]).startswith("FAILED shape")
