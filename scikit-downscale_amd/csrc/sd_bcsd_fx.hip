@@ -864,9 +864,34 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fx_kernel(const Params) {
 // reason: the compiler treats a pending __builtin_amdgcn_global_load_lds as an LDS write and puts s_waitcnt vmcnt(0) in front of
 // every DS instruction -- the ds_swizzle / ds_bpermute partner fetches of the sort included.  Waits are counted by hand.
 namespace tmj {
-constexpr int kChunkRows = 16, kChunkStride = 1024 + 16;
-__host__ __device__ constexpr int chunks_of(int n) { return (n + kChunkRows - 1) / kChunkRows; }
-__device__ __forceinline__ unsigned row_off(unsigned j) { return (j << 6) + ((j >> 4) << 4); }  // row j of the tile, cell 0
+// Layout of a tile (K = 20): a chunk = what one request lands = 16 row fragments of 64 B, and the REQUEST chooses which 16 rows
+// (the source address is per lane).  Lane l of the wave that owns a cell works on rows 20 l .. 20 l + 19 of the segment:
+//   chunk l             rows 20 l .. 20 l + 15          (slot i = row 20 l + i)
+//   chunk nl + t(l)     the tails, rows 20 l + 16 + e    (slot s2(l) + 4 e), t(l) = (l & 7) + 8 (l >> 5), s2(l) = (l >> 3) & 3
+// (nl = lanes with data = m / 20), and chunk bases are 1 032 B apart -- 8 bytes of skew, which the DMA accepts (measured:
+// csrc/microbench/tile_dma).  A column read of a wave (its cell, the same row number i in every lane) then touches
+// (base + 1 032 l + 64 i) / 8 mod 32 = (l + 8 i) mod 32: 32 consecutive lanes on 32 different bank pairs, conflict-free for
+// ds_read_b64 and ds_read2_b64 alike; the tails likewise ((nl + t) + 8 s2 = nl + l mod 32).  (Rows in time order with the
+// chunks skewed by 16 B -- the first version -- put lanes 16 chunks apart on the same banks: 3-way conflicts, and the column
+// phases ran at half the speed of the old cell-major rows.)  A sample's tag = its position 16 chunk + slot (11 bits).
+constexpr int kChunkStride = 1024 + 8;
+constexpr int kBlock = 20;  // rows per lane (the kernel's K)
+__host__ __device__ constexpr int chunks_of(int n) { return n / kBlock + 16; }  // n = whole lanes of 20, more than 32 of them
+__device__ __forceinline__ int tail_chunk(int l) { return (l & 7) + 8 * (l >> 5); }
+__device__ __forceinline__ int tail_slot(int l) { return (l >> 3) & 3; }
+// row of the segment that slot S of chunk Q holds (n - 1 where the slot holds none)
+__device__ __forceinline__ int row_of_slot(int Q, int S, int nl, int n) {
+    int r;
+    if (Q < nl) {
+        r = kBlock * Q + S;
+    } else {
+        const int t = Q - nl;
+        const int l = (t & 7) + 8 * (S & 3) + 32 * (t >> 3);
+        r = l < nl ? kBlock * l + 16 + (S >> 2) : n - 1;
+    }
+    return r < n ? r : n - 1;
+}
+__device__ __forceinline__ unsigned tag_off(unsigned tag) { return (tag << 6) + ((tag >> 4) << 3); }  // position -> byte offset (cell 0)
 
 template <int NREG>
 struct RowIdx {
@@ -876,11 +901,11 @@ struct RowIdx {
 template <int NREG>
 __device__ __forceinline__ RowIdx<NREG> rows_of_wave(const int32_t* __restrict__ ord, int n, int q0, int wave, int lane) {
     RowIdx<NREG> t;
+    const int nl = n / kBlock;
 #pragma unroll
     for (int j = 0; j < NREG; ++j) {
         const int e = 64 * j + lane;
-        const int r = kChunkRows * (q0 + wave + kW * (e >> 4)) + (e & 15);
-        t.v[j] = ord[r < n ? r : n - 1];
+        t.v[j] = ord[row_of_slot(q0 + wave + kW * (e >> 4), e & 15, nl, n)];
     }
     return t;
 }
@@ -918,50 +943,50 @@ __device__ __forceinline__ void dma_chunks(const double* __restrict__ src, int64
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// Column access of lane block bl (rows K bl + idx, idx = -4 .. K + 3) of the wave's cell: K bl = 16 chunk0 + 4 p4, so row
-// K bl + idx sits (p4 + floor(idx / 4)) / 4 chunks further on -- one base per zone of four rows (two instructions, shared by the
-// zone's reads), immediate offsets inside.  fresh() hides p4 from the optimiser: the zone bases are rebuilt where they are
-// needed instead of living in seven registers across the phases.
-template <int K>
-struct ColBase {
-    unsigned base2;
-    int p4;
-    // address of the first row of zone z (rows 4 z .. 4 z + 3 of the block, z = -1 .. K / 4): the rows of a zone follow at the
-    // immediate offsets 0, 64, 128, 192
-    __device__ __forceinline__ unsigned zone(int z) const {
-        return base2 + (unsigned)(16 * ((p4 + z) >> 2) + 256 * z);  // (arithmetic shift: zone -1 of p4 = 0 lies one chunk back)
-    }
+// Column access of lane block bl of the wave's cell (rows 20 bl + idx, idx = -4 .. 23): four bases, immediate offsets
+//   idx -4 .. -1  the tail of lane bl - 1      idx 0 .. 15  the lane's chunk      idx 16 .. 19  its tail
+//   idx 20 .. 23  the head of lane bl + 1's chunk (one chunk stride further)
+// (pointer arithmetic: an in-bounds element offset becomes the DS instruction's immediate; an unsigned sum does not)
+struct Col {
+    unsigned mainb, tailb, prevb;
     __device__ __forceinline__ unsigned at(int idx) const {  // idx: compile-time after unrolling
-        const int z = (idx + 4) / 4 - 1;                      // floor(idx / 4) for idx >= -4
-        return zone(z) + (unsigned)(64 * (idx - 4 * z));
+        return idx < 0 ? prevb + (unsigned)(256 * (idx + 4)) : idx < 16 ? mainb + (unsigned)(64 * idx)
+             : idx < 20 ? tailb + (unsigned)(256 * (idx - 16)) : mainb + (unsigned)(kChunkStride + 64 * (idx - 20));
     }
-    // the value at row idx: pointer arithmetic on the zone's address (an in-bounds element offset becomes the DS instruction's
-    // immediate; an unsigned sum does not -- it may wrap)
     __device__ __forceinline__ double get(int idx) const {
-        const int z = (idx + 4) / 4 - 1;
-        return reinterpret_cast<lds_cdouble_t*>((uintptr_t)zone(z))[8 * (idx - 4 * z)];
+        if (idx < 0) return reinterpret_cast<lds_cdouble_t*>((uintptr_t)prevb)[32 * (idx + 4)];
+        if (idx < 16) return reinterpret_cast<lds_cdouble_t*>((uintptr_t)mainb)[8 * idx];
+        if (idx < 20) return reinterpret_cast<lds_cdouble_t*>((uintptr_t)tailb)[32 * (idx - 16)];
+        return reinterpret_cast<lds_cdouble_t*>((uintptr_t)mainb)[kChunkStride / 8 + 8 * (idx - 20)];
     }
-    __device__ __forceinline__ void put(int idx, double x) const {
-        const int z = (idx + 4) / 4 - 1;
-        reinterpret_cast<lds_double_t*>((uintptr_t)zone(z))[8 * (idx - 4 * z)] = x;
+    __device__ __forceinline__ void put(int idx, double x) const {  // own rows only (0 <= idx < 20)
+        if (idx < 16) reinterpret_cast<lds_double_t*>((uintptr_t)mainb)[8 * idx] = x;
+        else reinterpret_cast<lds_double_t*>((uintptr_t)tailb)[32 * (idx - 16)] = x;
     }
-    __device__ __forceinline__ void fresh() { asm volatile("" : "+v"(p4)); }
 };
-template <int K>
-__device__ __forceinline__ ColBase<K> col_base(unsigned tile_b, int col, int bl) {
-    static_assert(K % 4 == 0, "lane blocks start on multiples of four rows");
-    const int a = K * bl;
-    ColBase<K> c;
-    c.p4 = (a & 15) >> 2;
-    c.base2 = tile_b + 8u * (unsigned)col + (unsigned)(a >> 4) * (unsigned)kChunkStride + (unsigned)((a & 15) * 64);
+__device__ __forceinline__ Col col_of(unsigned tile_b, int col, int bl, int nl) {
+    const unsigned cb = tile_b + 8u * (unsigned)col;
+    const int lp = (bl - 1) & 63;  // (lane 0 has no predecessor: it reads -- and drops -- the tail slot of lane 63)
+    Col c;
+    c.mainb = cb + (unsigned)bl * (unsigned)kChunkStride;
+    c.tailb = cb + (unsigned)(nl + tail_chunk(bl)) * (unsigned)kChunkStride + 64u * (unsigned)tail_slot(bl);
+    c.prevb = cb + (unsigned)(nl + tail_chunk(lp)) * (unsigned)kChunkStride + 64u * (unsigned)tail_slot(lp);
     return c;
+}
+// tags (positions) of the lane's samples: i < 16: 16 lane + i; tails: 16 (nl + t) + s2 + 4 e
+struct Tags {
+    unsigned main0, tail0;
+    __device__ __forceinline__ unsigned of(int i) const { return i < 16 ? main0 + (unsigned)i : tail0 + (unsigned)(4 * (i - 16)); }
+};
+__device__ __forceinline__ Tags tags_of(int lane, int nl) {
+    return Tags{16u * (unsigned)lane, 16u * (unsigned)(nl + tail_chunk(lane)) + (unsigned)tail_slot(lane)};
 }
 
 // keys + second-level keys of the shifted series: t = (v - lo) * sc + 1 in [1, kQD - 1]; t + 2^21 has the exponent of 2^21, so its
 // mantissa is t in units of 2^-31: 21 bits of q above 31 further bits.  Monotone in v (fma, add: correctly rounded).
 // key = (q << 11) | sample index; u2 = the low mantissa word (bit 31 = the lowest bit of q: equal wherever q is).
 template <int K, class GetU>
-__device__ __forceinline__ void keys_u2(const GetU& u_of, double lo, double hi, int m, int lane, unsigned (&key)[K], unsigned (&u2)[K]) {
+__device__ __forceinline__ void keys_u2(const GetU& u_of, double lo, double hi, int m, int lane, const Tags& tg, unsigned (&key)[K], unsigned (&u2)[K]) {
     const double sc = (double)(kQD - 2u) / (hi - lo);  // +inf when every sample is equal: t = NaN everywhere, all keys and u2 tie
     const double off = -lo * sc + 1.0;
     const unsigned tag0 = (unsigned)(K * lane);
@@ -973,10 +998,35 @@ __device__ __forceinline__ void keys_u2(const GetU& u_of, double lo, double hi, 
         const unsigned w0 = (unsigned)__double2loint(t), w1 = (unsigned)__double2hiint(t);
         unsigned q = __builtin_amdgcn_alignbit(w1, w0, 31) & 0x1fffffu;
         q = q < kQD ? q : kQD;
-        const unsigned dk = (q << kTagBits) | (tag0 + (unsigned)i);
+        const unsigned dk = (q << kTagBits) | tg.of(i);
         const unsigned pk = pad0 + (unsigned)i * ((1u << kTagBits) + 1u);
         key[i] = lane_in ? dk : pk;
         u2[i] = w0;
+    }
+}
+// keys of the observations (the cvt path of keys_from_range, whole lanes) with position tags
+template <int K>
+__device__ __forceinline__ void keys_pos(const double (&v)[K], int m, int lane, const Tags& tg, unsigned (&key)[K]) {
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        lo = vmin(lo, v[i]);
+        hi = vmax(hi, v[i]);
+    }
+    lo = wave_min_f64(lo);
+    hi = wave_max_f64(hi);
+    const double sc = (double)kQD / (hi - lo);
+    const double off = -lo * sc;
+    const unsigned tag0 = (unsigned)(K * lane);
+    const unsigned pad0 = ((kQD + 1u + tag0) << kTagBits) | tag0;
+    const bool lane_in = K * lane < m;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        unsigned q = (unsigned)__builtin_fma(v[i], sc, off);
+        q = q < kQD ? q : kQD;
+        const unsigned dk = (q << kTagBits) | tg.of(i);
+        const unsigned pk = pad0 + (unsigned)i * ((1u << kTagBits) + 1u);
+        key[i] = lane_in ? dk : pk;
     }
 }
 
@@ -1028,20 +1078,23 @@ __device__ __forceinline__ int fix_equal_q_by(unsigned (&k)[K], int lane, const 
 }
 }  // namespace tmj
 
-// LDS of a workgroup: [head: kHeadDoubles][tile: chunks_of(nmax) x 1 040 B]; the u2 area (8 cells x RSU 32-bit words) overlays
-// the first chunks of the tile
-__host__ __device__ constexpr int fd_u2_stride(int nmax) { return (nmax + 3) / 4 * 4; }
-__host__ __device__ constexpr int fd_late_chunks(int nmax) { return (kW * 4 * fd_u2_stride(nmax) + tmj::kChunkStride - 1) / tmj::kChunkStride; }
+// LDS of a workgroup: [head: kHeadDoubles][tile: chunks_of(nmax) x 1 032 B]; the u2 area (8 cells x RSU 32-bit words, indexed by
+// tag) overlays the first chunks of the tile
+__host__ __device__ constexpr int fd_u2_stride(int nmax) { return 16 * tmj::chunks_of(nmax); }
+__host__ __device__ constexpr int fd_late_chunks(int rsu) { return (kW * 4 * rsu + tmj::kChunkStride - 1) / tmj::kChunkStride; }  // rsu = fd_u2_stride(nmax)
 inline size_t fd_lds_bytes(int nmax) { return (size_t)kHeadDoubles * sizeof(double) + (size_t)tmj::chunks_of(nmax) * tmj::kChunkStride; }
 
-template <int K>
+// EARLY: half of the y tile is requested ahead of the sort of u (the second-level keys are compacted into the other half behind a
+// workgroup barrier); !EARLY: the second-level keys stay in the wave's own column (low words of its slots: no barrier), the whole y
+// tile is requested behind the vote.
+template <int K, bool EARLY>
 __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ParamsPtr p = (ParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int NR = K / 2;
     constexpr int CH = K >= 20 ? K / 4 : K >= 14 ? K / 2 : K;
     constexpr int NKX = 10;  // requests per wave and tile at most: 80 chunks = 1 280 rows
-    static_assert(K % 4 == 0 && K % CH == 0 && 64 * K <= 1280, "tile of at most 80 chunks");
+    static_assert(K == tmj::kBlock && K % CH == 0, "the chunk layout is that of 20 rows per lane");
 #ifdef SD_DEV
     const int abl = p->dev_flags;
 #else
@@ -1072,6 +1125,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
     const int m = p->off_f[g + 1] - begf;  // == the predict segment's length (whole-lane groups of equal length)
     const int begp = p->off_p[g];
     if (m == 0) return;
+    const int nl = m / K;                     // lanes with data
     const int nch = tmj::chunks_of(m);
     const int RSU = p->RS;                    // 32-bit words per cell of the u2 area
     const int nlate = fd_late_chunks(RSU) < nch ? fd_late_chunks(RSU) : nch;  // chunks under the u2 area: the late half of y
@@ -1085,7 +1139,8 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
     // ---- x climatology (bcsd.py:222) from registers; the x_fut tile by DMA ------------------------------------------------
     SDPH("x_tiles");
     double xc = 0.0;
-    tmj::RowIdx<2> ry_late, ry_early;
+    tmj::RowIdx<EARLY ? 2 : 3> ry_late;
+    tmj::RowIdx<2> ry_early;
     {
         SD_LANE();
         tmj::RowIdx<3> rp = tmj::rows_of_wave<3>(p->ord_p + begp, m, 0, wave, lane);  // (in one batch with the rows of the x_hist tile)
@@ -1134,7 +1189,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
         const bool has = K * lane < m;
         const int bl = has ? lane : 0;
         const bool first_lane = bl == 0, last_lane = K * (bl + 1) == m;
-        tmj::ColBase<K> cz = tmj::col_base<K>(tile_b, col, bl);
+        const tmj::Col cz = tmj::col_of(tile_b, col, bl, nl);
         // (the shifted samples themselves are not kept -- 40 registers beside the 40 of the shifts --: their extremes are taken
         // here, the key generation below re-reads the samples from the column and subtracts the kept shifts again)
         double ulo = __builtin_inf(), uhi = -__builtin_inf();
@@ -1142,13 +1197,11 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
 #pragma unroll
         for (int cbeg = 0; cbeg < K; cbeg += CH) {
             double w[CH + 8];
-            cz.fresh();
 #pragma unroll
             for (int t = 0; t < CH + 8; ++t) {
                 const int idx = cbeg - 4 + t;  // row K * bl + idx of the cell's column
-                // (every lane reads, also where the row lies before or behind the segment -- the head of the LDS block, the rest
-                // of the last chunk or nothing at all: an LDS read past the allocation returns 0 -- and drops the value: a select
-                // on the address made the compiler wrap every such read in a divergent branch)
+                // (every lane reads, also where the row lies before or behind the segment -- some other slot of the tile -- and
+                // drops the value: a select on the address made the compiler wrap every such read in a divergent branch)
                 const double x = cz.get(idx);
                 w[t] = idx < 0 ? (first_lane ? 0.0 : x) : idx >= K ? (last_lane ? 0.0 : x) : x;
             }
@@ -1187,30 +1240,43 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
         }
         SDT(3);  // rolling mean
         // the rows of the y requests (the loads return under the key generation)
-        ry_late = tmj::rows_of_wave<2>(p->ord_f + begf, m, 0, wave, lane);
-        ry_early = tmj::rows_of_wave<2>(p->ord_f + begf, m, nlate, wave, lane);
+        ry_late = tmj::rows_of_wave<EARLY ? 2 : 3>(p->ord_f + begf, m, 0, wave, lane);
+        if (EARLY) ry_early = tmj::rows_of_wave<2>(p->ord_f + begf, m, nlate, wave, lane);
         SDPH("u_keys");
         unsigned u2[K];
         {
             ulo = wave_min_f64(ulo);
             uhi = wave_max_f64(uhi);
-            cz.fresh();
             const auto u_of = [&](int i) { return (cz.get(i) - shift[i]) + 0.0; };
-            tmj::keys_u2<K>(u_of, ulo, uhi, m, lane, ku, u2);
+            tmj::keys_u2<K>(u_of, ulo, uhi, m, lane, tmj::tags_of(lane, nl), ku, u2);
         }
-        // every wave has read its column for the last time: the tile is dead, the y requests and the u2 area may overwrite it
-        tmj::rows_ready(ry_early);
         tmj::rows_ready(ry_late);
-        __syncthreads();
-        if (!(abl & 32)) tmj::dma_chunks<5, 2>(p->y, p->ld, ry_early, nlate, nch, cfetch, tile_b, wave, lane);
-        const unsigned ub = tile_b + 4u * (unsigned)(col * RSU);
-        if (has) {
+        unsigned ub;
+        if constexpr (EARLY) {
+            // every wave has read its column for the last time: the tile is dead, the y requests and the u2 area may overwrite it
+            tmj::rows_ready(ry_early);
+            __syncthreads();
+            if (!(abl & 32)) tmj::dma_chunks<5, 2>(p->y, p->ld, ry_early, nlate, nch, cfetch, tile_b, wave, lane);
+            ub = tile_b + 4u * (unsigned)(col * RSU);
+        } else {
+            wave_fence();  // every lane of the wave has read its rows: their low words take the second-level keys
+            ub = 0u;
+        }
+        if (!EARLY) {
+            if (has) {
+                const tmj::Col cw = tmj::col_of(tile_b, col, lane, nl);
 #pragma unroll
-            for (int i = 0; i < K; i += 4) {
-                typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
-                *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((uintptr_t)(ub + 4u * (unsigned)(K * lane + i))) =
-                    u32x4{u2[i], u2[i + 1], u2[i + 2], u2[i + 3]};
+                for (int i = 0; i < K; ++i) *reinterpret_cast<__attribute__((address_space(3))) unsigned*>((uintptr_t)cw.at(i)) = u2[i];
             }
+        } else if (has) {  // by tag: the lane's chunk is 16 consecutive words, its tail four words 16 bytes apart
+            const tmj::Tags tg = tmj::tags_of(lane, nl);
+            typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+            __attribute__((address_space(3))) u32x4* um = reinterpret_cast<__attribute__((address_space(3))) u32x4*>((uintptr_t)(ub + 4u * tg.main0));
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) um[i / 4] = u32x4{u2[i], u2[i + 1], u2[i + 2], u2[i + 3]};
+            __attribute__((address_space(3))) unsigned* ut = reinterpret_cast<__attribute__((address_space(3))) unsigned*>((uintptr_t)(ub + 4u * tg.tail0));
+#pragma unroll
+            for (int i = 16; i < K; ++i) ut[4 * (i - 16)] = u2[i];
         }
         wave_fence();
         SDT(4);  // u2 stored, keys
@@ -1218,8 +1284,9 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
         if (!(abl & 1)) sdws::wave_sort<K>(ku, lane, (m + K - 1) / K);
         SDT(5);  // sort of u
         SDPH("u_fix");
-        const auto cmp_u2 = [ub](unsigned ta, unsigned tb, bool* gt, bool* eq) {
-            const unsigned a = lds_u32(ub + 4u * ta), b = lds_u32(ub + 4u * tb);
+        const unsigned colb_u = tile_b + 8u * (unsigned)col;
+        const auto cmp_u2 = [ub, colb_u](unsigned ta, unsigned tb, bool* gt, bool* eq) {
+            const unsigned a = lds_u32(EARLY ? ub + 4u * ta : colb_u + tmj::tag_off(ta)), b = lds_u32(EARLY ? ub + 4u * tb : colb_u + tmj::tag_off(tb));
             *gt = a > b;
             *eq = a == b;
         };
@@ -1250,7 +1317,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
     bool redo_y = false;
     {
         SD_LANE();
-        if (!(abl & 32)) tmj::dma_chunks<5, 2>(p->y, p->ld, ry_late, 0, nlate, cfetch, tile_b, wave, lane);
+        if (!(abl & 32)) tmj::dma_chunks<EARLY ? 5 : NKX, EARLY ? 2 : 3>(p->y, p->ld, ry_late, 0, EARLY ? nlate : nch, cfetch, tile_b, wave, lane);
         SDT(8);  // late half requested
         tmj::dma_wait_all();
         __syncthreads();
@@ -1258,7 +1325,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
         SDPH("y_keys");
         const bool has = K * lane < m;
         const int bl = has ? lane : 0;
-        tmj::ColBase<K> cz = tmj::col_base<K>(tile_b, col, bl);
+        const tmj::Col cz = tmj::col_of(tile_b, col, bl, nl);
         const unsigned colb = tile_b + 8u * (unsigned)col;
         unsigned ky[K];
         {
@@ -1275,7 +1342,7 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
             s = has ? s : 0.0;
             yc = wave_sum_f64(s) / (double)m;  // bcsd.py:223
             if (__any(bad && has) && lane == 0 && cell_ok) atomicOr(&p->status_fit[c], SDI_NONFINITE);
-            make_keys_impl<K, false, true, true>(v, m, lane, ky);  // tags = sample indices
+            tmj::keys_pos<K>(v, m, lane, tmj::tags_of(lane, nl), ky);
         }
         SDT(10);  // y_climo, keys
         SDPH("y_sort");
@@ -1283,16 +1350,16 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
         SDT(11);  // sort of y
         SDPH("y_fix");
         const auto cmp_y = [colb](unsigned ta, unsigned tb, bool* gt, bool* eq) {
-            const double a = lds_f64(colb + tmj::row_off(ta)), b = lds_f64(colb + tmj::row_off(tb));
+            const double a = lds_f64(colb + tmj::tag_off(ta)), b = lds_f64(colb + tmj::tag_off(tb));
             *gt = a > b;
             *eq = a == b;
         };
         if (!(abl & 8)) redo_y = (tmj::fix_equal_q_by<K>(ky, lane, cmp_y) & kUnsorted) != 0 && cell_live;  // tied observations are interchangeable
         SDPH("y_gather");
         {
-            const unsigned tm = has ? kTagMask : 0u;  // (pad keys carry indices past the segment: those lanes read row 0)
+            const unsigned tm = has ? kTagMask : 0u;  // (pad keys carry tags of no sample: those lanes read position 0)
 #pragma unroll
-            for (int i = 0; i < K; ++i) t[i] = lds_f64(colb + tmj::row_off(ky[i] & tm));
+            for (int i = 0; i < K; ++i) t[i] = lds_f64(colb + tmj::tag_off(ky[i] & tm));
         }
         SDT(12);  // fix-up of y, sorted observations gathered
         // ---- identity map (equal group lengths): rank r of u takes the r-th smallest observation; scatter to the time slots ----
@@ -1300,11 +1367,10 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
         wave_fence();  // every lane has read what it needs of the column
         if (has) {
 #pragma unroll
-            for (int i = 0; i < K; ++i) lds_store_f64(colb + tmj::row_off(ku[i] & kTagMask), t[i]);
+            for (int i = 0; i < K; ++i) lds_store_f64(colb + tmj::tag_off(ku[i] & kTagMask), t[i]);
         }
         wave_fence();
         SDPH("restore");
-        cz.fresh();
         double q[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) q[i] = cz.get(i);
@@ -1340,9 +1406,11 @@ __global__ void __launch_bounds__(kThreads, 4) bcsd_fd_kernel(const Params) {
 #pragma unroll
         for (int k = 0; k < NKX; ++k) {
             const int qc = wave + kW * k;
-            const int r = tmj::kChunkRows * qc + (lane >> 2);
+            const int S = lane >> 2;
+            // (a tail slot of a lane without data holds no row)
+            const bool row_in = qc < nl ? K * qc + S < m : (((qc - nl) & 7) + 8 * (S & 3) + 32 * ((qc - nl) >> 3)) < nl;
             const int ti = tmj::row_of_request(ro, k, lane);
-            if (qc < nch && r < m && keep) {
+            if (qc < nch && row_in && keep) {
                 typedef double __attribute__((ext_vector_type(2))) f64x2;
                 const f64x2 v = *reinterpret_cast<__attribute__((address_space(3))) const f64x2*>((uintptr_t)(tile_b + (unsigned)qc * (unsigned)tmj::kChunkStride + 16u * (unsigned)lane));
                 *reinterpret_cast<f64x2*>(colp + (uint64_t)(uint32_t)ti * (uint64_t)(uint32_t)((uint32_t)p->ld_out * 8u)) = v;
@@ -1995,15 +2063,21 @@ int launch_ki(sd_ctx* ctx, Params p, int nmax, const int* group_len) {
         const size_t lds_fd = fd_lds_bytes(nfull);
         const bool ok = full != 0ull && p.kind == SD_BCSD_TAS && !p.from_state && p.X != nullptr && p.C >= kW && p.C % 2 == 0 && p.ld % 2 == 0 &&
                         p.ld_p % 2 == 0 && p.ld_out % 2 == 0 && al16(p.X) && al16(p.y) && al16(p.Xp) && al16(p.out) && 2 * lds_fd <= ctx->lds_max &&
-                        tmj::chunks_of(nfull) - fd_late_chunks(nfull) <= 40 && fd_late_chunks(nfull) <= 40 && sd_dev_env("SD_FX_NODMA") == nullptr;
+                        nfull % 20 == 0 && nfull > 640 && tmj::chunks_of(nfull) <= 80 && fd_late_chunks(fd_u2_stride(nfull)) <= 40 &&
+                        tmj::chunks_of(nfull) - fd_late_chunks(fd_u2_stride(nfull)) <= 40 && sd_dev_env("SD_FX_NODMA") == nullptr;
         if (ok) {
             Params q = p;
             q.gmask = full;
             q.RS = fd_u2_stride(nfull);
             const int64_t nb = 8 * ((p.ntiles + 7) / 8) * __builtin_popcountll(full);
             SD_CHECK_ARG(nb < ((int64_t)1 << 31), "grid too large");
-            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fd_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fd));
-            SD_LAUNCH(ctx, "bcsd_fd_kernel", (bcsd_fd_kernel<K>), dim3((unsigned)nb), dim3(kThreads), lds_fd, q);
+            if (sd_dev_env("SD_FD_LATE") != nullptr) {  // (development: the variant without the early half of the y tile)
+                SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fd_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fd));
+                SD_LAUNCH(ctx, "bcsd_fd_kernel", (bcsd_fd_kernel<K, false>), dim3((unsigned)nb), dim3(kThreads), lds_fd, q);
+            } else {
+                SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bcsd_fd_kernel<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fd));
+                SD_LAUNCH(ctx, "bcsd_fd_kernel", (bcsd_fd_kernel<K, true>), dim3((unsigned)nb), dim3(kThreads), lds_fd, q);
+            }
             if (rest == 0ull) return SD_OK;
             q = p;
             q.gmask = rest;

@@ -936,3 +936,56 @@ def test_precipitation_fit_predict_with_empty_groups(ctx):
         out, st = ctx.bcsd_fit_predict(1, ctx.to_device(X), ctx.to_device(y), gid, G, ctx.to_device(Xp), gid, ra)
         assert np.array_equal(st, est) and (st == 0).all()
         assert_close(out.to_host(), exp, what=f"empty groups, return_anoms={ra}")
+
+
+@pytest.mark.parametrize("C,c0,Ct", [(8, 0, 8), (10, 0, 10), (42, 0, 42), (62, 4, 70), (24, 6, 40)])
+def test_dma_tile_kernel_against_the_register_tile_kernel(dev_ctx, monkeypatch, C, c0, Ct):
+    """bcsd_fd_kernel (round 6: whole-lane months of a 40-year daily series, tiles landing by LDS-DMA in the lane-per-chunk
+    layout, second-level keys, half of the y tile in flight during the sort of u) against bcsd_fx_kernel<20, true, true> (tiles
+    through registers into per-cell rows): same arithmetic in the same order, so the fields must agree BIT FOR BIT -- for grids
+    whose last tile is ragged (even cell counts: the tile is fetched shifted back over its predecessor), cell views of a wider
+    resident field (leading dimension > cells, even offsets), a masked cell, a cell with a non-finite sample in each field,
+    and cells with exactly tied shifted samples (work list).  Both variants of the kernel (SD_FD_LATE: the whole y tile behind
+    the vote, second-level keys in the wave's own column).  Against the oracle for the first cells (bcsd.py:197-269)."""
+    ctx = dev_ctx
+    rng = np.random.default_rng(100 + C)
+    T = 14600
+    index = pd.date_range("1980-01-01", periods=T, freq="D")
+    gid = month_gid(index)
+    full = {k: 15 + 8 * rng.standard_normal((T, Ct)) for k in ("X", "y", "Xp")}
+    sl = slice(c0, c0 + C)
+    X, y, Xp = (full[k][:, sl] for k in ("X", "y", "Xp"))  # (views: the edits below land in `full`)
+    if C > 8:
+        X[0, 1] = np.nan                  # masked cell (core.py:35-37)
+        X[777, 3] = np.inf                # non-finite x_hist
+        y[5000, C - 3] = np.nan           # non-finite y_obs
+        Xp[9000, C - 1] = -np.inf         # non-finite x_fut (last cell: the ragged tile)
+        Xp[4000:4024, 5] = Xp[4000, 5]    # a constant stretch: exactly tied shifted samples -> work list
+        Xp[120:150, C - 2] = Xp[120, C - 2]
+    dev = {k: ctx.to_device(v) for k, v in full.items()}
+    args = lambda: (dev["X"].cells(c0, c0 + C), dev["y"].cells(c0, c0 + C), gid, 12, dev["Xp"].cells(c0, c0 + C), gid)  # noqa: E731
+    res = {}
+    for name, env in (("dma", {}), ("dma_late", {"SD_FD_LATE": "1"}), ("regs", {"SD_FX_NODMA": "1"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        big = ctx.to_device(np.full((T, Ct), -777.0))
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        _, st = ctx.bcsd_fit_predict(0, *args(), out=big.cells(c0, c0 + C))
+        ctx.prof_enable(False)
+        kernels = set(ctx.prof())
+        assert ("bcsd_fd_kernel" in kernels) == (name != "regs"), (name, kernels)
+        res[name] = (big.to_host(), st)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    ref, st_ref = res["regs"]
+    for name in ("dma", "dma_late"):
+        got, st = res[name]
+        assert np.array_equal(st, st_ref), name
+        assert np.array_equal(got, ref, equal_nan=True), f"{name}: differs from the register-tile kernel"
+    assert (np.delete(ref, np.s_[c0:c0 + C], axis=1) == -777.0).all()  # neighbours of the view untouched
+    n = min(C, 8)
+    exp, est = bo.pointwise_fit_predict(0, X[:, :n], y[:, :n], Xp[:, :n], gid, gid)
+    assert np.array_equal(st_ref[:n], est)
+    ok = est == 0
+    assert_close(ref[:, sl][:, :n][:, ok], exp[:, ok], what="DMA tile kernel vs oracle")
