@@ -37,6 +37,7 @@
 #include "sd_lsq.h"
 #include "sd_sortnet.h"
 #include "sd_wave.h"
+#include "sd_wsort.h"
 
 namespace {
 
@@ -62,6 +63,7 @@ __device__ __forceinline__ int64_t first_cell(int64_t C, int64_t* step, int64_t*
 }
 
 #include "sd_analog_fit.h"
+#include "sd_analog_runs.h"
 #include "sd_analog_epilogue.h"
 #include "sd_analog_f1.h"
 #include "sd_analog_fn.h"
@@ -152,9 +154,12 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
         // Cells are processed in chunks so that the staging buffers stay small (and cache-resident).
         const int64_t chunk = 16384;
         const int64_t cc_max = C < chunk ? C : chunk;
-        sd_scratch qc, oc;
+        sd_scratch qc, oc, qtags;
         SD_HIP(qc.alloc(ctx, sizeof(double) * (size_t)Tq * cc_max));
         SD_HIP(oc.alloc(ctx, sizeof(double) * (size_t)Tq * 3 * cc_max));
+        // round 6: the queries of a cell in value order inside runs of 1 024 time steps (sd_analog_runs.h): the kernels below index
+        // queries and results by position, the two staging kernels translate between positions and times
+        bool runs_q = query_runs_apply(Tq);
         SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_window_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // single pass with only xs in LDS (statistics from the prefix sums, or the window of yx read from memory)
@@ -164,6 +169,12 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
         const bool phases = mean_only && mode == 0 && ((kind == SD_ANALOG_MEAN && !has_thresh) || k == 1) && T <= 1024 * 20 &&
                             sd_dev_env("SD_ANALOG_NOPHASES") == nullptr;
         const int skip_prob = phases && !has_thresh ? 1 : 0;  // the probability column is 1 wherever the prediction is not NaN (gard.py:346)
+        // Value-ordered runs pay where a query reads its window of analog values from memory (weights, thresholds, the regression):
+        // neighbouring lanes then read overlapping lines.  The three-generation kernel reads nothing per query but LDS words, and
+        // its search is bound by its spilled registers, not by bank conflicts: measured equal with sorted queries (33.7 against
+        // 33.0 ms per 100 000 cells), while the run staging costs 6 ms more than the plain transposes -- it keeps the time order.
+        runs_q = runs_q && !(phases && sd_dev_env("SD_ANALOG_RUNS_ALWAYS") == nullptr);
+        if (runs_q) SD_HIP(qtags.alloc(ctx, sizeof(unsigned short) * (size_t)Tq * cc_max));
         const size_t lds_mean3 = lds_mean;
         if (mean_only) {
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean_kernel),
@@ -191,8 +202,12 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
         for (int64_t cb = 0; cb < C; cb += chunk) {
             const int64_t cc = C - cb < chunk ? C - cb : chunk;
             dim3 tgrid((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32));
-            SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, tgrid, dim3(256), 0, Xq + cb, ld, Tq, 1, 0, cc,
-                      qc.as<double>(), status_p.as<int32_t>() + cb, 0);
+            if (runs_q) {
+                SD_TRY(launch_query_runs(ctx, Xq + cb, ld, Tq, cc, qc.as<double>(), qtags.as<unsigned short>(), status_p.as<int32_t>() + cb));
+            } else {
+                SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, tgrid, dim3(256), 0, Xq + cb, ld, Tq, 1, 0, cc,
+                          qc.as<double>(), status_p.as<int32_t>() + cb, 0);
+            }
             PredictArgs pw = pa;
             pw.out = oc.as<double>();
             pw.oc_Tq = Tq;
@@ -245,9 +260,13 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
                           (const double*)st->yx + cb * T, (const double*)st->X + cb * T, (const double*)st->y + cb * T,
                           (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb, sc_d.as<double>(), sc_i.as<int32_t>(), pw);
             }
-            SD_LAUNCH(ctx, "analog_untranspose_kernel", analog_untranspose_kernel,
-                      dim3((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32), skip_prob ? 2 : 3), dim3(256), 0,
-                      (const double*)oc.p, Tq, cc, out + cb, ld_out, skip_prob);
+            if (runs_q) {
+                SD_TRY(launch_untranspose_runs(ctx, (const double*)oc.p, (const unsigned short*)qtags.p, Tq, cc, out + cb, ld_out, skip_prob));
+            } else {
+                SD_LAUNCH(ctx, "analog_untranspose_kernel", analog_untranspose_kernel,
+                          dim3((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32), skip_prob ? 2 : 3), dim3(256), 0,
+                          (const double*)oc.p, Tq, cc, out + cb, ld_out, skip_prob);
+            }
         }
         SD_HIP(hipStreamSynchronize(ctx->stream));  // qc / oc go back to the block cache at scope exit
     } else if (f1) {
@@ -393,6 +412,10 @@ int fit_predict_dev(sd_ctx* ctx, const double* X, const double* y, int64_t ld, i
     SD_HIP(list.alloc(ctx, sizeof(int32_t) * (size_t)(C + 1)));
     SD_HIP(qc.alloc(ctx, sizeof(double) * (size_t)Tq * cc_max));
     SD_HIP(oc.alloc(ctx, sizeof(double) * (size_t)Tq * 3 * cc_max));
+    sd_scratch qtags;
+    // (the fused kernel gains nothing from value-ordered queries -- see predict_common -- : development switch only)
+    const bool runs_q = query_runs_apply(Tq) && sd_dev_env("SD_ANALOG_RUNS_ALWAYS") != nullptr;
+    if (runs_q) SD_HIP(qtags.alloc(ctx, sizeof(unsigned short) * (size_t)Tq * cc_max));
     pa.one_class = st_p.as<int32_t>();
     int32_t* work_count = list.as<int32_t>();
     int32_t* worklist = work_count + 1;
@@ -409,8 +432,12 @@ int fit_predict_dev(sd_ctx* ctx, const double* X, const double* y, int64_t ld, i
     for (int64_t cb = 0; cb < C; cb += chunk) {
         const int64_t cc = C - cb < chunk ? C - cb : chunk;
         dim3 tgrid((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32));
-        SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, tgrid, dim3(256), 0, Xq + cb, ld_q, Tq, 1, 0, cc, qc.as<double>(),
-                  st_p.as<int32_t>() + cb, 0);
+        if (runs_q) {
+            SD_TRY(launch_query_runs(ctx, Xq + cb, ld_q, Tq, cc, qc.as<double>(), qtags.as<unsigned short>(), st_p.as<int32_t>() + cb));
+        } else {
+            SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, tgrid, dim3(256), 0, Xq + cb, ld_q, Tq, 1, 0, cc, qc.as<double>(),
+                      st_p.as<int32_t>() + cb, 0);
+        }
         PredictArgs pw = pa;
         pw.out = oc.as<double>();
         pw.oc_Tq = Tq;
@@ -429,9 +456,13 @@ int fit_predict_dev(sd_ctx* ctx, const double* X, const double* y, int64_t ld, i
             default: rc = launch_fused_k<17>(ctx, nbc, lds, r, np, od, xc, yy, qc.as<double>(), Tq, T, cc, sf, sp, worklist, work_count, cb, pw, skip_prob); break;
         }
         SD_TRY(rc);
-        SD_LAUNCH(ctx, "analog_untranspose_kernel", analog_untranspose_kernel,
-                  dim3((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32), skip_prob ? 2 : 3), dim3(256), 0, (const double*)oc.p, Tq, cc,
-                  out + cb, ld_out, skip_prob);
+        if (runs_q) {
+            SD_TRY(launch_untranspose_runs(ctx, (const double*)oc.p, (const unsigned short*)qtags.p, Tq, cc, out + cb, ld_out, skip_prob));
+        } else {
+            SD_LAUNCH(ctx, "analog_untranspose_kernel", analog_untranspose_kernel,
+                      dim3((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32), skip_prob ? 2 : 3), dim3(256), 0, (const double*)oc.p, Tq, cc,
+                      out + cb, ld_out, skip_prob);
+        }
     }
     int32_t nw = 0;
     SD_HIP(hipMemcpyAsync(&nw, work_count, sizeof(nw), hipMemcpyDeviceToHost, ctx->stream));

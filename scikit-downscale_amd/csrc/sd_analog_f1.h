@@ -353,6 +353,84 @@ __global__ void __launch_bounds__(1024) analog_f1_window_kernel(int mode, const 
     }
 }
 
+// Window start of two queries in ONE bisection each (round 6).  The window of the k nearest values of q starts at the first i
+// whose left end is not farther from q than the value k places on: (q - xs[i])^2 <= (xs[i + k] - q)^2, i.e. xs[i] + xs[i + k] >= 2 q
+// -- a predicate that is monotone in i (a rounded sum of two sorted sequences is sorted), false before the start and true from it
+// on, with xs[n] = +inf closing the range at i = M = n - k.  Two LDS reads, an addition and a compare per step over the M + 1
+// candidates replace the position search among the values (14 steps) AND the refinement among the k + 1 candidates around the
+// position (5 steps of two squared distances each): a third fewer vector instructions in the loop that bounds these kernels.
+// The rounding of the sum can misplace the start by one only when q sits within an ulp of a midpoint; the callers' test that
+// the window is STRICTLY separated from its outside neighbours -- exact, on the values -- then fails as it does for a real tie,
+// and the query takes the exact walk (the unique strictly separated window is the same whichever search found it).
+template <int NQ>
+__device__ __forceinline__ void window_starts_n(const double* buf, int k, int M, const double (&q)[NQ], int (&L)[NQ]) {
+    int pos[NQ];  // index of the last candidate known to lie before the start
+    double q2[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        pos[j] = -1;
+        q2[j] = q[j] + q[j];
+    }
+#pragma unroll 1
+    for (int len = M + 1; len > 1;) {
+        int half = len >> 1;
+        if ((half & 15) == 0) --half;  // (strides that are multiples of 16 doubles pile the probes on two banks)
+        len -= half;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int t = pos[j] + half;
+            pos[j] = buf[t] + buf[t + k] < q2[j] ? t : pos[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int t = pos[j] + 1;  // <= M; the candidate M is a start for every q (xs[n] = +inf)
+        L[j] = t + (t < M && buf[t] + buf[t + k] < q2[j] ? 1 : 0);
+    }
+}
+// the search these kernels had until round 5: position of q among the values (one read per step), then the start of the window
+// among the k + 1 candidates around it (two reads per step).  Fewer reads than the single bisection while k + 1 candidates are
+// few: a single analog (best_analog, the reference's default) refines in one step.
+template <int NQ>
+__device__ __forceinline__ void window_starts_two_level(const double* buf, int k, int n, int M, const double (&q)[NQ], int (&L)[NQ]) {
+    int pos[NQ], hi[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) pos[j] = -1;  // index of the last value known to be < q
+#pragma unroll 1
+    for (int len = n; len > 1;) {
+        int half = len >> 1;
+        if ((half & 15) == 0) --half;
+        len -= half;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) pos[j] += buf[pos[j] + half] < q[j] ? half : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int p = pos[j] + 1 + (buf[pos[j] + 1] < q[j] ? 1 : 0);
+        L[j] = p - k > 0 ? p - k : 0;
+        hi[j] = p < M ? p : M;
+    }
+    int nsteps = 0;
+    while ((1 << nsteps) < (k + 1 < M + 1 ? k + 1 : M + 1)) ++nsteps;
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int mid = (L[j] + hi[j]) >> 1;
+            const bool act = L[j] < hi[j];
+            const bool right = sq_dist(q[j], buf[mid]) > sq_dist(q[j], buf[mid + k]);
+            L[j] = (act && right) ? mid + 1 : L[j];
+            hi[j] = (act && !right) ? mid : hi[j];
+        }
+    }
+}
+constexpr int kSingleBisectionFromK = 8;  // (k + 1 candidates: the refinement of the two-level search costs 2 log2(k + 1) reads)
+template <int NQ>
+__device__ __forceinline__ void window_starts_any(const double* buf, int k, int n, int M, const double (&q)[NQ], int (&L)[NQ]) {
+    if (k >= kSingleBisectionFromK) window_starts_n<NQ>(buf, k, M, q, L);  // (k is uniform over the launch)
+    else window_starts_two_level<NQ>(buf, k, n, M, q, L);
+}
+
 #ifndef SD_MEANQ
 #define SD_MEANQ 2
 #endif
@@ -432,37 +510,8 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
             // [L, L + k) with p - k <= L <= p: the smallest L of that range with rdist(L) <= rdist(L + k), log2(k + 1)
             // more steps of two reads (rdist is unimodal along xs).  With ties the separation test below sends the query
             // to the exact walk.
-            int lo[kMeanQ], hi[kMeanQ];
-            {
-                int pos[kMeanQ];
-#pragma unroll
-                for (int j = 0; j < kMeanQ; ++j) pos[j] = -1;  // index of the last value known to be < q
-#pragma unroll 1
-                for (int len = n; len > 1;) {
-                    int half = len >> 1;
-                    if ((half & 15) == 0) --half;
-                    len -= half;
-#pragma unroll
-                    for (int j = 0; j < kMeanQ; ++j) pos[j] += xs[pos[j] + half] < q[j] ? half : 0;
-                }
-#pragma unroll
-                for (int j = 0; j < kMeanQ; ++j) {
-                    const int p = pos[j] + 1 + (xs[pos[j] + 1] < q[j] ? 1 : 0);
-                    lo[j] = p - k > 0 ? p - k : 0;
-                    hi[j] = p < n - k ? p : n - k;
-                }
-            }
-#pragma unroll 1
-            for (int s = 0; s < nsteps; ++s) {
-#pragma unroll
-                for (int j = 0; j < kMeanQ; ++j) {
-                    const int mid = (lo[j] + hi[j]) >> 1;
-                    const bool act = lo[j] < hi[j];
-                    const bool right = sq_dist(q[j], xs[mid]) > sq_dist(q[j], xs[mid + k]);
-                    lo[j] = (act && right) ? mid + 1 : lo[j];
-                    hi[j] = (act && !right) ? mid : hi[j];
-                }
-            }
+            int lo[kMeanQ];
+            window_starts_any<kMeanQ>(xs, k, n, n - k > 0 ? n - k : 0, q, lo);  // (round 6: one bisection on xs[i] + xs[i + k] >= 2 q, see window_starts)
             // the statistics of one query at a time, as a rolled loop (its body is long: unrolled over the queries of the
             // thread it no longer fits the instruction cache); the query in turn sits in slot 0, the others move down
             unsigned hasm = 0u, okm = 0u;
@@ -738,7 +787,7 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
             for (int i0 = 0; i0 < kPhQ; i0 += 2) {
                 double q[2];
                 bool has[2], ok[2];
-                int lo[2], hi[2];
+                int lo[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     has[j] = (hasmask >> (i0 + j)) & 1u;
@@ -747,37 +796,7 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
                     if (active && has[j] && !ok[j]) atomicOr(&status[c], SDI_NONFINITE);
                     if (!ok[j]) q[j] = 0.0;
                 }
-                // position of the query among the sorted values (branch-free bisection; strides that are multiples of 16
-                // doubles are shortened by one: see the rank search in sd_bcsd_rs.hip), then the start of the window of k
-                // nearest values among the k + 1 candidates around it
-                int pos[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) pos[j] = -1;  // index of the last value known to be < q
-#pragma unroll 1
-                for (int len = n; len > 1;) {
-                    int half = len >> 1;
-                    if ((half & 15) == 0) --half;
-                    len -= half;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) pos[j] += buf[pos[j] + half] < q[j] ? half : 0;
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int p = pos[j] + 1 + (buf[pos[j] + 1] < q[j] ? 1 : 0);
-                    lo[j] = p - k > 0 ? p - k : 0;
-                    hi[j] = p < M ? p : M;
-                }
-#pragma unroll 1
-                for (int s = 0; s < nsteps; ++s) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int mid = (lo[j] + hi[j]) >> 1;
-                        const bool act = lo[j] < hi[j];
-                        const bool right = sq_dist(q[j], buf[mid]) > sq_dist(q[j], buf[mid + k]);
-                        lo[j] = (act && right) ? mid + 1 : lo[j];
-                        hi[j] = (act && !right) ? mid : hi[j];
-                    }
-                }
+                window_starts_any<2>(buf, k, n, M, q, lo);
                 Lw2[i0 >> 1] = (unsigned)lo[0] | ((unsigned)lo[1] << 16);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -1079,7 +1098,7 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
         for (int i0 = 0; i0 < kPhQ; i0 += 2) {
             double q[2];
             bool has[2], ok[2];
-            int lo[2], hi[2];
+            int lo[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 has[j] = tid + (i0 + j) * nthr < nq;
@@ -1091,34 +1110,7 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
                 if (has[j] && !ok[j]) atomicOr(&status[c], SDI_NONFINITE);
                 if (!ok[j]) q[j] = 0.0;
             }
-            int pos[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) pos[j] = -1;
-#pragma unroll 1
-            for (int len = n; len > 1;) {
-                int half = len >> 1;
-                if ((half & 15) == 0) --half;
-                len -= half;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) pos[j] += buf[pos[j] + half] < q[j] ? half : 0;
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int p = pos[j] + 1 + (buf[pos[j] + 1] < q[j] ? 1 : 0);
-                lo[j] = p - k > 0 ? p - k : 0;
-                hi[j] = p < M ? p : M;
-            }
-#pragma unroll 1
-            for (int s = 0; s < nsteps; ++s) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int mid = (lo[j] + hi[j]) >> 1;
-                    const bool act = lo[j] < hi[j];
-                    const bool right = sq_dist(q[j], buf[mid]) > sq_dist(q[j], buf[mid + k]);
-                    lo[j] = (act && right) ? mid + 1 : lo[j];
-                    hi[j] = (act && !right) ? mid : hi[j];
-                }
-            }
+            window_starts_any<2>(buf, k, n, M, q, lo);
             Lw2[i0 >> 1] = (unsigned)lo[0] | ((unsigned)lo[1] << 16);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
