@@ -376,11 +376,22 @@ __device__ __forceinline__ void window_starts_n(const double* buf, int k, int M,
         int half = len >> 1;
         if ((half & 15) == 0) --half;  // (strides that are multiples of 16 doubles pile the probes on two banks)
         len -= half;
+        // The reads of ALL the queries are issued before the first is consumed (sched_barrier): left alone, the compiler -- short
+        // of registers in these kernels -- reuses one pair of destination registers and serialises the queries inside a step,
+        // read, wait, compare, next query: one chain of LDS round trips in flight per thread, whatever NQ is.  That, not LDS
+        // bandwidth, bank conflicts or instruction count, is what bounded the search.
+        double a[NQ], b[NQ];
+        int t[NQ];
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            const int t = pos[j] + half;
-            pos[j] = buf[t] + buf[t + k] < q2[j] ? t : pos[j];
+            t[j] = pos[j] + half;
+            a[j] = buf[t[j]];
+            b[j] = buf[t[j] + k];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) pos[j] = a[j] + b[j] < q2[j] ? t[j] : pos[j];
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
@@ -401,8 +412,13 @@ __device__ __forceinline__ void window_starts_two_level(const double* buf, int k
         int half = len >> 1;
         if ((half & 15) == 0) --half;
         len -= half;
+        double a[NQ];
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) pos[j] += buf[pos[j] + half] < q[j] ? half : 0;
+        for (int j = 0; j < NQ; ++j) a[j] = buf[pos[j] + half];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) pos[j] += a[j] < q[j] ? half : 0;
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
@@ -414,14 +430,23 @@ __device__ __forceinline__ void window_starts_two_level(const double* buf, int k
     while ((1 << nsteps) < (k + 1 < M + 1 ? k + 1 : M + 1)) ++nsteps;
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
+        double a[NQ], b[NQ];
+        int mid[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {  // (all reads first: see window_starts_n)
+            mid[j] = (L[j] + hi[j]) >> 1;
+            a[j] = buf[mid[j]];
+            b[j] = buf[mid[j] + k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            const int mid = (L[j] + hi[j]) >> 1;
             const bool act = L[j] < hi[j];
-            const bool right = sq_dist(q[j], buf[mid]) > sq_dist(q[j], buf[mid + k]);
-            L[j] = (act && right) ? mid + 1 : L[j];
-            hi[j] = (act && !right) ? mid : hi[j];
+            const bool right = sq_dist(q[j], a[j]) > sq_dist(q[j], b[j]);
+            L[j] = (act && right) ? mid[j] + 1 : L[j];
+            hi[j] = (act && !right) ? mid[j] : hi[j];
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 constexpr int kSingleBisectionFromK = 8;  // (k + 1 candidates: the refinement of the two-level search costs 2 log2(k + 1) reads)
@@ -679,6 +704,13 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
 // With skip_prob the exceedance-probability column is not written: it is 1 wherever the prediction is not NaN
 // (gard.py:346) and the staging transpose fills it in.
 constexpr int kPhQ = 16;  // queries per thread and LDS generation (1024 threads: series up to 16 384 queries per pass)
+#ifndef SD_SEARCHQ
+#define SD_SEARCHQ 2
+#endif
+// queries a thread searches together: a query is a chain of dependent LDS round trips, and the phase is bound by the number of
+// chains in flight, not by LDS bandwidth or instruction issue
+constexpr int kSearchQ = SD_SEARCHQ;
+static_assert(kSearchQ % 2 == 0 && kPhQ % kSearchQ == 0, "queries are searched in groups that fill the 16-bit window-start pairs");
 
 // a wave-uniform double, pinned to scalar registers (the allocator otherwise keeps such values in vector registers and,
 // in this kernel, spills them)
@@ -784,22 +816,23 @@ __global__ void __launch_bounds__(1024) analog_f1_mean3_kernel(const double* __r
 #define SD_LW(i) ((int)(((i) & 1) ? (Lw2[(i) >> 1] >> 16) : (Lw2[(i) >> 1] & 0xffffu)))
             unsigned okmask = 0u, nanmask = 0u, walkmask = 0u;  // bit i: prefix-sum statistics / NaN output / exact walk
 #pragma unroll
-            for (int i0 = 0; i0 < kPhQ; i0 += 2) {
-                double q[2];
-                bool has[2], ok[2];
-                int lo[2];
+            for (int i0 = 0; i0 < kPhQ; i0 += kSearchQ) {
+                double q[kSearchQ];
+                bool has[kSearchQ], ok[kSearchQ];
+                int lo[kSearchQ];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < kSearchQ; ++j) {
                     has[j] = (hasmask >> (i0 + j)) & 1u;
                     q[j] = qv[i0 + j];
                     ok[j] = active && has[j] && sd_finite(q[j]);
                     if (active && has[j] && !ok[j]) atomicOr(&status[c], SDI_NONFINITE);
                     if (!ok[j]) q[j] = 0.0;
                 }
-                window_starts_any<2>(buf, k, n, M, q, lo);
-                Lw2[i0 >> 1] = (unsigned)lo[0] | ((unsigned)lo[1] << 16);
+                window_starts_any<kSearchQ>(buf, k, n, M, q, lo);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < kSearchQ; j += 2) Lw2[(i0 + j) >> 1] = (unsigned)lo[j] | ((unsigned)lo[j + 1] << 16);
+#pragma unroll
+                for (int j = 0; j < kSearchQ; ++j) {
                     const int i = i0 + j;
                     if (!has[j]) continue;
                     if (!ok[j]) {
@@ -1085,35 +1118,36 @@ __global__ void __launch_bounds__(1024) analog_f1_fused_kernel(const double* __r
         SD_TID();
         const double* qrow = Xq + c * Tq;
         const int nq = (int)Tq;  // (one pass: the host sends Tq <= kPhQ * 1024 here)
-        // (the queries of a thread are fetched two pairs ahead of their use instead of all at once: 8 registers instead of 32)
-        double qn[4];
+        // (the queries of a thread are fetched one group ahead of their use instead of all at once)
+        double qn[2 * kSearchQ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2 * kSearchQ; ++i) {
             const int j = tid + i * nthr;
             qn[i] = j < nq ? qrow[j] : 0.0;
         }
         unsigned Lw2[kPhQ / 2];
         unsigned okmask = 0u, nanmask = 0u, walkmask = 0u;
 #pragma unroll
-        for (int i0 = 0; i0 < kPhQ; i0 += 2) {
-            double q[2];
-            bool has[2], ok[2];
-            int lo[2];
+        for (int i0 = 0; i0 < kPhQ; i0 += kSearchQ) {
+            double q[kSearchQ];
+            bool has[kSearchQ], ok[kSearchQ];
+            int lo[kSearchQ];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < kSearchQ; ++j) {
                 has[j] = tid + (i0 + j) * nthr < nq;
                 q[j] = qn[j];
-                qn[j] = qn[j + 2];
-                const int jn = tid + (i0 + j + 4) * nthr;
-                qn[j + 2] = (i0 + j + 4 < kPhQ && jn < nq) ? qrow[jn] : 0.0;
+                qn[j] = qn[j + kSearchQ];
+                const int jn = tid + (i0 + j + 2 * kSearchQ) * nthr;
+                qn[j + kSearchQ] = (i0 + j + 2 * kSearchQ < kPhQ && jn < nq) ? qrow[jn] : 0.0;
                 ok[j] = has[j] && sd_finite(q[j]);
                 if (has[j] && !ok[j]) atomicOr(&status[c], SDI_NONFINITE);
                 if (!ok[j]) q[j] = 0.0;
             }
-            window_starts_any<2>(buf, k, n, M, q, lo);
-            Lw2[i0 >> 1] = (unsigned)lo[0] | ((unsigned)lo[1] << 16);
+            window_starts_any<kSearchQ>(buf, k, n, M, q, lo);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < kSearchQ; j += 2) Lw2[(i0 + j) >> 1] = (unsigned)lo[j] | ((unsigned)lo[j + 1] << 16);
+#pragma unroll
+            for (int j = 0; j < kSearchQ; ++j) {
                 const int i = i0 + j;
                 if (!has[j]) continue;
                 if (!ok[j]) {
