@@ -67,6 +67,7 @@ __device__ __forceinline__ int64_t first_cell(int64_t C, int64_t* step, int64_t*
 #include "sd_analog_epilogue.h"
 #include "sd_analog_f1.h"
 #include "sd_analog_fn.h"
+#include "sd_analog_topk.h"
 
 __global__ void __launch_bounds__(256) analog_status_public_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b,
                                                                    int64_t C, int32_t* __restrict__ outp) {

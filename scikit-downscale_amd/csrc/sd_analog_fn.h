@@ -161,17 +161,12 @@ __device__ __forceinline__ void heap_replace_root(double* sd, IT* si, int lane, 
 // scalar registers, or they spill into vector-register lanes inside the scan loop
 template <int F>
 constexpr int kScanG = F <= 2 ? 8 : 4;
-template <int F, typename IT, bool SORTED>
-__device__ __forceinline__ void scan_chunk(const double* __restrict__ P, int64_t T, const int32_t* __restrict__ PI, int j0, int nj,
-                                           int next_j0, double (&cur)[F][kScanG<F>], const double (&q)[F], double& tau, double* sd,
-                                           IT* si, int k, int lane, double* stage /* [F][64] */, int32_t* stage_i /* [64] */,
-                                           int ablate = 0, unsigned long long* dbg = nullptr) {
+// The chunk's points closer to the lane's query than tau (INCL: or as close), bit j = point j0 + j.  Full chunks take their
+// coordinates from `cur` (wave-uniform groups, see scan_chunk) and leave the first group of the chunk at next_j0 there.
+template <int F, bool INCL>
+__device__ __forceinline__ unsigned long long chunk_mask(const double* __restrict__ P, int64_t T, int j0, int nj, int next_j0,
+                                                         double (&cur)[F][kScanG<F>], const double (&q)[F], double tau) {
     constexpr int G = kScanG<F>;
-    double mine[F];
-    int32_t mine_i = 0;
-#pragma unroll
-    for (int f = 0; f < F; ++f) mine[f] = lane < nj ? P[(int64_t)f * T + j0 + lane] : 0.0;
-    if (SORTED) mine_i = lane < nj ? PI[j0 + lane] : 0;
     unsigned long long mask = 0ull;
     if (nj == 64) {
         double nxt[F][G];
@@ -190,7 +185,7 @@ __device__ __forceinline__ void scan_chunk(const double* __restrict__ P, int64_t
                     const double df = q[f] - cur[f][g];
                     d += df * df;
                 }
-                const bool hit = SORTED ? d <= tau : d < tau;
+                const bool hit = INCL ? d <= tau : d < tau;
                 mask |= hit ? (1ull << (jg + g)) : 0ull;
             }
 #pragma unroll
@@ -206,10 +201,24 @@ __device__ __forceinline__ void scan_chunk(const double* __restrict__ P, int64_t
                 const double df = q[f] - P[(int64_t)f * T + j0 + j];
                 d += df * df;
             }
-            const bool hit = SORTED ? d <= tau : d < tau;
+            const bool hit = INCL ? d <= tau : d < tau;
             mask |= hit ? (1ull << j) : 0ull;
         }
     }
+    return mask;
+}
+
+template <int F, typename IT, bool SORTED>
+__device__ __forceinline__ void scan_chunk(const double* __restrict__ P, int64_t T, const int32_t* __restrict__ PI, int j0, int nj,
+                                           int next_j0, double (&cur)[F][kScanG<F>], const double (&q)[F], double& tau, double* sd,
+                                           IT* si, int k, int lane, double* stage /* [F][64] */, int32_t* stage_i /* [64] */,
+                                           int ablate = 0, unsigned long long* dbg = nullptr) {
+    double mine[F];
+    int32_t mine_i = 0;
+#pragma unroll
+    for (int f = 0; f < F; ++f) mine[f] = lane < nj ? P[(int64_t)f * T + j0 + lane] : 0.0;
+    if (SORTED) mine_i = lane < nj ? PI[j0 + lane] : 0;
+    unsigned long long mask = chunk_mask<F, SORTED>(P, T, j0, nj, next_j0, cur, q, tau);
     if (ablate & 1) mask = 0ull;  // (timing experiments: no insertions)
     if (__builtin_amdgcn_ballot_w64(mask != 0ull) == 0ull) return;  // (the usual case far from the queries)
     __syncthreads();  // one wave per workgroup: orders the LDS traffic of the previous chunk's insertions
@@ -377,14 +386,17 @@ __global__ void __launch_bounds__(64) analog_slab_predict_kernel(int mode, const
                                                                  const double* __restrict__ Xc, const double* __restrict__ yc,
                                                                  const double* __restrict__ ps, const int32_t* __restrict__ pi,
                                                                  const int32_t* __restrict__ fit_status, int32_t* status,
-                                                                 PredictArgs pa, int ablate, unsigned long long* dbg) {
+                                                                 PredictArgs pa, int ablate, unsigned long long* dbg,
+                                                                 const int32_t* __restrict__ worklist) {
     typedef uint16_t IT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int k = pa.k, lane = threadIdx.x;
     double* sd = reinterpret_cast<double*>(smem_raw);   // [k][64]
     IT* si = reinterpret_cast<IT*>(sd + (size_t)k * 64);  // [k][64]
-    const int64_t cl = blockIdx.x / nbatch, c = c_base + cl;
-    const int64_t slot = (int64_t)(blockIdx.x % nbatch) * 64 + lane;
+    // worklist: the (cell, query batch) pairs analog_slab_topk_kernel handed back (sd_analog_topk.h), one per workgroup
+    const unsigned bid = worklist != nullptr ? (unsigned)worklist[blockIdx.x] : blockIdx.x;
+    const int64_t cl = bid / nbatch, c = c_base + cl;
+    const int64_t slot = (int64_t)(bid % nbatch) * 64 + lane;
     const bool active = fit_status[c] == 0, has_q = slot < Tq;
     const int64_t tq = has_q ? qi[cl * Tq + slot] : 0;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
@@ -563,13 +575,14 @@ __global__ void __launch_bounds__(256) analog_slab_key_kernel(const double* __re
     }
 }
 
+// worklist (device, nwork entries): only the listed (cell, query batch) pairs (the hand-backs of analog_slab_topk_kernel)
 template <int F>
 int launch_slab(sd_ctx* ctx, int mode, const sd_analog_state* st, const double* qc, const int32_t* qi, int64_t cb, int64_t cc,
-                int64_t Tq, int32_t* status_p, const PredictArgs& pa) {
+                int64_t Tq, int32_t* status_p, const PredictArgs& pa, const int32_t* worklist = nullptr, int64_t nwork = 0) {
     const size_t lds = bf2_lds_bytes(pa.k, F, sizeof(uint16_t));
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_slab_predict_kernel<F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t nbatch = (Tq + 63) / 64, nblocks = cc * nbatch;
+    const int64_t nbatch = (Tq + 63) / 64, nblocks = worklist != nullptr ? nwork : cc * nbatch;
     const char* eab = sd_dev_env("SD_ANALOG_ABLATE");  // timing experiments only (results are wrong): 1 no insertions, 2 no epilogue
     const int ablate = eab ? atoi(eab) : 0;
     sd_scratch dbg;  // 4: count scanned chunks and insertion rounds, printed per launch
@@ -579,7 +592,7 @@ int launch_slab(sd_ctx* ctx, int mode, const sd_analog_state* st, const double* 
     }
     SD_LAUNCH(ctx, "analog_slab_predict_kernel", (analog_slab_predict_kernel<F>), dim3((unsigned)nblocks), dim3(64), lds, mode, qc,
               qi, cb, Tq, st->T, (int)nbatch, (const double*)st->X, (const double*)st->y, (const double*)st->ps,
-              (const int32_t*)st->xi, (const int32_t*)st->status, status_p, pa, ablate, dbg.as<unsigned long long>());
+              (const int32_t*)st->xi, (const int32_t*)st->status, status_p, pa, ablate, dbg.as<unsigned long long>(), worklist);
     if (ablate & 4) {
         unsigned long long h[2];
         SD_HIP(hipMemcpyAsync(h, dbg.p, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -587,59 +600,5 @@ int launch_slab(sd_ctx* ctx, int mode, const sd_analog_state* st, const double* 
         fprintf(stderr, "[slab] waves %lld: chunks/wave %.1f insertion rounds/wave %.1f\n", (long long)nblocks,
                 (double)h[0] / (double)nblocks, (double)h[1] / (double)nblocks);
     }
-    return SD_OK;
-}
-
-// F > 1 with the feature-0 sorted copy: queries go cell-major, are sorted by feature 0 per cell, and every wave scans
-// only the slab of training points its 64 neighbouring queries can reach (analog_slab_predict_kernel)
-int predict_slab(sd_ctx* ctx, int mode, const sd_analog_state* st, const double* Xq, int64_t ld, int64_t Tq, int32_t* status_p,
-                 const PredictArgs& pa) {
-    const int F = st->F;
-    const int64_t C = st->C, nbatch = (Tq + 63) / 64;
-    int64_t chunk = 4096;
-    while (chunk > 1 && chunk * nbatch >= ((int64_t)1 << 31)) chunk >>= 1;
-    const int64_t cc_max = C < chunk ? C : chunk;
-    const int Kq = sort2_width(Tq, ctx->lds_max);
-    // classes of the query order (analog_slab_s2_kernel); a short series would only get waves that straddle classes
-    const char* ecl = sd_dev_env("SD_ANALOG_SLAB_CLASSES");
-    int nclass = ecl ? atoi(ecl) : (int)std::min<int64_t>(8, Tq / 512);
-    nclass = nclass < 1 ? 1 : (nclass > 8 ? 8 : nclass);
-    sd_scratch qc, qs, qi, key;
-    if (nclass > 1) SD_HIP(key.alloc(ctx, sizeof(double) * (size_t)Tq * cc_max));
-    SD_HIP(qc.alloc(ctx, sizeof(double) * (size_t)Tq * F * cc_max));
-    SD_HIP(qs.alloc(ctx, sizeof(double) * (size_t)Tq * cc_max));
-    SD_HIP(qi.alloc(ctx, sizeof(int32_t) * (size_t)Tq * cc_max));
-    for (int64_t cb = 0; cb < C; cb += chunk) {
-        const int64_t cc = C - cb < chunk ? C - cb : chunk;
-        dim3 tgrid((unsigned)((cc + 31) / 32), (unsigned)((Tq + 31) / 32));
-        for (int f = 0; f < F; ++f)
-            SD_LAUNCH(ctx, "analog_transpose_kernel", analog_transpose_kernel, tgrid, dim3(256), 0, Xq + cb, ld, Tq, F, f, cc,
-                      qc.as<double>(), status_p + cb, 0);
-        const int nbk = (int)std::min<int64_t>(cc, (int64_t)ctx->cu_count * 8);
-        Sort2Args a{qc.as<double>(), (int64_t)F * Tq, 1, nullptr, Tq, cc, qs.as<double>(), qi.as<int32_t>(),
-                    nullptr, nullptr, nullptr};
-        if (nclass > 1) {
-            SD_LAUNCH(ctx, "analog_slab_s2_kernel", analog_slab_s2_kernel, dim3(nbk), dim3(256), 0, (const double*)qc.p, Tq, F, cc,
-                      key.as<double>());
-            a.X = key.as<double>();
-            a.x_stride = Tq;
-            SD_TRY(launch_sort2_width(ctx, Kq, a));  // qs = sorted s2 (class thresholds)
-            SD_LAUNCH(ctx, "analog_slab_key_kernel", analog_slab_key_kernel, dim3(nbk), dim3(256), 0, (const double*)qc.p,
-                      (const double*)qs.p, Tq, F, cc, nclass, key.as<double>());
-        }
-        SD_TRY(launch_sort2_width(ctx, Kq, a));  // qi = query order
-        const double* q = qc.as<double>();
-        const int32_t* qix = qi.as<int32_t>();
-        switch (F) {
-            case 2: SD_TRY(launch_slab<2>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa)); break;
-            case 3: SD_TRY(launch_slab<3>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa)); break;
-            case 4: SD_TRY(launch_slab<4>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa)); break;
-            case 5: SD_TRY(launch_slab<5>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa)); break;
-            case 6: SD_TRY(launch_slab<6>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa)); break;
-            case 7: SD_TRY(launch_slab<7>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa)); break;
-            default: SD_TRY(launch_slab<8>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa)); break;
-        }
-    }
-    SD_HIP(hipStreamSynchronize(ctx->stream));  // the staging buffers go back to the block cache at scope exit
     return SD_OK;
 }

@@ -216,6 +216,11 @@ def test_pure_analog_constant_windows_full_length(ctx, case):
     (4, 200, 65, 2, 200, "normal"),      # k == T: every point is a neighbour, both sides run to the ends
     (2, 64, 64, 2, 5, "normal"),         # one chunk
     (3, 200, 100, 4500, 4, "normal"),    # more cells than one staging chunk
+    (3, 4000, 3000, 2, 30, "duplicates"),  # every training point four times: ties on the k-th distance (candidate lists hand back)
+    (3, 3000, 1000, 2, 30, "huge"),      # squares beyond the float32 range: the pre-filter does not apply
+    (3, 3000, 1000, 2, 29, "offset"),    # a large common offset: a coarse float32 image of the points, the selection stays exact
+    (2, 3000, 700, 2, 31, "normal"),     # k above the candidate-list kernel's limit
+    (5, 2500, 900, 2, 30, "normal"),
 ])
 def test_slab_search_matches_full_scan(ctx, dev_ctx, monkeypatch, F, T, Tq, C, k, data):
     """F > 1: the feature-0 slab search (training points and queries sorted by feature 0, scan ends when the axis
@@ -225,6 +230,12 @@ def test_slab_search_matches_full_scan(ctx, dev_ctx, monkeypatch, F, T, Tq, C, k
     X, Xq = rng.standard_normal((T, F, C)), 1.2 * rng.standard_normal((Tq, F, C))
     if data == "quantized":
         X, Xq = np.round(X * 4) / 4, np.round(Xq * 4) / 4  # dyadic grid: squared distances are exact
+    if data == "duplicates":
+        X[T // 4:] = np.concatenate([X[:T // 4]] * 3)
+    if data == "huge":
+        X, Xq = X * 1e17, Xq * 1e17
+    if data == "offset":
+        X, Xq = X + 3.0e5, Xq + 3.0e5
     y = rng.standard_normal((T, C))
     Xq[3, F - 1, 0] = np.nan  # one query without neighbours
     monkeypatch.delenv("SD_ANALOG_NOSLAB", raising=False)
@@ -248,6 +259,11 @@ def test_slab_search_matches_full_scan(ctx, dev_ctx, monkeypatch, F, T, Tq, C, k
     assert np.array_equal(inds[ok], inds0[ok]) and np.array_equal(inds[3, :, 1:], inds0[3, :, 1:])
     assert np.array_equal(dist[ok], dist0[ok])
     assert np.array_equal(out[ok], out0[ok]) and np.isnan(out[3, :, 0]).all()
+    # candidate lists pruned by the register network (k <= 30) against the LDS heap of the same slab scan
+    monkeypatch.setenv("SD_ANALOG_HEAP", "1")
+    outh, _, indsh, disth = dev_ctx.analog_predict(std, Xq, k, 3, want_neighbors=True)
+    monkeypatch.delenv("SD_ANALOG_HEAP")
+    assert np.array_equal(indsh[ok], inds[ok]) and np.array_equal(disth[ok], dist[ok]) and np.array_equal(outh[ok], out[ok])
     for c in range(min(C, 2)):
         d, i = ao.knn(X[:, :, c], Xq[ok][:, :, c], k)
         assert np.array_equal(inds[ok][:, :, c], i)
