@@ -20,6 +20,7 @@
 
 #include "sd_internal.h"
 #include "sd_sortnet.h"
+#include "sd_wave.h"
 
 struct sd_qm_state {
     sd_ctx* ctx = nullptr;
@@ -98,6 +99,123 @@ __global__ void __launch_bounds__(1024) qm_sort_kernel(double* __restrict__ data
         __syncthreads();
         sdsort::block_merge_sort<K>(v, buf, np, xch, tid, nthr);
         for (int i = tid; i < n; i += nthr) x[i] = buf[i];
+    }
+}
+
+
+// ---- fit, tile-shaped first stage (round 6) -----------------------------------------------------------------------------
+// qm_tile_runs_kernel<K>: one 512-thread workgroup = 8 adjacent cells x one chunk of 64 * K consecutive time steps of ONE
+// time-major field, read as 64-byte row fragments (the geometry of the BCSD kernels and of analog_tile_sort_kernel, sd_wave.h).
+// It replaces the staging transpose (mask / finite bookkeeping included) and the first six rounds of qm_sort_kernel: while
+// the tile is on chip every wave sorts its cell's chunk (sdw::sort_segment) and the sorted runs go out cell-major, 512
+// consecutive bytes per wave store.  qm_merge_runs_kernel<K> -- one 1 024-thread workgroup per cell -- then only merges the
+// at most 16 runs (sdsort::block_merge_rounds from round 6).  np.sort needs no index: plain float64 keys, pads = +inf.
+// Non-finite samples sort as 0 (their cell is flagged and answers NaN; NaNs must not enter the min / max networks).
+template <int K>
+__global__ void __launch_bounds__(sdw::kThreads, 4) qm_tile_runs_kernel(const double* __restrict__ X, int64_t ld, int64_t T, int64_t C,
+                                                                        int nchunks, double* __restrict__ runs, int64_t runs_stride,
+                                                                        int32_t* status, int set_mask) {
+    using namespace sdw;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int CHUNK = kWave * K;
+    constexpr int NR = (CHUNK + kRowsPerPass - 1) / kRowsPerPass;
+    constexpr int RS = CHUNK + 2 + ((4 - (CHUNK + 2) % 4) + 2) % 4;  // row stride: >= CHUNK + 1 slots, RS % 4 == 2
+    double* const tile = reinterpret_cast<double*>(smem_raw) + kHeadDoubles;
+    const int64_t ntiles = (C + kW - 1) / kW;
+    int64_t tile_id;
+    int q;
+    xcd_tile_of_block(blockIdx.x, ntiles, &tile_id, &q);
+    if (tile_id >= ntiles || q >= nchunks) return;
+    const int64_t c0 = tile_id * kW;
+    const int64_t r0 = (int64_t)q * CHUNK;
+    const int nq = (int)(T - r0 < CHUNK ? T - r0 : CHUNK);  // valid rows of this chunk (> 0)
+    const int tid = tid_now();
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave;
+    const int cp = tid & 3, rr = tid >> 2;
+    const int64_t cpair = c0 + 2 * cp;
+    const bool vec = (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && cpair + 1 < C;
+    double x0[NR], x1[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int r = rr + k * kRowsPerPass;
+        const int64_t row = r0 + (r < nq ? r : 0);
+        const double* px = X + row * ld + cpair;
+        if (vec) {
+            const double2 v = *reinterpret_cast<const double2*>(px);
+            x0[k] = v.x;
+            x1[k] = v.y;
+        } else {
+            x0[k] = cpair < C ? px[0] : 0.0;
+            x1[k] = cpair + 1 < C ? px[1] : 0.0;
+        }
+    }
+    {
+        double* d0 = tile + (2 * cp) * RS;
+        double* d1 = d0 + RS;
+        int bits0 = 0, bits1 = 0;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = rr + k * kRowsPerPass;
+            if (r < nq) {
+                if (set_mask && r0 + r == 0) {  // core.py:35-37: the first sample of X is NaN
+                    bits0 |= x0[k] != x0[k] ? SDI_MASKED : 0;
+                    bits1 |= x1[k] != x1[k] ? SDI_MASKED : 0;
+                }
+                const bool f0 = qm_finite(x0[k]), f1 = qm_finite(x1[k]);
+                bits0 |= f0 ? 0 : SDI_NONFINITE;
+                bits1 |= f1 ? 0 : SDI_NONFINITE;
+                d0[r] = f0 ? x0[k] : 0.0;
+                d1[r] = f1 ? x1[k] : 0.0;
+            }
+        }
+        if (bits0 && cpair < C) atomicOr(&status[cpair], bits0);
+        if (bits1 && cpair + 1 < C) atomicOr(&status[cpair + 1], bits1);
+    }
+    __syncthreads();
+    const int64_t c = c0 + wave;
+    double* const row = tile + wave * RS;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double v[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const int jl = K * lane + i;  // (lane stride K is odd: conflict-free)
+        v[i] = jl < nq ? row[jl] : inf;
+    }
+    wave_fence();
+    sort_segment<K>(v, row, CHUNK, lane);  // every slot of the chunk is an element: pads sort behind the data
+    if (c < C) {
+        double* dst = runs + c * runs_stride + r0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) dst[lane + i * kWave] = row[lane + i * kWave];
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(1024) qm_merge_runs_kernel(const double* __restrict__ runs, int np, int64_t T, int64_t C,
+                                                             double* __restrict__ xs /* [C][T] */) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* buf = reinterpret_cast<double*>(smem_raw);  // np + 1 doubles
+    int* xch = reinterpret_cast<int*>(buf + np + 1);     // nthr + 1 ints
+    const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const double* rc = runs + c * (int64_t)np;
+        __syncthreads();
+        double kv[K + 1];
+#pragma unroll
+        for (int t2 = 0; t2 <= K; ++t2) {
+            const int i = tid + t2 * nthr;
+            kv[t2] = i < np ? rc[i] : inf;
+        }
+#pragma unroll
+        for (int t2 = 0; t2 <= K; ++t2) {
+            const int i = tid + t2 * nthr;
+            if (i <= np) buf[i] = kv[t2];
+        }
+        __syncthreads();
+        sdsort::block_merge_rounds<K>(buf, np, xch, tid, nthr, 6);
+        double* dst = xs + c * T;
+        for (int i = tid; i < n; i += nthr) dst[i] = buf[i];
     }
 }
 
@@ -184,6 +302,21 @@ __global__ void __launch_bounds__(1024) qm_rank_kernel(const double* __restrict_
 constexpr double kAlpha = 0.4, kBeta = 0.4;
 __device__ __forceinline__ double pp_denom(int n) { return ((double)n + 1.0 - kAlpha) - kBeta; }
 __device__ __forceinline__ double pp_at(int i, double denom) { return ((double)(i + 1) - kAlpha) / denom; }
+// The same quotient without the division (12 instructions, five of them quarter rate; qm_map_kernel needs ~8 per sample and was bound
+// by them): q0 = a * r, q = q0 + (a - q0 * d) * r with r = RN(1 / d) and both products fused -- Markstein's correction step, which
+// returns the correctly rounded quotient whenever q0 is within an ulp of it.  Not taken on trust: qm_ppcheck_kernel compares it with
+// the division for every position of the grid (i = 0 .. n-1, the only arguments the kernels ever pass) before a launch uses it.
+template <bool FAST>
+__device__ __forceinline__ double ppq(int i, double denom, double rden) {
+    const double a = (double)(i + 1) - kAlpha;
+    if (!FAST) return a / denom;
+    const double q0 = a * rden;
+    return __builtin_fma(__builtin_fma(-q0, denom, a), rden, q0);
+}
+__global__ void __launch_bounds__(256) qm_ppcheck_kernel(int n, double denom, double rden, int32_t* __restrict__ mismatch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && __double_as_longlong(ppq<true>(i, denom, rden)) != __double_as_longlong(ppq<false>(i, denom, rden))) atomicOr(mismatch, 1);
+}
 
 constexpr double kSyntheticMin = -1e20, kSyntheticMax = 1e20;  // quantile.py:17-18
 // value of the least-squares line through (pp[first + i], f[first + i]), i < e, at position x0: sklearn's
@@ -232,88 +365,287 @@ __device__ __forceinline__ double interp_on_grid(double p, int n, double denom, 
     return slope * (p - x0) + f[j];
 }
 
-// model: 0 QuantileMappingReressor, 1 EquidistantCdfMatcher 'difference', 2 'ratio'.  One workgroup per cell;
-// QMR keeps the cell's sorted fit X in LDS for the value -> position search.
+// interp_on_grid in two steps, so that the table reads of several samples can be in flight together: the bracket ...
+constexpr int kMapQ = 4;
+template <bool FAST>
+__device__ __forceinline__ int grid_bracket(double p, int n, double denom, double rden) {
+    const double pc = p > 0.0 ? (p < 2.0 ? p : 2.0) : 0.0;  // (tail positions reach +-1e20 / +-inf: first / last interval)
+    int j = (int)floor(pc * denom + kAlpha) - 1;
+    j = j < 0 ? 0 : (j > n - 2 ? n - 2 : j);
+    while (j > 0 && ppq<FAST>(j, denom, rden) > p) --j;      // guard the analytic index by one step either way
+    while (j < n - 2 && ppq<FAST>(j + 1, denom, rden) <= p) ++j;
+    return j;
+}
+// ... and the value, given fa = f[j], fb = f[j + 1] of j = grid_bracket(p): for p at or beyond the ends of the grid the bracket is
+// the first / last interval, whose outer value is the one interp_on_grid's clamped branches read
+template <bool FAST>
+__device__ __forceinline__ double interp_on_grid_with(double p, int n, double denom, double rden, int j, double fa, double fb, bool ext_lo,
+                                                      double f_lo, bool ext_hi, double f_hi) {
+    if (p <= ppq<FAST>(0, denom, rden)) {  // left clamp / exact hit of the first node (j == 0: fa = f[0])
+        if (!ext_lo || p == ppq<FAST>(0, denom, rden)) return fa;
+        if (p <= kSyntheticMin) return f_lo;
+        const double slope = (fa - f_lo) / (ppq<FAST>(0, denom, rden) - kSyntheticMin);
+        return slope * (p - kSyntheticMin) + f_lo;
+    }
+    if (p >= ppq<FAST>(n - 1, denom, rden)) {  // (j == n - 2: fb = f[n - 1])
+        if (!ext_hi || p == ppq<FAST>(n - 1, denom, rden)) return fb;
+        if (p >= kSyntheticMax) return f_hi;
+        const double slope = (f_hi - fb) / (kSyntheticMax - ppq<FAST>(n - 1, denom, rden));
+        return slope * (p - ppq<FAST>(n - 1, denom, rden)) + fb;
+    }
+    const double x0 = ppq<FAST>(j, denom, rden);
+    if (x0 == p) return fa;
+    const double slope = (fb - fa) / (ppq<FAST>(j + 1, denom, rden) - x0);
+    return slope * (p - x0) + fa;
+}
+
+// model: 0 QuantileMappingReressor, 1 EquidistantCdfMatcher 'difference', 2 'ratio'.  One workgroup per cell, the cell's two
+// sorted tables staged through ONE LDS array, one after the other (round 6; the round-3 kernel kept xs in LDS and read the
+// brackets of ys -- EDCDF: of xs and ys -- from memory, two to four scattered 8-byte requests per sample, one sample in
+// flight per thread):
+//   generation 1, LDS = xs:  QMR  the value -> position search and p = interp(x, xs, pp);  EDCDF  x_train = interp(p, pp, xs)
+//   generation 2, LDS = ys:  y = interp(p, pp, ys) and the result
+// A thread carries one number per sample from the first generation to the second (p or x_train), kMapPer samples per thread
+// and pass (QMR 16: one pass for series of up to 16 384 samples; EDCDF 8: it holds ranks and samples as well), kMapQ samples in flight at a time: the reads of a step are issued
+// before its compares (sched_barrier: see window_starts_n in sd_analog_f1.h).
+// a cell's table -> LDS, eight requests per thread in flight (a plain copy loop pays one memory round trip per element: the
+// sixteen waves of the workgroup all wait at the same time, nothing hides it)
+__device__ __forceinline__ void fill_table(double* __restrict__ dst, const double* __restrict__ src, int n, int tid, int nthr) {
+#pragma unroll 1
+    for (int base = 0; base < n; base += 8 * nthr) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * nthr + tid;
+            v[u] = i < n ? src[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * nthr + tid;
+            if (i < n) dst[i] = v[u];
+        }
+    }
+}
+#ifdef SD_DEV
+__device__ long long sd_qm_trace[8 * 8];  // development library: phase clocks of the first 8 cells of workgroup 0 (SD_QM_TRACE)
+#define SD_QSTAMP(slot)                                                                                                        \
+    do {                                                                                                                       \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && traced < 8) sd_qm_trace[traced * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define SD_QSTAMP(slot) do { } while (0)
+#endif
+// a wave-uniform double, pinned to scalar registers (the allocator otherwise keeps the cell's constants in vector registers)
+__device__ __forceinline__ double qm_uniform(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// values of the tail lines at the synthetic end points (quantile.py:366-385) of every cell: tails[c] = (vx_lo, vy_lo, vx_hi, vy_hi)
+__global__ void __launch_bounds__(256) qm_tails_kernel(int mode, int n_end, const double* __restrict__ xs_all, const double* __restrict__ ys_all,
+                                                       int64_t T, int64_t C, double* __restrict__ tails) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int n = (int)T;
+    const double dn = pp_denom(n);
+    const int e = n_end < n ? n_end : n;
+    const double* xs = xs_all + c * T;
+    const double* ys = ys_all + c * T;
+    const bool ext_lo = (mode & SD_EXTRAP_MIN) != 0, ext_hi = (mode & SD_EXTRAP_MAX) != 0;
+    tails[c * 4 + 0] = ext_lo ? ols_value_at(xs, 0, e, dn, kSyntheticMin) : 0.0;
+    tails[c * 4 + 1] = ext_lo ? ols_value_at(ys, 0, e, dn, kSyntheticMin) : 0.0;
+    tails[c * 4 + 2] = ext_hi ? ols_value_at(xs, n - e, e, dn, kSyntheticMax) : 0.0;
+    tails[c * 4 + 3] = ext_hi ? ols_value_at(ys, n - e, e, dn, kSyntheticMax) : 0.0;
+}
+
+template <bool QMR, int kMapPer, bool FAST>
 __global__ void __launch_bounds__(1024) qm_map_kernel(int model, int mode, int n_end, const double* __restrict__ qc /* [C][Tp] */,
                                                       const int32_t* __restrict__ rank /* [C][Tp] or null */,
                                                       const double* __restrict__ xs_all, const double* __restrict__ ys_all,
-                                                      int64_t T, int64_t Tp, int64_t C, double* __restrict__ oc /* [C][Tp] */) {
+                                                      int64_t T, int64_t Tp64, int64_t C, double* __restrict__ oc /* [C][Tp] */,
+                                                      double rdn_in, double rdm_in, const double* __restrict__ tails /* [C][4] or null */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* xl = reinterpret_cast<double*>(smem_raw);  // QMR: n sorted fit values
-    const int n = (int)T, tid = threadIdx.x, nthr = blockDim.x;
-    const double dn = pp_denom(n), dm = pp_denom((int)Tp);
+    double* xl = reinterpret_cast<double*>(smem_raw);  // n table values: xs, then ys
+    const int n = (int)T, Tp = (int)Tp64, tid = threadIdx.x, nthr = blockDim.x;
+    const double dn = qm_uniform(pp_denom(n)), dm = qm_uniform(pp_denom(Tp));
+    const double rdn = qm_uniform(rdn_in), rdm = qm_uniform(rdm_in);  // RN(1 / dn), RN(1 / dm) from the host
+    const double pp_first = qm_uniform(ppq<FAST>(0, dn, rdn)), pp_last = qm_uniform(ppq<FAST>(n - 1, dn, rdn));
+    static_assert(kMapPer % kMapQ == 0, "whole batches");
+#ifdef SD_DEV
+    int traced = 0;
+#endif
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
-        const double* xs = xs_all + c * T;
-        const double* ys = ys_all + c * T;
-        __syncthreads();
-        if (model == 0)
-            for (int i = tid; i < n; i += nthr) xl[i] = xs[i];
-        __syncthreads();
-        const double x_min = xs[0], x_max = xs[n - 1], y_min = ys[0], y_max = ys[n - 1];
+        SD_QSTAMP(0);
+        const double* __restrict__ xs = xs_all + c * T;
+        const double* __restrict__ ys = ys_all + c * T;
+        const double* __restrict__ qrow = qc + c * Tp64;
+        const int32_t* __restrict__ rrow = QMR ? nullptr : rank + c * Tp64;
+        double* __restrict__ orow = oc + c * Tp64;
+        const double x_min = qm_uniform(xs[0]), x_max = qm_uniform(xs[n - 1]), y_min = qm_uniform(ys[0]), y_max = qm_uniform(ys[n - 1]);
         // synthetic end points of the extended CDFs (quantile.py:366-385); every thread computes the same four numbers
         const bool ext_lo = (mode & SD_EXTRAP_MIN) != 0, ext_hi = (mode & SD_EXTRAP_MAX) != 0, one_to_one = (mode & SD_EXTRAP_1TO1) != 0;
-        const int e = n_end < n ? n_end : n;
-        const double vx_lo = ext_lo ? ols_value_at(xs, 0, e, dn, kSyntheticMin) : 0.0, vy_lo = ext_lo ? ols_value_at(ys, 0, e, dn, kSyntheticMin) : 0.0;
-        const double vx_hi = ext_hi ? ols_value_at(xs, n - e, e, dn, kSyntheticMax) : 0.0, vy_hi = ext_hi ? ols_value_at(ys, n - e, e, dn, kSyntheticMax) : 0.0;
-        for (int64_t tq = tid; tq < Tp; tq += nthr) {
-            const double x = qc[c * Tp + tq];
-            double res;
-            if (model == 0) {
-                // p = np.interp(x, xs, pp): j = last index with xs[j] <= x
-                double p;
-                if (x < x_min) {
-                    if (ext_lo) {  // bracket (synthetic node, first value); below the synthetic node: left = -inf (quantile.py:245)
-                        // (tied end points give a level tail line: vx_lo == x_min, every x < x_min is "below the node")
-                        if (x < vx_lo || !(x_min > vx_lo)) {
-                            p = -__builtin_inf();
-                        } else {
-                            const double slope = (pp_at(0, dn) - kSyntheticMin) / (x_min - vx_lo);
-                            p = slope * (x - vx_lo) + kSyntheticMin;
-                        }
-                    } else {
-                        p = pp_at(0, dn);
+        (void)n_end;  // (qm_tails_kernel has worked the tail lines out: 80 dependent memory round trips per cell if every thread does)
+        const double vx_lo = qm_uniform(ext_lo ? tails[c * 4 + 0] : 0.0), vy_lo = qm_uniform(ext_lo ? tails[c * 4 + 1] : 0.0);
+        const double vx_hi = qm_uniform(ext_hi ? tails[c * 4 + 2] : 0.0), vy_hi = qm_uniform(ext_hi ? tails[c * 4 + 3] : 0.0);
+        for (int pass0 = 0; pass0 < Tp; pass0 += nthr * kMapPer) {
+            // the thread's samples (EDCDF: their ranks in the new series) are requested before the table: one round trip for both
+            double xq[kMapPer];
+            int rk[kMapPer];
+#pragma unroll
+            for (int i = 0; i < kMapPer; ++i) {
+                const int tq = pass0 + i * nthr + tid;
+                if (QMR) xq[i] = tq < Tp ? qrow[tq] : x_min;
+                else rk[i] = tq < Tp ? rrow[tq] : 0;
+            }
+            SD_QSTAMP(1);
+            __syncthreads();  // (the previous pass / cell has left the LDS array)
+            fill_table(xl, xs, n, tid, nthr);
+            __syncthreads();
+            SD_QSTAMP(2);
+            double carry[kMapPer];  // QMR: p; EDCDF: x_train
+#pragma unroll
+            for (int b0 = 0; b0 < kMapPer; b0 += kMapQ) {
+                if (QMR) {
+                    double x[kMapQ];
+                    int pos[kMapQ];  // last index known to hold a value <= x
+#pragma unroll
+                    for (int i = 0; i < kMapQ; ++i) {
+                        x[i] = xq[b0 + i];
+                        pos[i] = -1;
                     }
-                } else if (x >= x_max) {
-                    if (ext_hi && x > x_max) {
-                        if (x > vx_hi || !(vx_hi > x_max)) {
-                            p = __builtin_inf();
-                        } else {
-                            const double slope = (kSyntheticMax - pp_at(n - 1, dn)) / (vx_hi - x_max);
-                            p = slope * (x - x_max) + pp_at(n - 1, dn);
-                        }
-                    } else {
-                        p = pp_at(n - 1, dn);
-                    }
-                } else {
-                    int pos = -1;  // last index known to hold a value <= x
+#pragma unroll 1
                     for (int len = n; len > 1;) {
                         int half = len >> 1;
-                        if ((half & 15) == 0) --half;
+                        if ((half & 15) == 0) --half;  // keep the probe strides off the LDS bank period
                         len -= half;
-                        pos += xl[pos + half] <= x ? half : 0;
+                        double a[kMapQ];
+#pragma unroll
+                        for (int i = 0; i < kMapQ; ++i) a[i] = xl[pos[i] + half];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < kMapQ; ++i) pos[i] += a[i] <= x[i] ? half : 0;
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    const int j = pos + (xl[pos + 1] <= x ? 1 : 0);  // in [0, n-2] here
-                    const double x0 = xl[j];
-                    if (x0 == x) {
-                        p = pp_at(j, dn);
-                    } else {
-                        const double slope = (pp_at(j + 1, dn) - pp_at(j, dn)) / (xl[j + 1] - x0);
-                        p = slope * (x - x0) + pp_at(j, dn);
+                    double xa[kMapQ], xb[kMapQ];
+                    int jx[kMapQ];
+#pragma unroll
+                    for (int i = 0; i < kMapQ; ++i) {
+                        const double nx = xl[pos[i] + 1 < n ? pos[i] + 1 : n - 1];
+                        int j = pos[i] + (nx <= x[i] ? 1 : 0);
+                        j = j < 0 ? 0 : (j > n - 2 ? n - 2 : j);  // (in [0, n-2] already for a sample inside the fitted range)
+                        jx[i] = j;
                     }
+#pragma unroll
+                    for (int i = 0; i < kMapQ; ++i) {
+                        xa[i] = xl[jx[i]];
+                        xb[i] = xl[jx[i] + 1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < kMapQ; ++i) {
+                        // p = np.interp(x, xs, pp): j = last index with xs[j] <= x
+                        const double xv = x[i];
+                        double pv;
+                        if (xv < x_min) {
+                            if (ext_lo) {  // bracket (synthetic node, first value); below the synthetic node: left = -inf (quantile.py:245)
+                                // (tied end points give a level tail line: vx_lo == x_min, every x < x_min is "below the node")
+                                if (xv < vx_lo || !(x_min > vx_lo)) {
+                                    pv = -__builtin_inf();
+                                } else {
+                                    const double slope = (pp_first - kSyntheticMin) / (x_min - vx_lo);
+                                    pv = slope * (xv - vx_lo) + kSyntheticMin;
+                                }
+                            } else {
+                                pv = pp_first;
+                            }
+                        } else if (xv >= x_max) {
+                            if (ext_hi && xv > x_max) {
+                                if (xv > vx_hi || !(vx_hi > x_max)) {
+                                    pv = __builtin_inf();
+                                } else {
+                                    const double slope = (kSyntheticMax - pp_last) / (vx_hi - x_max);
+                                    pv = slope * (xv - x_max) + pp_last;
+                                }
+                            } else {
+                                pv = pp_last;
+                            }
+                        } else {
+                            const int j = jx[i];
+                            if (xa[i] == xv) {
+                                pv = ppq<FAST>(j, dn, rdn);
+                            } else {
+                                const double slope = (ppq<FAST>(j + 1, dn, rdn) - ppq<FAST>(j, dn, rdn)) / (xb[i] - xa[i]);
+                                pv = slope * (xv - xa[i]) + ppq<FAST>(j, dn, rdn);
+                            }
+                        }
+                        carry[b0 + i] = pv;
+                    }
+                } else {
+                    double p[kMapQ], ta[kMapQ], tb[kMapQ];
+                    int jb[kMapQ];
+#pragma unroll
+                    for (int i = 0; i < kMapQ; ++i) {
+                        p[i] = ppq<FAST>(rk[b0 + i], dm, rdm);  // plotting position of x within the new series
+                        jb[i] = grid_bracket<FAST>(p[i], n, dn, rdn);
+                    }
+#pragma unroll
+                    for (int i = 0; i < kMapQ; ++i) {
+                        ta[i] = xl[jb[i]];
+                        tb[i] = xl[jb[i] + 1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < kMapQ; ++i)
+                        carry[b0 + i] = interp_on_grid_with<FAST>(p[i], n, dn, rdn, jb[i], ta[i], tb[i], ext_lo, vx_lo, ext_hi, vx_hi);  // quantile.py:613
                 }
-                res = interp_on_grid(p, n, dn, ys, ext_lo, vy_lo, ext_hi, vy_hi);  // quantile.py:268-269
-            } else {
-                const double p = pp_at(rank[c * Tp + tq], dm);  // plotting position of x within the new series
-                const double x_train = interp_on_grid(p, n, dn, xs, ext_lo, vx_lo, ext_hi, vx_hi);  // quantile.py:613
-                const double y_map = interp_on_grid(p, n, dn, ys, ext_lo, vy_lo, ext_hi, vy_hi);
-                res = model == 1 ? y_map + (x - x_train) : y_map * (x / x_train);  // quantile.py:616-623
             }
-            if (one_to_one) {  // quantile.py:277-310 (fit X and y have the same length)
-                if (x > x_max) res = y_max + (x - x_max);
-                if (x < x_min) res = y_min + (x - x_min);
+            if (!QMR) {  // (the samples themselves enter in the second generation only)
+#pragma unroll
+                for (int i = 0; i < kMapPer; ++i) {
+                    const int tq = pass0 + i * nthr + tid;
+                    xq[i] = tq < Tp ? qrow[tq] : x_min;
+                }
             }
-            oc[c * Tp + tq] = res;
+            SD_QSTAMP(3);
+            __syncthreads();
+            SD_QSTAMP(4);
+            fill_table(xl, ys, n, tid, nthr);
+            __syncthreads();
+            SD_QSTAMP(5);
+#pragma unroll
+            for (int b0 = 0; b0 < kMapPer; b0 += kMapQ) {
+                double p[kMapQ], ya[kMapQ], yb[kMapQ];
+                int jb[kMapQ];
+#pragma unroll
+                for (int i = 0; i < kMapQ; ++i) {
+                    p[i] = QMR ? carry[b0 + i] : ppq<FAST>(rk[b0 + i], dm, rdm);
+                    jb[i] = grid_bracket<FAST>(p[i], n, dn, rdn);
+                }
+#pragma unroll
+                for (int i = 0; i < kMapQ; ++i) {
+                    ya[i] = xl[jb[i]];
+                    yb[i] = xl[jb[i] + 1];
+                }
+#pragma unroll
+                for (int i = 0; i < kMapQ; ++i) {
+                    const int tq = pass0 + (b0 + i) * nthr + tid;
+                    if (tq >= Tp) continue;
+                    const double xv = xq[b0 + i];
+                    const double y_map = interp_on_grid_with<FAST>(p[i], n, dn, rdn, jb[i], ya[i], yb[i], ext_lo, vy_lo, ext_hi, vy_hi);  // quantile.py:268-269
+                    double res = y_map;
+                    if (!QMR) {
+                        const double x_train = carry[b0 + i];
+                        res = model == 1 ? y_map + (xv - x_train) : y_map * (xv / x_train);  // quantile.py:616-623
+                    }
+                    if (one_to_one) {  // quantile.py:277-310 (fit X and y have the same length)
+                        if (xv > x_max) res = y_max + (xv - x_max);
+                        if (xv < x_min) res = y_min + (xv - x_min);
+                    }
+                    orow[tq] = res;
+                }
+            }
+            SD_QSTAMP(6);
         }
+#ifdef SD_DEV
+        ++traced;
+#endif
     }
 }
 
@@ -433,6 +765,49 @@ int launch_rank(sd_ctx* ctx, const double* data, int64_t T, int64_t C, int32_t* 
     return SD_OK;
 }
 
+
+// widths of the tile-shaped fit stage: at most 16 runs of 64 * K samples, merged by a 1 024-thread workgroup
+int tile_runs_width(int64_t T, size_t lds_max) {
+    if (sd_dev_env("SD_QM_NOTILE") != nullptr) return 0;
+    const int widths[] = {13, 15, 17};
+    for (int K : widths) {
+        const int64_t chunk = 64 * K, nchunks = (T + chunk - 1) / chunk;
+        if (nchunks <= 16 && sizeof(double) * (size_t)(nchunks * chunk + 1) + sizeof(int) * 1025 <= lds_max) return K;
+    }
+    return 0;
+}
+
+// np.sort of every cell's series of one time-major field -> xs [C][T] (plus mask / finite bookkeeping)
+template <int K>
+int launch_tile_sort(sd_ctx* ctx, const double* X_dev, int64_t ld, int64_t T, int64_t C, double* xs, int32_t* status, int set_mask,
+                     double* runs) {
+    constexpr int CHUNK = 64 * K;
+    constexpr int RS = CHUNK + 2 + ((4 - (CHUNK + 2) % 4) + 2) % 4;
+    const int nchunks = (int)((T + CHUNK - 1) / CHUNK);
+    const int np = nchunks * CHUNK;
+    const size_t lds_t = sizeof(double) * ((size_t)sdw::kW * RS + sdw::kHeadDoubles);
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qm_tile_runs_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+    const int64_t ntiles = (C + sdw::kW - 1) / sdw::kW, tx = (ntiles + 7) / 8;
+    const int64_t nblocks = 8 * tx * nchunks;
+    SD_CHECK_ARG(nblocks < ((int64_t)1 << 31), "sd_qm_fit: grid too large");
+    SD_LAUNCH(ctx, "qm_tile_runs_kernel", qm_tile_runs_kernel<K>, dim3((unsigned)nblocks), dim3(sdw::kThreads), lds_t, X_dev, ld, T, C, nchunks,
+              runs, (int64_t)np, status, set_mask);
+    const size_t lds_m = sizeof(double) * (size_t)(np + 1) + sizeof(int) * 1025;
+    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qm_merge_runs_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+    const int nb = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * 4);
+    SD_LAUNCH(ctx, "qm_merge_runs_kernel", qm_merge_runs_kernel<K>, dim3(nb), dim3(1024), lds_m, (const double*)runs, np, T, C, xs);
+    return SD_OK;
+}
+int launch_tile_sort_width(sd_ctx* ctx, int K, const double* X_dev, int64_t ld, int64_t T, int64_t C, double* xs, int32_t* status, int set_mask,
+                           double* runs) {
+    switch (K) {
+        case 13: return launch_tile_sort<13>(ctx, X_dev, ld, T, C, xs, status, set_mask, runs);
+        case 15: return launch_tile_sort<15>(ctx, X_dev, ld, T, C, xs, status, set_mask, runs);
+        case 17: return launch_tile_sort<17>(ctx, X_dev, ld, T, C, xs, status, set_mask, runs);
+    }
+    return sd_set_error(SD_ERR_INVALID, "qm tile sort: width %d not instantiated", K);
+}
+
 #define QM_DISPATCH_K(K, call_prefix, ...)                              \
     switch (K) {                                                        \
         case 1: SD_TRY(call_prefix<1>(__VA_ARGS__)); break;             \
@@ -503,6 +878,16 @@ int sd_qm_fit_dev(sd_ctx* ctx, const double* X_dev, const double* y_dev, int64_t
         if (y_dev) SD_HIP(sd_pool_malloc(ctx, (void**)&st->ys, sizeof(double) * (size_t)T * C));
         SD_HIP(sd_pool_malloc(ctx, (void**)&st->status, sizeof(int32_t) * C));
         SD_HIP(hipMemsetAsync(st->status, 0, sizeof(int32_t) * C, ctx->stream));
+        const int Kt = tile_runs_width(T, ctx->lds_max);
+        if (Kt != 0) {  // tile-shaped first stage: sorted runs straight from the time-major fields, then the merge rounds
+            sd_scratch runs;
+            const int64_t np = (T + 64 * Kt - 1) / (64 * Kt) * (64 * Kt);
+            SD_HIP(runs.alloc(ctx, sizeof(double) * (size_t)np * C));
+            SD_TRY(launch_tile_sort_width(ctx, Kt, X_dev, ld, T, C, st->xs, st->status, 1, runs.as<double>()));
+            if (y_dev) SD_TRY(launch_tile_sort_width(ctx, Kt, y_dev, ld, T, C, st->ys, st->status, 0, runs.as<double>()));
+            SD_HIP(hipStreamSynchronize(ctx->stream));  // (the runs go back to the block cache at scope exit)
+            return SD_OK;
+        }
         dim3 grid((unsigned)((C + 31) / 32), (unsigned)((T + 31) / 32));
         SD_LAUNCH(ctx, "qm_transpose_kernel", qm_transpose_kernel, grid, dim3(256), 0, X_dev, ld, T, C, st->xs, st->status, 1);
         QM_DISPATCH_K(K, launch_sort, ctx, st->xs, T, C);
@@ -550,7 +935,7 @@ int sd_qm_predict_dev(sd_ctx* ctx, const sd_qm_state* st, int model, int extrapo
     const int64_t C = st->C, T = st->T;
     const int K = model == SD_QM_REGRESSOR ? 1 : sort_width(Tp, ctx->lds_max);
     if (K == 0) return sd_set_error(SD_ERR_UNSUPPORTED, "sd_qm_predict: series of %lld samples exceed the workgroup sort (19456)", (long long)Tp);
-    const size_t lds_map = model == SD_QM_REGRESSOR ? sizeof(double) * (size_t)T : 0;
+    const size_t lds_map = sizeof(double) * (size_t)T;  // one table of the fit at a time (qm_map_kernel)
     SD_CHECK_ARG(lds_map <= ctx->lds_max, "sd_qm_predict: fitted series too long for the LDS-resident search");
     sd_scratch qc, oc, rk, status_p, status_pub;
     SD_HIP(qc.alloc(ctx, sizeof(double) * (size_t)Tp * C));
@@ -564,11 +949,51 @@ int sd_qm_predict_dev(sd_ctx* ctx, const sd_qm_state* st, int model, int extrapo
         SD_HIP(rk.alloc(ctx, sizeof(int32_t) * (size_t)Tp * C));
         QM_DISPATCH_K(K, launch_rank, ctx, qc.as<double>(), Tp, C, rk.as<int32_t>());
     }
-    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qm_map_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(lds_map ? lds_map : 8)));
+    // plotting positions without divisions (ppq): only if the correction step reproduces the division on both grids
+    const double dn_h = ((double)T + 1.0 - kAlpha) - kBeta, dm_h = ((double)Tp + 1.0 - kAlpha) - kBeta;  // pp_denom
+    const double rdn_h = 1.0 / dn_h, rdm_h = 1.0 / dm_h;
+    sd_scratch ppflag, tails;
+    SD_HIP(ppflag.alloc(ctx, sizeof(int32_t)));
+    SD_HIP(hipMemsetAsync(ppflag.p, 0, sizeof(int32_t), ctx->stream));
+    SD_LAUNCH(ctx, "qm_ppcheck_kernel", qm_ppcheck_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (int)T, dn_h, rdn_h, ppflag.as<int32_t>());
+    SD_LAUNCH(ctx, "qm_ppcheck_kernel", qm_ppcheck_kernel, dim3((unsigned)((Tp + 255) / 256)), dim3(256), 0, (int)Tp, dm_h, rdm_h, ppflag.as<int32_t>());
+    int32_t pp_mismatch = 1;
+    SD_HIP(hipMemcpyAsync(&pp_mismatch, ppflag.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if ((extrapolate & (SD_EXTRAP_MIN | SD_EXTRAP_MAX)) != 0 && extrapolate != SD_EXTRAP_1TO1) {
+        SD_HIP(tails.alloc(ctx, sizeof(double) * 4 * (size_t)C));
+        SD_LAUNCH(ctx, "qm_tails_kernel", qm_tails_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, extrapolate, n_endpoints,
+                  (const double*)st->xs, (const double*)st->ys, T, C, tails.as<double>());
+    }
+    SD_HIP(hipStreamSynchronize(ctx->stream));
+    const bool fastpp = pp_mismatch == 0 && sd_dev_env("SD_QM_DIVIDE") == nullptr;
     const int nb = (int)std::min<int64_t>(C, (int64_t)ctx->cu_count * (lds_map > ctx->lds_max / 2 ? 1 : 2));
-    SD_LAUNCH(ctx, "qm_map_kernel", qm_map_kernel, dim3(nb), dim3(1024), lds_map ? lds_map : 8, model, extrapolate, n_endpoints,
-              (const double*)qc.p, (const int32_t*)rk.p, (const double*)st->xs, (const double*)st->ys, T, Tp, C, oc.as<double>());
+    SD_CHECK_ARG(Tp < ((int64_t)1 << 31), "sd_qm_predict: series too long");
+#define SD_QM_MAP(QMR, PER, FAST)                                                                                                          \
+    do {                                                                                                                                   \
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qm_map_kernel<QMR, PER, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)lds_map));                                                                                         \
+        SD_LAUNCH(ctx, "qm_map_kernel", (qm_map_kernel<QMR, PER, FAST>), dim3(nb), dim3(1024), lds_map, model, extrapolate, n_endpoints,   \
+                  (const double*)qc.p, (const int32_t*)rk.p, (const double*)st->xs, (const double*)st->ys, T, Tp, C, oc.as<double>(),      \
+                  rdn_h, rdm_h, (const double*)tails.p);                                                                                   \
+    } while (0)
+    if (model == SD_QM_REGRESSOR) {
+        if (fastpp) SD_QM_MAP(true, 16, true);
+        else SD_QM_MAP(true, 16, false);
+    } else {
+        if (fastpp) SD_QM_MAP(false, 8, true);
+        else SD_QM_MAP(false, 8, false);
+    }
+#undef SD_QM_MAP
+#ifdef SD_DEV
+    if (sd_dev_env("SD_QM_TRACE") != nullptr) {
+        long long h[64];
+        SD_HIP(hipStreamSynchronize(ctx->stream));
+        SD_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(sd_qm_trace), sizeof(h)));
+        for (int r = 0; r < 8; ++r)
+            fprintf(stderr, "qm_map trace cell %d: consts+loads %lld fill xs %lld gen1 %lld barrier %lld fill ys %lld gen2 %lld\n", r, h[r * 8 + 1] - h[r * 8],
+                    h[r * 8 + 2] - h[r * 8 + 1], h[r * 8 + 3] - h[r * 8 + 2], h[r * 8 + 4] - h[r * 8 + 3], h[r * 8 + 5] - h[r * 8 + 4], h[r * 8 + 6] - h[r * 8 + 5]);
+    }
+#endif
     SD_LAUNCH(ctx, "qm_untranspose_kernel", qm_untranspose_kernel, grid, dim3(256), 0, (const double*)oc.p, Tp, C, out_dev, ld_out,
               (const int32_t*)st->status, (const int32_t*)status_p.p);
     if (cell_status) {
