@@ -25,6 +25,7 @@
 // first k go to the epilogue of the heap kernel (finish_query): same neighbours, same order, same statistics, bit for bit.
 
 constexpr int kTopKeep = 32, kTopNew = 32;
+constexpr int kTopMaxF = 6;                   // (7 and 8 features do not fit 256 registers with the matrix-core tiles: the heap kernel)
 constexpr int kTopMaxK = 30;                  // two spare kept slots tell "every tie of the k-th bucket is here" from "maybe not"
 constexpr unsigned kTopEmpty = 0xffffffc0u;   // keys of empty slots: above the high word of every finite double
 
@@ -163,21 +164,85 @@ __device__ __forceinline__ void pure_analog_stats_regs(const PredictArgs& pa, in
     *pred = p;
 }
 
-// pmax[cl] = max |ps| of cell c_base + cl (one workgroup per cell)
-__global__ void __launch_bounds__(256) analog_slab_pmax_kernel(const double* __restrict__ ps, int64_t n /* F * T */, int64_t cc,
-                                                               double* __restrict__ pmax) {
-    __shared__ double red[4];
+// cen[cl][f] = centre of the range of feature f over the training points of cell c_base + cl, pmax[cl] = the largest half-range:
+// the float32 images are taken of (coordinate - centre), so a common offset of the data costs the pre-filter no precision
+// (one workgroup per cell)
+__global__ void __launch_bounds__(256) analog_slab_center_kernel(const double* __restrict__ ps, int64_t T, int F, int64_t cc,
+                                                                 double* __restrict__ cen, double* __restrict__ pmax) {
+    __shared__ double red[2][4];
     for (int64_t cl = blockIdx.x; cl < cc; cl += gridDim.x) {
-        const double* src = ps + cl * n;
-        double m = 0.0;
-        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, __builtin_fabs(src[i]));
+        double half = 0.0;
+        for (int f = 0; f < F; ++f) {
+            const double* src = ps + (cl * F + f) * T;
+            double lo = __longlong_as_double(0x7ff0000000000000ll), hi = -lo;
+            for (int64_t i = threadIdx.x; i < T; i += blockDim.x) {
+                const double v = src[i];
+                lo = fmin(lo, v);
+                hi = fmax(hi, v);
+            }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) pmax[cl] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+            for (int o = 32; o >= 1; o >>= 1) {
+                lo = fmin(lo, __shfl_xor(lo, o, 64));
+                hi = fmax(hi, __shfl_xor(hi, o, 64));
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) {
+                red[0][threadIdx.x >> 6] = lo;
+                red[1][threadIdx.x >> 6] = hi;
+            }
+            __syncthreads();
+            lo = fmin(fmin(red[0][0], red[0][1]), fmin(red[0][2], red[0][3]));
+            hi = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+            const double c = lo * 0.5 + hi * 0.5;  // (no overflow for finite data)
+            if (threadIdx.x == 0) cen[cl * F + f] = c;
+            half = fmax(half, fmax(hi - c, c - lo));
+        }
+        if (threadIdx.x == 0) pmax[cl] = half;
     }
+}
+
+// ---- the same bit from the matrix cores ------------------------------------------------------------------------------------
+// 64 queries x 64 points x (F coordinates + 1) is a small matrix product: with x', q' the centred float32 images,
+//     |q' - x'|^2 - T  =  sum_k X'[k][point] * Q'[k][query] + (|q'|^2 - T),   X' = (x'_0 .. x'_{F-1}, |x'|^2),  Q' = (-2 q'_0 .. -2 q'_{F-1}, 1)
+// is what v_mfma_f32_32x32x2_f32 accumulates when the accumulator starts at (|q'|^2 - T): four 32 x 32 tiles (two point blocks x two
+// query blocks), ceil((F + 1) / 2) instructions each, 64 cycles of the matrix pipe per instruction -- 512 cycles per chunk for
+// F = 3 against ~2 100 cycles of vector issue for the v_readlane form -- and the sign bits of the 64 accumulators a lane ends up
+// with are the mask bits (one v_alignbit each).  Operand layout (cdna_hip_programming.md): A[i = lane & 31][k = lane >> 5],
+// B[k = lane >> 5][j = lane & 31], D: column j = lane & 31, row i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Points are rows,
+// queries columns: a lane holds, per tile, 16 of the 32 points of one query; the two lanes that share a query (l, l ^ 32)
+// exchange their halves so that lane Q ends up with the 64 bits of query Q -- in the order the hardware produced them, see
+// mfma_mask_point.  The matrix instruction is an fmaf chain, bit for bit, so its error obeys the usual dot-product bound:
+//     computed <= |q - x|^2 - T + E_coord + E_mfma,
+//     E_coord = 2 eta sqrt(F d) + F eta^2  (the rounding of the coordinates, eta = 2^-23 M),
+//     E_mfma <= (K + 2) 2^-23 (4 F M^2 + T)  (K + 2 roundings of partial sums bounded by |x'|^2 + 2 |q'| |x'| + |q'|^2 + T), doubled here;
+// T is tau plus both, inflated by 2^-19 and the accumulator start is rounded down: every point with d <= tau comes out negative.
+typedef float topk_v16f __attribute__((ext_vector_type(16)));
+template <int F>
+struct TopkMfma {
+    static constexpr int NKS = (F + 2) / 2;  // MFMA steps: F coordinates and the norm, two values of k per instruction
+    static constexpr int KP = 2 * NKS;
+};
+__device__ __forceinline__ float float_down(float c, double exact) {  // the float32 at or below `exact` nearest to c = (float)exact
+    if ((double)c <= exact) return c;
+    const unsigned b = __float_as_uint(c);
+    return c > 0.0f ? __uint_as_float(b - 1u) : (c < 0.0f ? __uint_as_float(b + 1u) : -1.4e-45f);
+}
+// accumulator start of the lane's own query: |q'|^2 - T(tau)
+template <int F>
+__device__ __forceinline__ float mfma_start(double tau, double nq, double eta, double m2) {
+    if (!(tau >= 0.0)) return 1e30f;  // a lane without a query: never negative
+    if (!(tau < 1e29)) return (float)(nq - 1e30);  // no bound yet: every point of the chunk (padding rows carry |x'|^2 = 3e38)
+    const double t0 = tau + 2.0 * eta * sqrt((double)F * tau) + (double)F * eta * eta;
+    const double em = (double)(TopkMfma<F>::KP + 2) * 0x1p-22 * (4.0 * (double)F * m2 + t0);
+    const double t = fmin((t0 + em) * (1.0 + 0x1p-19) + 1e-37, 1e30);
+    return float_down((float)(nq - t), nq - t);
+}
+// mask bit b of a lane -> point of the chunk (see the layout above): bits 0..31 come from the lane's own accumulators, 32..63 from
+// lane ^ 32; inside a half: 16 bits per point block, register v = 15 - (b & 15) (v_alignbit shifts left)
+__device__ __forceinline__ int mfma_mask_point(int b, int lane) {
+    const int own_half = lane >> 5, src_half = (b >> 5) ? own_half ^ 1 : own_half;
+    const int v = 15 - (b & 15);
+    return (((b >> 4) & 1) << 5) | ((v >> 2) << 3) | (src_half << 2) | (v & 3);
 }
 
 // slab_pick with the two boundary values it tests held in the cursor: the value behind a side that moved is requested when the
@@ -219,14 +284,16 @@ __device__ __forceinline__ SlabChunk topk_pick(const double* __restrict__ P0, in
     return ch;
 }
 
+// (two waves per SIMD -- what the 20 KB of LDS per wave allow -- need the kernel inside 256 registers)
 template <int F>
-__global__ void __launch_bounds__(64) analog_slab_topk_kernel(int mode, const double* __restrict__ qc /* [cc][F][Tq] */,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) analog_slab_topk_kernel(int mode, const double* __restrict__ qc /* [cc][F][Tq] */,
                                                               const int32_t* __restrict__ qi /* [cc][Tq] */, int64_t c_base,
                                                               int64_t Tq, int64_t T, int nbatch, const double* __restrict__ Xc,
                                                               const double* __restrict__ yc, const double* __restrict__ ps,
                                                               const int32_t* __restrict__ pi, const int32_t* __restrict__ fit_status,
                                                               int32_t* status, PredictArgs pa, int prune_at,
-                                                              const double* __restrict__ pmax /* [cc] */,
+                                                              const double* __restrict__ cen /* [cc][F] */,
+                                                              const double* __restrict__ pmax /* [cc] */, int use_mfma,
                                                               int32_t* __restrict__ worklist, int32_t* __restrict__ nwork,
                                                               unsigned long long* dbg) {
     typedef uint16_t IT;
@@ -253,17 +320,49 @@ __global__ void __launch_bounds__(64) analog_slab_topk_kernel(int mode, const do
             ok = false;
         }
     }
+    double cf[F];  // centre of the cell's training points, per feature (wave-uniform)
+    double nq = 0.0;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        qf[f] = ok ? (float)q[f] : 0.0f;
-        mq = fmax(mq, ok ? __builtin_fabs(q[f]) : 0.0);
+        cf[f] = uniform_f64(cen[cl * F + f]);
+        qf[f] = ok ? (float)(q[f] - cf[f]) : 0.0f;
+        nq += (double)qf[f] * (double)qf[f];
+        mq = fmax(mq, ok ? __builtin_fabs(q[f] - cf[f]) : 0.0);
     }
-    const double mx = fmax(mq, pmax[cl]);
-    if (!(uniform_f64(wave_max_f64(mx)) < 1e15)) {  // (wave-uniform) squares beyond the float32 range: the heap kernel's batch
+    const double mx = uniform_f64(wave_max_f64(fmax(mq, pmax[cl]))) * (1.0 + 0x1p-20);  // >= every |centred coordinate| of the wave's work
+    if (!(mx < 1e12)) {  // squares beyond the float32 range: the heap kernel's batch
         if (lane == 0) worklist[atomicAdd(nwork, 1)] = (int32_t)blockIdx.x;
         return;
     }
     const double eta = mx * (0x1p-23 * (1.0 + 0x1p-10));
+    const double m2 = mx * mx;
+    constexpr int NKS = TopkMfma<F>::NKS, KP = TopkMfma<F>::KP;
+    // matrix-core operands of the wave's queries: B[k = lane >> 5][j = lane & 31] of query block qb = Q'[2 ks + (lane >> 5)] of
+    // query 32 qb + (lane & 31), fetched from the lane that owns that query
+    float bop[2][NKS];
+    {
+        float qp[KP];
+#pragma unroll
+        for (int kk = 0; kk < KP; ++kk) qp[kk] = kk < F ? -2.0f * qf[kk] : (kk == F ? 1.0f : 0.0f);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int src = 32 * qb + (lane & 31);
+                const float t0 = __shfl(qp[2 * ks], src, 64), t1 = __shfl(qp[2 * ks + 1], src, 64);
+                bop[qb][ks] = lane < 32 ? t0 : t1;
+            }
+    }
+    topk_v16f cstart[2];  // accumulator starts of the two query blocks (every register: the start of the lane's column query)
+    auto set_starts = [&](double tau_now) {
+        const float own = mfma_start<F>(tau_now, nq, eta, m2);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float cs = __shfl(own, 32 * qb + (lane & 31), 64);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) cstart[qb][v] = cs;
+        }
+    };
     const double* __restrict__ P = ps + c * F * T;  // [F][T], ascending in feature 0
     const int32_t* __restrict__ PI = pi + c * T;
     unsigned kept[kTopKeep];
@@ -273,6 +372,7 @@ __global__ void __launch_bounds__(64) analog_slab_topk_kernel(int mode, const do
     bool overflow = false;
     double tau = ok ? inf : -1.0;  // bound of the k-th best distance; a lane without a query never flags a point
     float tauf = topk_tauf(tau, eta, F);
+    if (use_mfma) set_starts(tau);
     long long tclk[3] = {0, 0, 0};  // (dbg: clocks in mask building, appends, prunes)
     // The queries of a wave ascend in feature 0 -- except where the wave straddles two classes of the query order
     // (analog_slab_s2_kernel): the second class starts over at its smallest q0, and one slab around both ranges would be the
@@ -291,6 +391,7 @@ __global__ void __launch_bounds__(64) analog_slab_topk_kernel(int mode, const do
     const double tau_kept = tau;  // (lanes of other runs: no flags, no say in the slab)
     if (!ok) tau = -1.0;
     tauf = topk_tauf(tau, eta, F);
+    if (use_mfma) set_starts(tau);
     if (__any(ok)) {
         const double qlo = uniform_f64(wave_min_f64(ok ? q[0] : inf));
         const double qhi = uniform_f64(wave_max_f64(ok ? q[0] : -inf));
@@ -320,9 +421,49 @@ __global__ void __launch_bounds__(64) analog_slab_topk_kernel(int mode, const do
             const long long t0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
             float mf[F];
 #pragma unroll
-            for (int f = 0; f < F; ++f) mf[f] = (float)mine[f];
-            unsigned long long mask = lanes_mask_f32<F>(mf, qf, tauf);
-            if (nj < 64) mask &= (1ull << nj) - 1ull;
+            for (int f = 0; f < F; ++f) mf[f] = (float)(mine[f] - cf[f]);
+            unsigned long long mask;
+            if (use_mfma) {
+                // A[i = lane & 31][k = lane >> 5] of point block pb = X'[2 ks + (lane >> 5)] of point 32 pb + (lane & 31): the lane's
+                // own point or the one lane ^ 32 holds
+                float xp[KP], sw[KP];
+                double nx = 0.0;
+#pragma unroll
+                for (int f = 0; f < F; ++f) nx += (double)mf[f] * (double)mf[f];
+#pragma unroll
+                for (int kk = 0; kk < KP; ++kk) {
+                    xp[kk] = kk < F ? (lane < nj ? mf[kk] : 0.0f) : (kk == F ? (lane < nj ? (float)nx : 3.0e38f) : 0.0f);
+                    sw[kk] = __shfl_xor(xp[kk], 32, 64);
+                }
+                topk_v16f acc[2][2];
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const float a0 = lane < 32 ? xp[2 * ks] : sw[2 * ks + 1];  // point block 0
+                    const float a1 = lane < 32 ? sw[2 * ks] : xp[2 * ks + 1];  // point block 1
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        acc[0][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bop[qb][ks], ks == 0 ? cstart[qb] : acc[0][qb], 0, 0, 0);
+                        acc[1][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bop[qb][ks], ks == 0 ? cstart[qb] : acc[1][qb], 0, 0, 0);
+                    }
+                }
+                unsigned m16[2][2];
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        unsigned m = 0u;
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[pb][qb][v]), 31);
+                        m16[pb][qb] = m;
+                    }
+                const unsigned q0 = m16[0][0] | (m16[1][0] << 16), q1 = m16[0][1] | (m16[1][1] << 16);
+                const unsigned keep = lane < 32 ? q0 : q1, send = lane < 32 ? q1 : q0;
+                const unsigned recv = (unsigned)__shfl_xor((int)send, 32, 64);
+                mask = (unsigned long long)keep | ((unsigned long long)recv << 32);
+            } else {
+                mask = lanes_mask_f32<F>(mf, qf, tauf);
+                if (nj < 64) mask &= (1ull << nj) - 1ull;
+            }
             const long long t1 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
             tclk[0] += t1 - t0;
             if (__builtin_amdgcn_ballot_w64(mask != 0ull) != 0ull) {
@@ -339,11 +480,12 @@ __global__ void __launch_bounds__(64) analog_slab_topk_kernel(int mode, const do
                     // flagged points two at a time: the staged coordinates of both are requested before either distance is
                     // formed (one chain of LDS round trip + nine dependent float64 operations per point otherwise)
                     while (mask != 0ull && cnt < kTopNew - 1) {
-                        const int j1 = __builtin_ctzll(mask);
+                        const int b1 = __builtin_ctzll(mask);
                         mask &= mask - 1;
                         const bool two = mask != 0ull;
-                        const int j2 = two ? __builtin_ctzll(mask) : j1;
+                        const int b2 = two ? __builtin_ctzll(mask) : b1;
                         mask = two ? (mask & (mask - 1)) : mask;
+                        const int j1 = use_mfma ? mfma_mask_point(b1, lane) : b1, j2 = use_mfma ? mfma_mask_point(b2, lane) : b2;
                         double x1[F], x2[F];
 #pragma unroll
                         for (int f = 0; f < F; ++f) {
@@ -369,7 +511,8 @@ __global__ void __launch_bounds__(64) analog_slab_topk_kernel(int mode, const do
                         }
                     }
                     if (mask != 0ull && cnt < kTopNew) {  // one free slot
-                        const int j = __builtin_ctzll(mask);
+                        const int b = __builtin_ctzll(mask);
+                        const int j = use_mfma ? mfma_mask_point(b, lane) : b;
                         mask &= mask - 1;
                         double d = 0.0;
 #pragma unroll
@@ -387,6 +530,7 @@ __global__ void __launch_bounds__(64) analog_slab_topk_kernel(int mode, const do
                     const long long t2 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
                     topk_prune(kept, nk, bi, cnt, tau, k, lane, overflow);  // a lane ran out of slots with points left
                     tauf = topk_tauf(tau, eta, F);
+                    if (use_mfma) set_starts(tau);
                     if (dbg) {
                         const long long dt = (long long)__builtin_amdgcn_s_memtime() - t2;
                         tclk[2] += dt;
@@ -400,6 +544,7 @@ __global__ void __launch_bounds__(64) analog_slab_topk_kernel(int mode, const do
             if (__builtin_amdgcn_ballot_w64(cnt >= prune_at) != 0ull) {
                 topk_prune(kept, nk, bi, cnt, tau, k, lane, overflow);
                 tauf = topk_tauf(tau, eta, F);
+                if (use_mfma) set_starts(tau);
                 if (dbg) {
                     tclk[2] += (long long)__builtin_amdgcn_s_memtime() - t3;
                     if (lane == 0) atomicAdd(&dbg[2], 1ull);
@@ -509,7 +654,7 @@ size_t topk_lds_bytes(int F) {
 template <int F>
 int launch_slab_topk(sd_ctx* ctx, int mode, const sd_analog_state* st, const double* qc, const int32_t* qi, int64_t cb, int64_t cc,
                      int64_t Tq, int32_t* status_p, const PredictArgs& pa, int32_t* worklist /* [cc * nbatch + 1] */,
-                     double* pmax /* [cc] */) {
+                     double* cen /* [cc][F] */, double* pmax /* [cc] */) {
     const size_t lds = topk_lds_bytes(F);
     SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_slab_topk_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
@@ -524,13 +669,14 @@ int launch_slab_topk(sd_ctx* ctx, int mode, const sd_analog_state* st, const dou
         SD_HIP(dbg.alloc(ctx, 128));
         SD_HIP(hipMemsetAsync(dbg.p, 0, 128, ctx->stream));
     }
-    SD_LAUNCH(ctx, "analog_slab_pmax_kernel", analog_slab_pmax_kernel, dim3((unsigned)std::min<int64_t>(cc, (int64_t)ctx->cu_count * 8)),
-              dim3(256), 0, (const double*)st->ps + cb * F * st->T, (int64_t)F * st->T, cc, pmax);
+    SD_LAUNCH(ctx, "analog_slab_center_kernel", analog_slab_center_kernel, dim3((unsigned)std::min<int64_t>(cc, (int64_t)ctx->cu_count * 8)),
+              dim3(256), 0, (const double*)st->ps + cb * F * st->T, st->T, F, cc, cen, pmax);
+    const int use_mfma = sd_dev_env("SD_TOPK_READLANE") == nullptr ? 1 : 0;  // (A/B: the v_readlane form of the pre-filter)
     int32_t* nwork = worklist + nblocks;
     SD_HIP(hipMemsetAsync(nwork, 0, sizeof(int32_t), ctx->stream));
     SD_LAUNCH(ctx, "analog_slab_topk_kernel", (analog_slab_topk_kernel<F>), dim3((unsigned)nblocks), dim3(64), lds, mode, qc, qi, cb,
               Tq, st->T, (int)nbatch, (const double*)st->X, (const double*)st->y, (const double*)st->ps, (const int32_t*)st->xi,
-              (const int32_t*)st->status, status_p, pa, prune_at, (const double*)pmax, worklist, nwork,
+              (const int32_t*)st->status, status_p, pa, prune_at, (const double*)cen, (const double*)pmax, use_mfma, worklist, nwork,
               count ? dbg.as<unsigned long long>() : nullptr);
     int32_t nw = 0;
     SD_HIP(hipMemcpyAsync(&nw, nwork, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -564,12 +710,13 @@ int predict_slab(sd_ctx* ctx, int mode, const sd_analog_state* st, const double*
     nclass = nclass < 1 ? 1 : (nclass > 8 ? 8 : nclass);
     // k <= 30: candidate lists pruned by a register sorting network (analog_slab_topk_kernel); the heap kernel takes larger k
     // and the batches the fast kernel hands back
-    const bool topk = pa.k <= kTopMaxK && sd_dev_env("SD_ANALOG_HEAP") == nullptr;
+    const bool topk = pa.k <= kTopMaxK && F <= kTopMaxF && sd_dev_env("SD_ANALOG_HEAP") == nullptr;
     sd_scratch qc, qs, qi, key, wl;
-    sd_scratch pmax;
+    sd_scratch pmax, cen;
     if (topk) {
         SD_HIP(wl.alloc(ctx, sizeof(int32_t) * (size_t)(cc_max * nbatch + 1)));
         SD_HIP(pmax.alloc(ctx, sizeof(double) * (size_t)cc_max));
+        SD_HIP(cen.alloc(ctx, sizeof(double) * (size_t)cc_max * F));
     }
     if (nclass > 1) SD_HIP(key.alloc(ctx, sizeof(double) * (size_t)Tq * cc_max));
     SD_HIP(qc.alloc(ctx, sizeof(double) * (size_t)Tq * F * cc_max));
@@ -599,13 +746,11 @@ int predict_slab(sd_ctx* ctx, int mode, const sd_analog_state* st, const double*
         if (topk) {
             int32_t* w = wl.as<int32_t>();
             switch (F) {
-                case 2: SD_TRY(launch_slab_topk<2>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa, w, pmax.as<double>())); break;
-                case 3: SD_TRY(launch_slab_topk<3>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa, w, pmax.as<double>())); break;
-                case 4: SD_TRY(launch_slab_topk<4>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa, w, pmax.as<double>())); break;
-                case 5: SD_TRY(launch_slab_topk<5>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa, w, pmax.as<double>())); break;
-                case 6: SD_TRY(launch_slab_topk<6>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa, w, pmax.as<double>())); break;
-                case 7: SD_TRY(launch_slab_topk<7>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa, w, pmax.as<double>())); break;
-                default: SD_TRY(launch_slab_topk<8>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa, w, pmax.as<double>())); break;
+                case 2: SD_TRY(launch_slab_topk<2>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa, w, cen.as<double>(), pmax.as<double>())); break;
+                case 3: SD_TRY(launch_slab_topk<3>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa, w, cen.as<double>(), pmax.as<double>())); break;
+                case 4: SD_TRY(launch_slab_topk<4>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa, w, cen.as<double>(), pmax.as<double>())); break;
+                case 5: SD_TRY(launch_slab_topk<5>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa, w, cen.as<double>(), pmax.as<double>())); break;
+                default: SD_TRY(launch_slab_topk<6>(ctx, mode, st, q, qix, cb, cc, Tq, status_p, pa, w, cen.as<double>(), pmax.as<double>())); break;
             }
             continue;
         }

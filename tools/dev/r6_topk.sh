@@ -7,6 +7,7 @@ import json,sys;d=json.loads(sys.stdin.readline());r=d['roofline'];print('$1', r
   grep -E "^\[topk\]|^\[slab\]" /tmp/err.txt | tail -3
 }
 for pa in ${PRUNE_ATS:-16}; do
+  SD_TOPK_READLANE=1 SD_TOPK_PRUNE_AT=$pa run "readlane filter, prune_at=$pa"
   SD_TOPK_PRUNE_AT=$pa run "prune_at=$pa"
   SD_TOPK_PRUNE_AT=$pa SD_ANALOG_ABLATE=4 CELLS=2048 run "prune_at=$pa (counters)"
 done
