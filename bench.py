@@ -863,8 +863,12 @@ def main():
             cells_s = d["value"]
             # the brute-force equivalent: 3 F Tf Tq flops per cell at the measured cells per second
             f3["brute_force_equivalent_tflops"] = cells_s * 3.0 * 3 * args.times * args.times / 1e12
-            f3["note"] = ("KDTree-equivalent exact search (slab scan over feature 0, register / LDS heap per query); flops of a full pairwise scan "
-                          "at this rate are reported for scale, the kernel does not execute them")
+            # against the float64 vector peak of the guide (78.6 TFLOP/s): what a full pairwise scan in float64 would need at this rate
+            f3["brute_force_equivalent_frac_of_fp64_vector_peak"] = f3["brute_force_equivalent_tflops"] / 78.6
+            f3["note"] = ("KDTree-equivalent exact search: slab scan over feature 0; per chunk of 64 points a float32 pre-filter on the matrix cores "
+                          "(v_mfma_f32_32x32x2_f32), exact float64 distances for the flagged points only, candidate lists pruned by a register sorting "
+                          "network (analog_slab_topk_kernel); flops of a full float64 pairwise scan at this rate are reported for scale, the kernel does "
+                          "not execute them; roofline.frac is the HBM fraction of the algorithmic bytes")
             secondary["analog_f3"] = f3
         except Exception as e:  # noqa: BLE001
             secondary["analog_f3"] = {"value": None, "error": f"{type(e).__name__}: {e}"}

@@ -55,3 +55,12 @@ def test_random_configurations_of_the_fused_analog_call():
     import fuzz_analog_fused
 
     fuzz_analog_fused.main(300, 5)
+
+
+def test_random_configurations_of_the_candidate_list_search():
+    """tools/dev/fuzz_topk.py: analog_slab_topk_kernel (F = 2 .. 6, k <= 30: matrix-core and v_readlane pre-filters, candidate lists
+    pruned by the register network, batches handed back on ties) against the heap kernel of the same slab scan, bit for bit, and the
+    oracle's brute force; 2 150 cases (seeds 1 .. 5) passed when the kernel was written (profiles/r06/fuzz_summary.txt)."""
+    import fuzz_topk
+
+    fuzz_topk.main(120, 77)
