@@ -419,3 +419,38 @@ def test_pointwise_transformers_match_the_reference_loop():
     pb.fit(grid(X, index), grid(y, index))
     climo = pb.get_attr("y_climo_")
     assert_close(np.asarray(climo.values).reshape(12, C), g["y_climo"], what="get_attr('y_climo_')")
+
+
+@pytest.mark.parametrize("T,Tp", [(14600, 14600), (3000, 7001), (19000, 5000)])
+def test_round6_paths_are_bit_identical_to_the_kernels_they_replace(dev_ctx, monkeypatch, T, Tp):
+    """Round 6: the tile-shaped first stage of the fit (qm_tile_runs_kernel + qm_merge_runs_kernel; series of up to 17 408 samples)
+    against the staging transpose + workgroup sort (SD_QM_NOTILE), and the plotting positions by the verified correction step
+    against the division (SD_QM_DIVIDE) -- switches of the development library -- every model and extrapolate mode, ties, a
+    masked and a non-finite cell."""
+    rng = np.random.default_rng(T)
+    C = 11
+    X = np.round(3 * rng.standard_normal((T, C)), 3)
+    y = np.round(4 * rng.standard_normal((T, C)), 3) + 2.0
+    Xp = np.round(3.5 * rng.standard_normal((Tp, C)), 3) + 1.0
+    X[0, 3] = np.nan
+    y[17, 5] = np.inf
+
+    def run():
+        st = dev_ctx.qm_fit(X, y)
+        e = st.export()
+        outs = [dev_ctx.qm_predict(st, code, Xp, ex, 10) for code in (0, 1, 2) for ex in (None, "1to1", "min", "both")]
+        st.close()
+        return e, outs
+
+    e0, o0 = run()
+    ok = np.ones(C, bool)
+    ok[[3, 5]] = False
+    assert np.array_equal(e0["x_sorted"][ok], np.sort(X, axis=0).T[ok]) and np.array_equal(e0["y_sorted"][ok], np.sort(y, axis=0).T[ok])
+    assert e0["status"][3] != 0 and e0["status"][5] != 0
+    for env in ("SD_QM_NOTILE", "SD_QM_DIVIDE"):
+        monkeypatch.setenv(env, "1")
+        e1, o1 = run()
+        monkeypatch.delenv(env)
+        assert np.array_equal(e1["x_sorted"][ok], e0["x_sorted"][ok]) and np.array_equal(e1["y_sorted"][ok], e0["y_sorted"][ok])
+        for (a, sa), (b, sb) in zip(o0, o1):
+            assert np.array_equal(sa, sb) and np.array_equal(a, b, equal_nan=True), env
