@@ -20,8 +20,10 @@
 //                           LDS-resident per value range;
 //   analog_f1_predict_kernel / f1_walk_query  exact (rdist, index)-ordered two-pointer walk: 'sample_analogs',
 //                           neighbour outputs, and any query whose window has a tie on its boundary.
-// predict, F > 1: analog_slab_predict_kernel (one wave per 64 queries sorted by feature 0, scalar-loaded training
-//   points from the feature-0 sorted copy, only the reachable slab is scanned, top-k heap in LDS);
+// predict, F > 1: analog_slab_topk_kernel (sd_analog_topk.h; k <= 30, F <= 6: one wave per 64 queries sorted by feature 0, only the
+//   reachable slab of the feature-0 sorted copy is scanned, the 64 x 64 mask of a chunk from the matrix cores, candidate lists pruned
+//   by a register sorting network); analog_slab_predict_kernel (the same scan with scalar-loaded points and a top-k heap in LDS:
+//   larger k / F and the batches the first hands back);
 //   analog_bf2_predict_kernel (same scanner over the whole set in index order); analog_bf_predict_kernel
 //   (LDS-staged tiles, lists in global scratch) for k > 208.
 // fit + predict in one call (sd_analog_fit_predict*): analog_f1_fused_kernel -- the workgroup that merged a cell's sorted runs
@@ -29,7 +31,7 @@
 //   take fit -> predict internally.
 // Epilogues: PureAnalog statistics (gard.py:303-346), per-query least squares (gard.py:194-224).
 // Layout of the sources: kernels in sd_analog_fit.h (fit), sd_analog_epilogue.h, sd_analog_f1.h (F == 1 predict, fused kernel),
-// sd_analog_fn.h (F > 1 predict), included below; host code and the C entry points here.
+// sd_analog_fn.h, sd_analog_topk.h (F > 1 predict), included below; host code and the C entry points here.
 #include <algorithm>
 #include <cstdlib>
 
