@@ -265,6 +265,12 @@ int sd_ctx_destroy(sd_ctx* ctx) {
     (void)hipEventDestroy(ctx->t1);
     (void)hipEventDestroy(ctx->p0);
     (void)hipEventDestroy(ctx->p1);
+    for (auto& pe : ctx->prof_pending) {
+        (void)hipEventDestroy(pe.e0);
+        (void)hipEventDestroy(pe.e1);
+    }
+    for (auto ev : ctx->prof_free) (void)hipEventDestroy(ev);
+    if (ctx->prof_open) (void)hipEventDestroy(ctx->prof_open);
     if (ctx->ws_ptr) (void)hipFree(ctx->ws_ptr);
     for (int b = 0; b < sd_ctx::kStageBufs; ++b) {
         if (ctx->stage[b]) (void)hipHostFree(ctx->stage[b]);
@@ -417,20 +423,41 @@ int sd_timer_stop(sd_ctx* ctx, float* elapsed_ms) {
     return SD_OK;
 }
 
+// the pending event pairs -> per-kernel totals (waits for the stream once)
+static int sd_prof_resolve(sd_ctx* ctx) {
+    if (ctx->prof_pending.empty()) return SD_OK;
+    SD_HIP(hipSetDevice(ctx->device));
+    SD_HIP(hipEventSynchronize(ctx->prof_pending.back().e1));
+    for (auto& pe : ctx->prof_pending) {
+        float ms = 0.f;
+        SD_HIP(hipEventElapsedTime(&ms, pe.e0, pe.e1));
+        auto& e = ctx->prof[pe.name];
+        e.ms += ms;
+        e.launches += 1;
+        ctx->prof_free.push_back(pe.e0);
+        ctx->prof_free.push_back(pe.e1);
+    }
+    ctx->prof_pending.clear();
+    return SD_OK;
+}
+
 int sd_prof_enable(sd_ctx* ctx, int on) {
     SD_CHECK_ARG(ctx, "ctx is NULL");
+    if (!on) SD_TRY(sd_prof_resolve(ctx));
     ctx->prof_on = on != 0;
     return SD_OK;
 }
 
 int sd_prof_reset(sd_ctx* ctx) {
     SD_CHECK_ARG(ctx, "ctx is NULL");
+    SD_TRY(sd_prof_resolve(ctx));
     ctx->prof.clear();
     return SD_OK;
 }
 
 int sd_prof_query(sd_ctx* ctx, const char* kernel_name, double* total_ms, int64_t* launches) {
     SD_CHECK_ARG(ctx && kernel_name, "sd_prof_query: NULL argument");
+    SD_TRY(sd_prof_resolve(ctx));
     auto it = ctx->prof.find(kernel_name);
     if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
     if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
@@ -439,6 +466,7 @@ int sd_prof_query(sd_ctx* ctx, const char* kernel_name, double* total_ms, int64_
 
 int sd_prof_names(sd_ctx* ctx, char* buf, size_t buf_len) {
     SD_CHECK_ARG(ctx && buf && buf_len, "sd_prof_names: NULL argument");
+    SD_TRY(sd_prof_resolve(ctx));
     std::string s;
     for (auto& kv : ctx->prof) {
         if (!s.empty()) s += ";";
@@ -514,20 +542,32 @@ int sd_workspace(sd_ctx* ctx, size_t bytes, void** out) {
     return SD_OK;
 }
 
+static int sd_prof_event(sd_ctx* ctx, hipEvent_t* ev) {
+    if (!ctx->prof_free.empty()) {
+        *ev = ctx->prof_free.back();
+        ctx->prof_free.pop_back();
+        return SD_OK;
+    }
+    SD_HIP(hipEventCreate(ev));
+    return SD_OK;
+}
+
 int sd_prof_begin(sd_ctx* ctx) {
-    if (ctx->prof_on) SD_HIP(hipEventRecord(ctx->p0, ctx->stream));
+    if (ctx->prof_on) {
+        if (ctx->prof_pending.size() >= 8192) SD_TRY(sd_prof_resolve(ctx));  // (bounds the events alive: a wait every 8 192 launches)
+        SD_TRY(sd_prof_event(ctx, &ctx->prof_open));
+        SD_HIP(hipEventRecord(ctx->prof_open, ctx->stream));
+    }
     return SD_OK;
 }
 
 int sd_prof_end(sd_ctx* ctx, const char* name) {
-    if (ctx->prof_on) {
-        SD_HIP(hipEventRecord(ctx->p1, ctx->stream));
-        SD_HIP(hipEventSynchronize(ctx->p1));
-        float ms = 0.f;
-        SD_HIP(hipEventElapsedTime(&ms, ctx->p0, ctx->p1));
-        auto& e = ctx->prof[name];
-        e.ms += ms;
-        e.launches += 1;
+    if (ctx->prof_on && ctx->prof_open != nullptr) {
+        hipEvent_t e1 = nullptr;
+        SD_TRY(sd_prof_event(ctx, &e1));
+        SD_HIP(hipEventRecord(e1, ctx->stream));
+        ctx->prof_pending.push_back({ctx->prof_open, e1, name});
+        ctx->prof_open = nullptr;
     }
     return SD_OK;
 }

@@ -50,9 +50,19 @@ struct sd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;  // sd_timer_*
-    hipEvent_t p0 = nullptr, p1 = nullptr;  // per-kernel profile
+    hipEvent_t p0 = nullptr, p1 = nullptr;  // (spare pair)
     bool prof_on = false;
     std::map<std::string, sd_prof_entry> prof;
+    // per-kernel profile: an event pair around every launch, recorded without waiting; the elapsed times are read when the profile
+    // is queried (sd_prof_resolve).  Waiting for every launch -- the first form -- put a host round trip between any two kernels of a
+    // step: ~0.2 ms of the 15 ms of the headline step went to the measurement of its seven launches.
+    struct sd_prof_pending {
+        hipEvent_t e0, e1;
+        const char* name;  // (string literals of the SD_LAUNCH sites)
+    };
+    std::vector<sd_prof_pending> prof_pending;
+    std::vector<hipEvent_t> prof_free;
+    hipEvent_t prof_open = nullptr;  // the begin event of the launch in progress
     int cu_count = 0;
     size_t lds_max = 0;
     // grow-only device workspace reused by calls on this context (hipMalloc/hipFree of GB-sized
