@@ -171,7 +171,9 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
                                lds_mean <= ctx->lds_max && sd_dev_env("SD_ANALOG_NOPREFIX") == nullptr;
         const bool phases = mean_only && mode == 0 && ((kind == SD_ANALOG_MEAN && !has_thresh) || k == 1) && T <= 1024 * 20 &&
                             sd_dev_env("SD_ANALOG_NOPHASES") == nullptr;
-        const int skip_prob = phases && !has_thresh ? 1 : 0;  // the probability column is 1 wherever the prediction is not NaN (gard.py:346)
+        // without a threshold the probability column is 1 wherever the prediction is not NaN (gard.py:346; AnalogRegression: gard.py:211-212):
+        // the single-pass kernels do not write it either, the staging transpose derives it from the predictions
+        const int skip_prob = (phases || mean_only) && !has_thresh ? 1 : 0;
         // Value-ordered runs pay where a query reads its window of analog values from memory (weights, thresholds, the regression):
         // neighbouring lanes then read overlapping lines.  The three-generation kernel reads nothing per query but LDS words, and
         // its search is bound by its spilled registers, not by bank conflicts: measured equal with sorted queries (33.7 against
@@ -214,6 +216,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
             PredictArgs pw = pa;
             pw.out = oc.as<double>();
             pw.oc_Tq = Tq;
+            pw.skip_prob = skip_prob;
             int nbc = nb;
             if ((int64_t)nbc > ((cc + 7) / 8) * 8) nbc = (int)(((cc + 7) / 8) * 8);
             // workgroups per cell in the single-pass kernel (see its qsplit): only when every XCD still gets whole groups

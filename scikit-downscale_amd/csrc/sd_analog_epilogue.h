@@ -18,13 +18,14 @@ struct PredictArgs {
     int64_t* inds;          // [Tq,k,ld_out] or null
     double* dist;           // [Tq,k,ld_out] or null
     int32_t* one_class;     // per-cell status words (predict side): SDI_ONE_CLASS is set here
+    int skip_prob = 0;      // staging path: the probability plane is not written (the staging transpose derives it from the predictions)
 };
 
 __device__ __forceinline__ void put_out(const PredictArgs& pa, int64_t tq, int64_t c, double pred, double prob, double err) {
     if (pa.oc_Tq > 0) {  // consecutive queries of a cell are consecutive in memory: coalesced across the workgroup
         double* o = pa.out + c * 3 * pa.oc_Tq + tq;
         o[0] = pred;
-        o[pa.oc_Tq] = prob;
+        if (!pa.skip_prob) o[pa.oc_Tq] = prob;
         o[2 * pa.oc_Tq] = err;
     } else {
         pa.out[(tq * 3 + 0) * pa.ld_out + c] = pred;
