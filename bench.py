@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--gather-steps", type=int, default=3, help="N>1: steps of the second loop that includes the gather to rank 0")
     ap.add_argument("--gather-chunks", type=int, default=4, help="N>1: cell chunks whose transfers overlap the next chunk's kernels")
+    ap.add_argument("--leg-timeout", type=float, default=float(os.environ.get("SD_BENCH_LEG_TIMEOUT", "420")),
+                    help="N>1: seconds the legs behind the timed loop (RCCL start-up, gathers, parity, config 5) may take together before "
+                         "rank 0 prints the line with what it has and every rank exits")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline, cpu_baseline_numpy and end_to_end")
     ap.add_argument("--check-cells", type=int, default=32, help="cells verified against the oracle outside the timed region")
@@ -467,16 +470,10 @@ def main():
     ctx = Context(local_rank % max(1, ndev.value))  # (more ranks than GPUs -- a test on a small box -- share devices)
     # control plane (barrier, max-over-ranks clock): a TCP star around rank 0; data path (gather of the predicted fields):
     # RCCL through the engine's C ABI.  The throughput line does not depend on the second one coming up.
+    # (RCCL comes up BEHIND the timed loop -- see the watchdog there: the path has never run on N > 1 GPUs of one node before the
+    # driver's scaling run, and a communicator that hangs while it is created must not cost the throughput line)
     rdv = Rendezvous(rank, world) if world > 1 else None
     comm, comm_error = None, None
-    if world > 1:
-        try:
-            comm = Communicator.from_env(ctx, rendezvous=rdv)
-        except Exception as e:  # noqa: BLE001
-            comm_error = f"{type(e).__name__}: {e}"
-        if rdv.allreduce_max(0.0 if comm is not None else 1.0) > 0.0 and comm is not None:  # all ranks or none
-            comm.close()
-            comm, comm_error = None, "communicator creation failed on another rank"
     info = ctx.device_info()
     T = args.times
     C = args.cells or wl["cells"]
@@ -566,9 +563,136 @@ def main():
     if rdv is not None:
         elapsed = rdv.allreduce_max(elapsed)
 
+    # ---- everything below is outside the timed region.  N > 1: the legs that follow bring up RCCL and move fields between GPUs for
+    # the first time on this node; a watchdog bounds them -- when they stall, rank 0 prints the line with what it has (the stalled
+    # leg named in `legs_timed_out`) and every rank leaves, so a hang in a collective cannot lose the measurement above ----
+    gather = None
+    parity = baseline = numpy_1 = numpy_n = e2e = pw_e2e = c_port = None
+    rccl = None
+    config5 = None
+    def build_line():
+        """the bench line from what has been measured so far (called once at the end -- or by the N > 1 watchdog while a leg stalls)"""
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = C * world * args.steps / elapsed
+        hot = {k: v for k, v in prof.items() if "mask" not in k and "status" not in k and "nan_fill" not in k and "synth" not in k}
+        kern = {k: v["ms"] / max(1, v["launches"]) for k, v in hot.items()}
+        launches_per_step = {k: hot[k]["launches"] / args.steps for k in kern}
+        kernel_ms = sum(kern[k] * launches_per_step[k] for k in kern)  # hot-path kernel time per step
+        alg_bytes = float(C) * T * wl["bytes_per_step"]
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # HBM bytes per step from the committed rocprofv3 PMC passes of this exact workload (separate --pmc runs,
+        # gfx950 FETCH_SIZE correction calibrated on a known byte count: profiles/pmc_traffic.json); null otherwise
+        traffic, traffic_source = None, None
+        try:
+            import hashlib
+
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                doc = json.load(f)
+            csrc = os.path.join(ROOT, "scikit-downscale_amd", "csrc")
+            now = hashlib.sha256(b"".join(open(os.path.join(csrc, fn), "rb").read() for fn in sorted(os.listdir(csrc))
+                                          if fn.endswith((".hip", ".h")))).hexdigest()[:16]
+            src = doc.get("source", {})
+            traffic_source = {"file": "profiles/pmc_traffic.json", "head": src.get("head"), "generated": src.get("generated"),
+                              "kernel_sources_match": src.get("kernel_sources_sha16") == now, "entry": None}
+            for pt in doc["entries"]:
+                w = pt["workload"]
+                if w["config"] == config and w["cells"] == C and w["timesteps"] == T:
+                    if w["kernel"] == "+".join(sorted(kern)):
+                        traffic = pt["traffic_bytes_per_step"]
+                        traffic_source["entry"] = "matches this run's workload and kernel set"
+                    else:
+                        traffic_source["entry"] = f"stale: measured for kernels {w['kernel']}, this run launches {'+'.join(sorted(kern))}"
+            if traffic_source["entry"] is None:
+                traffic_source["entry"] = "no PMC pass for this config / size"
+            if traffic is not None and not traffic_source["kernel_sources_match"]:
+                traffic_source["entry"] += "; kernel sources changed since the PMC pass (refresh with tools/dev/refresh_profiles.sh)"
+        except Exception as e:  # noqa: BLE001
+            traffic, traffic_source = None, {"file": "profiles/pmc_traffic.json", "entry": f"unreadable: {e}"}
+        dominant = max(kern, key=lambda k: kern[k] * launches_per_step[k]) if kern else None
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                    "traffic": traffic, "traffic_source": traffic_source, "kernel": "+".join(sorted(kern)), "dominant_kernel": dominant, "kernel_ms_per_step": kernel_ms,
+                    "algorithmic_bytes_per_step": alg_bytes, "algorithmic_bytes_per_cell": T * wl["bytes_per_step"],
+                    "per_kernel_avg_ms": kern, "launches_per_step": launches_per_step}
+        line = {
+            "metric": METRIC, "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wl["name"].format(C=C, T=T, Ct=C * world, N=world), "baseline_config": config, "cells_per_gpu": C,
+                       "total_cells": C * world, "timesteps": T, "groups": 12, "shards": "resident on their GPUs (value); gathered to rank 0 "
+                       "(value_with_gather)" if world > 1 else "single GPU", "device": info["name"]},
+            "roofline": roofline,
+            "parity_check": parity,
+        }
+        if gather is not None:
+            line.update(gather)
+        if world > 1:
+            line["rccl"] = rccl
+            line["baseline_config5"] = config5
+            line["scaling_claim"] = ("north_star's '>= 7x at 8 GPUs vs 1' is claimed on `value`: fit + predict of every rank's shard with the "
+                                     "predicted shards left resident on their GPUs (how a regridder or chunked writer consumes them); "
+                                     "`value_with_gather` (all shards into rank 0's HBM over xGMI, bound by the root's 7 links) and "
+                                     "`value_with_host_gather` (every rank to its own host memory over its own PCIe link) are reported beside "
+                                     "it and are NOT expected to reach 7x (DESIGN.md section 5)")
+        if baseline is not None:  # rank 0 at N = 1 only
+            line["cpu_baseline"] = baseline
+        if numpy_1 is not None:
+            line["cpu_baseline_numpy"] = numpy_1
+        if numpy_n is not None:
+            line["cpu_baseline_numpy_socket"] = numpy_n
+        if c_port is not None:
+            line["cpu_baseline_c_port"] = c_port
+        if e2e is not None:
+            line["end_to_end"] = e2e
+        if pw_e2e is not None:
+            line["pointwise_end_to_end"] = pw_e2e
+        return line
+
+    leg = {"name": "start", "done": False}
+    watchdog = None
+    if world > 1 and args.leg_timeout > 0:
+        import threading
+
+        def on_timeout():
+            if leg["done"]:
+                return
+            if rank == 0:
+                try:
+                    line = build_line()
+                    line["legs_timed_out"] = {"leg": leg["name"], "after_seconds": args.leg_timeout,
+                                              "note": "the legs behind the timed loop stalled; `value` was measured before them"}
+                    if line.get("rccl") is None:
+                        line["rccl"] = {"ranks": None, "error": f"stalled in leg '{leg['name']}'", "world_size_env": world}
+                    print(json.dumps(line), flush=True)
+                finally:
+                    os._exit(0)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.leg_timeout, on_timeout)
+        watchdog.daemon = True
+        watchdog.start()
+    if os.environ.get("SD_BENCH_FAKE_STALL") and world > 1:  # (test hook: a leg that never returns)
+        leg["name"] = "fake stall (SD_BENCH_FAKE_STALL)"
+        time.sleep(1e6)
+    if world > 1:
+        leg["name"] = "RCCL communicator (ncclCommInitRank)"
+        try:
+            comm = Communicator.from_env(ctx, rendezvous=rdv)
+        except Exception as e:  # noqa: BLE001
+            comm_error = f"{type(e).__name__}: {e}"
+        if rdv.allreduce_max(0.0 if comm is not None else 1.0) > 0.0 and comm is not None:  # all ranks or none
+            comm.close()
+            comm, comm_error = None, "communicator creation failed on another rank"
+        if comm is not None:  # what RCCL itself says it is running on (ncclCommCount: the ranks IT sees, not WORLD_SIZE)
+            try:
+                rccl = dict(comm.rccl_info(), world_size_env=world)
+            except Exception as e:  # noqa: BLE001
+                rccl = {"ranks": None, "error": f"{type(e).__name__}: {e}", "world_size_env": world}
+        else:
+            rccl = {"ranks": 0, "error": comm_error, "world_size_env": world}
+
     # ---- N > 1: the same step followed by the gather of the predicted field to rank 0 (cell chunks: a chunk's transfer
     # over xGMI overlaps the next chunk's kernels) ----
-    gather = None
+    leg["name"] = "gather to rank 0 over xGMI (RCCL send / recv)"
     if comm is not None and wl["kind"] != "analog" and args.gather_steps > 0:
         chunk_out, root_bufs = [], []
         try:
@@ -611,6 +735,7 @@ def main():
 
     # ---- N > 1: the other sink -- every rank copies its own shard to host memory over its own PCIe link (N links in
     # parallel instead of N - 1 xGMI links into one GPU); cell chunks through two alternating host buffers ----
+    leg["name"] = "shards to host memory"
     if world > 1 and wl["kind"] != "analog" and args.gather_steps > 0:
         host = None
         try:
@@ -669,16 +794,7 @@ def main():
         ok = bool((err <= tol).all()) and bool((np.asarray(status)[:n] == 0).all())
         return "ok" if ok else f"FAILED max_err={np.nanmax(err):.3e}"
 
-    parity = baseline = numpy_1 = numpy_n = e2e = pw_e2e = c_port = None
-    rccl = None
-    if world > 1:  # what RCCL itself says it is running on (ncclCommCount: the ranks IT sees, not WORLD_SIZE)
-        if comm is not None:
-            try:
-                rccl = dict(comm.rccl_info(), world_size_env=world)
-            except Exception as e:  # noqa: BLE001
-                rccl = {"ranks": None, "error": f"{type(e).__name__}: {e}", "world_size_env": world}
-        else:
-            rccl = {"ranks": 0, "error": comm_error, "world_size_env": world}
+    leg["name"] = "parity check of rank 0's shard"
     if rank == 0 and world > 1 and not args.no_cpu_baseline:
         # N > 1: rank 0's shard (cells 0 .. C-1 of the C * world grid) against the oracle, outside every timed region; the
         # cpu_baseline legs themselves stay with the N = 1 line
@@ -688,7 +804,7 @@ def main():
             _, _, _, parity, _ = cpu_baseline(wl["kind"], T, args.seed, c_full, 0.0, check_parity, parity_only=True)
         except Exception as e:  # noqa: BLE001
             parity = f"not run: {type(e).__name__}: {e}"
-    config5 = None
+    leg["name"] = "baseline_config5 (125 000 cells per GPU)"
     if world > 1 and wl.get("cells_config5") and not args.cells and wl["kind"] == "bcsd_tas":
         # BASELINE configs[4] at its own size: 125 000 cells per GPU (1 M cells at N = 8), shards resident
         try:
@@ -739,87 +855,18 @@ def main():
         except Exception as e:  # noqa: BLE001
             e2e = {"value": None, "error": str(e)}
 
+    leg["name"] = "closing barrier"
     if rdv is not None:
         rdv.barrier()
         if comm is not None:
             comm.close()
         rdv.close()
+    leg["done"] = True
+    if watchdog is not None:
+        watchdog.cancel()
     if rank != 0:
         return
-
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = C * world * args.steps / elapsed
-    hot = {k: v for k, v in prof.items() if "mask" not in k and "status" not in k and "nan_fill" not in k and "synth" not in k}
-    kern = {k: v["ms"] / max(1, v["launches"]) for k, v in hot.items()}
-    launches_per_step = {k: hot[k]["launches"] / args.steps for k in kern}
-    kernel_ms = sum(kern[k] * launches_per_step[k] for k in kern)  # hot-path kernel time per step
-    alg_bytes = float(C) * T * wl["bytes_per_step"]
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    # HBM bytes per step from the committed rocprofv3 PMC passes of this exact workload (separate --pmc runs,
-    # gfx950 FETCH_SIZE correction calibrated on a known byte count: profiles/pmc_traffic.json); null otherwise
-    traffic, traffic_source = None, None
-    try:
-        import hashlib
-
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            doc = json.load(f)
-        csrc = os.path.join(ROOT, "scikit-downscale_amd", "csrc")
-        now = hashlib.sha256(b"".join(open(os.path.join(csrc, fn), "rb").read() for fn in sorted(os.listdir(csrc))
-                                      if fn.endswith((".hip", ".h")))).hexdigest()[:16]
-        src = doc.get("source", {})
-        traffic_source = {"file": "profiles/pmc_traffic.json", "head": src.get("head"), "generated": src.get("generated"),
-                          "kernel_sources_match": src.get("kernel_sources_sha16") == now, "entry": None}
-        for pt in doc["entries"]:
-            w = pt["workload"]
-            if w["config"] == config and w["cells"] == C and w["timesteps"] == T:
-                if w["kernel"] == "+".join(sorted(kern)):
-                    traffic = pt["traffic_bytes_per_step"]
-                    traffic_source["entry"] = "matches this run's workload and kernel set"
-                else:
-                    traffic_source["entry"] = f"stale: measured for kernels {w['kernel']}, this run launches {'+'.join(sorted(kern))}"
-        if traffic_source["entry"] is None:
-            traffic_source["entry"] = "no PMC pass for this config / size"
-        if traffic is not None and not traffic_source["kernel_sources_match"]:
-            traffic_source["entry"] += "; kernel sources changed since the PMC pass (refresh with tools/dev/refresh_profiles.sh)"
-    except Exception as e:  # noqa: BLE001
-        traffic, traffic_source = None, {"file": "profiles/pmc_traffic.json", "entry": f"unreadable: {e}"}
-    dominant = max(kern, key=lambda k: kern[k] * launches_per_step[k]) if kern else None
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "traffic_source": traffic_source, "kernel": "+".join(sorted(kern)), "dominant_kernel": dominant, "kernel_ms_per_step": kernel_ms,
-                "algorithmic_bytes_per_step": alg_bytes, "algorithmic_bytes_per_cell": T * wl["bytes_per_step"],
-                "per_kernel_avg_ms": kern, "launches_per_step": launches_per_step}
-    line = {
-        "metric": METRIC, "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": wl["name"].format(C=C, T=T, Ct=C * world, N=world), "baseline_config": config, "cells_per_gpu": C,
-                   "total_cells": C * world, "timesteps": T, "groups": 12, "shards": "resident on their GPUs (value); gathered to rank 0 "
-                   "(value_with_gather)" if world > 1 else "single GPU", "device": info["name"]},
-        "roofline": roofline,
-        "parity_check": parity,
-    }
-    if gather is not None:
-        line.update(gather)
-    if world > 1:
-        line["rccl"] = rccl
-        line["baseline_config5"] = config5
-        line["scaling_claim"] = ("north_star's '>= 7x at 8 GPUs vs 1' is claimed on `value`: fit + predict of every rank's shard with the "
-                                 "predicted shards left resident on their GPUs (how a regridder or chunked writer consumes them); "
-                                 "`value_with_gather` (all shards into rank 0's HBM over xGMI, bound by the root's 7 links) and "
-                                 "`value_with_host_gather` (every rank to its own host memory over its own PCIe link) are reported beside "
-                                 "it and are NOT expected to reach 7x (DESIGN.md section 5)")
-    if baseline is not None:  # rank 0 at N = 1 only
-        line["cpu_baseline"] = baseline
-    if numpy_1 is not None:
-        line["cpu_baseline_numpy"] = numpy_1
-    if numpy_n is not None:
-        line["cpu_baseline_numpy_socket"] = numpy_n
-    if c_port is not None:
-        line["cpu_baseline_c_port"] = c_port
-    if e2e is not None:
-        line["end_to_end"] = e2e
-    if pw_e2e is not None:
-        line["pointwise_end_to_end"] = pw_e2e
+    line = build_line()
     # ---- the other single-GPU configurations of BASELINE.json, a few steps each, so that the driver's one run times them too:
     # each in a process of its own (this one has released its fields), full size, parity of the first cells against the oracle
     if world == 1 and config == 2 and not args.no_cpu_baseline and not args.parity_only and not args.no_secondary and not args.cells \

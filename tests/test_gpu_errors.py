@@ -1,5 +1,6 @@
 """GPU: error behaviour of the C ABI (argument checks, limits) as seen through the ctypes layer."""
 import ctypes as C
+import os
 
 import numpy as np
 import pandas as pd
@@ -204,3 +205,33 @@ def test_large_host_predict_matches_resident(ctx):
     assert np.array_equal(status, dstatus) and status[17] == 1 and status[4_650] == 2 and (np.delete(status, [17, 4_650]) == 0).all()
     assert np.array_equal(out, dout.to_host(), equal_nan=True)
     assert np.isnan(out[:, 17]).all() and np.isnan(out[:, 4_650]).all() and np.isfinite(out[:, 4_649]).all()
+
+
+def _bench_two_ranks(extra_env, extra_args, port):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--cells", "4096", "--times", "1461", "--no-cpu-baseline", "--gather-steps", "1"] + extra_args,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]  # ONE line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_line_and_stalled_leg_watchdog():
+    """bench.py at N = 2 with both ranks on this box's GPU(s): the throughput line is complete (rccl field: the ranks RCCL itself
+    counts, or its refusal of a shared device), and a leg behind the timed loop that never returns -- an RCCL start-up or collective
+    that hangs on a node nobody has run it on -- costs the legs, not the line: the watchdog prints it and every rank exits 0."""
+    d = _bench_two_ranks({}, [], 29561)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["cells_per_gpu"] == 4096
+    assert d["rccl"]["world_size_env"] == 2 and ("ranks" in d["rccl"])
+    assert "legs_timed_out" not in d
+    s = _bench_two_ranks({"SD_BENCH_FAKE_STALL": "1"}, ["--leg-timeout", "5"], 29562)
+    assert s["n_gpus"] == 2 and s["value"] > 0 and s["roofline"]["frac"] > 0
+    assert s["legs_timed_out"]["leg"].startswith("fake stall") and s["rccl"]["ranks"] is None
