@@ -536,7 +536,12 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
             // more steps of two reads (rdist is unimodal along xs).  With ties the separation test below sends the query
             // to the exact walk.
             int lo[kMeanQ];
+#ifdef SD_MEAN_NOSEARCH
+#pragma unroll
+            for (int j = 0; j < kMeanQ; ++j) lo[j] = (int)(((unsigned)(tq0 + j) * 2654435761u) % (unsigned)(n - k));
+#else
             window_starts_any<kMeanQ>(xs, k, n, n - k > 0 ? n - k : 0, q, lo);  // (round 6: one bisection on xs[i] + xs[i + k] >= 2 q, see window_starts)
+#endif
             // the statistics of one query at a time, as a rolled loop (its body is long: unrolled over the queries of the
             // thread it no longer fits the instruction cache); the query in turn sits in slot 0, the others move down
             unsigned hasm = 0u, okm = 0u;
@@ -636,9 +641,14 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
 #pragma unroll
                             for (int b = 0; b < kWinBatch; b += 2) {
                                 if (i0 + b + 1 < k) {
+#ifdef SD_MEAN_NOWIN
+                                    ab[b] = a0 + (double)(i0 + b);
+                                    ab[b + 1] = a0 - (double)(i0 + b);
+#else
                                     const f64x2_a8 v = *reinterpret_cast<const f64x2_a8*>(yl + i0 + b);
                                     ab[b] = v.x;
                                     ab[b + 1] = v.y;
+#endif
                                 } else {
                                     ab[b] = i0 + b < k ? yl[i0 + b] : 0.0;
                                     ab[b + 1] = 0.0;
@@ -654,11 +664,19 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                                     nexc += (!pa.has_thresh || ai > pa.thresh) ? 1 : 0;  // gard.py:307
                                     if (pa.kind == SD_ANALOG_WEIGHT) {
                                         // w = 1 / distance (gard.py:322-323): v_rcp_f64 + two Newton steps (< 1 ulp)
+#ifdef SD_MEAN_NOXS
+                                        double d = __builtin_fabs(qj - (a0 + (double)i));
+#else
                                         double d = __builtin_fabs(qj - xs[L + i]);
+#endif
                                         d = d == 0.0 ? 1e-20 : d;
+#ifdef SD_MEAN_NORCP
+                                        double r = d;
+#else
                                         double r = __builtin_amdgcn_rcp(d);
                                         r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
                                         r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+#endif
                                         wsum += r;
                                         awsum += ai * r;
                                     }
