@@ -456,6 +456,59 @@ __device__ __forceinline__ void window_starts_any(const double* buf, int k, int 
     else window_starts_two_level<NQ>(buf, k, n, M, q, L);
 }
 
+// B analogs of a 'weight_analogs' window (no threshold) as straight-line code: the distances, zero guards and refined reciprocals
+// of the batch are independent of one another and are requested / computed side by side, only the four running sums are chains.
+// (The generic loop of analog_f1_mean_kernel takes an analog at a time behind a scalar branch -- LDS read, wait, 14 dependent
+// float64 instructions --: with four waves per SIMD the vector ALUs sat at 67 %, profiles/r06/weight_mean_kernel_sq_counters.log.)
+// Same operations on the same operands in the same order of accumulation as that loop: bit-identical.
+template <int B>
+__device__ __forceinline__ void weight_batch(const double* __restrict__ yl, const double* xw, double qj, double a0, double& s1, double& s2,
+                                             double& wsum, double& awsum) {
+    static_assert(B % 2 == 0, "pairs of analog values per load");
+    double ab[B], xv[B], rw[B];
+#pragma unroll
+    for (int b = 0; b < B; b += 2) {
+        const f64x2_a8 v = *reinterpret_cast<const f64x2_a8*>(yl + b);
+        ab[b] = v.x;
+        ab[b + 1] = v.y;
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) xv[b] = xw[b];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        // w = 1 / distance (gard.py:322-323): v_rcp_f64 + two Newton steps (< 1 ulp)
+        double d = __builtin_fabs(qj - xv[b]);
+        d = d == 0.0 ? 1e-20 : d;
+        double r = __builtin_amdgcn_rcp(d);
+        r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+        rw[b] = r;
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const double e = ab[b] - a0;
+        s1 += e;
+        s2 += e * e;
+        wsum += rw[b];
+        awsum += ab[b] * rw[b];
+    }
+}
+// B training values of a regression window: sums of x - x0 and of its square, the LDS reads of the batch issued together
+template <int B>
+__device__ __forceinline__ void xsum_batch(const double* xw, double x0, double& sx, double& sxx) {
+    double xv[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) xv[b] = xw[b];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const double dx = xv[b] - x0;
+        sx += dx;
+        sxx += dx * dx;
+    }
+}
+
 #ifndef SD_MEANQ
 #define SD_MEANQ 2
 #endif
@@ -578,10 +631,18 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                         //   sum (x - xm)(y - ym) = [rx] + (xbar - xm) [p],  sum (y - ym)^2 = [q] - k m1^2
                         const double x0 = xs[L];
                         double sx = 0.0, sxx = 0.0;
-                        for (int i = 0; i < k; ++i) {
-                            const double dx = xs[L + i] - x0;
-                            sx += dx;
-                            sxx += dx * dx;
+                        {
+                            int i = 0;
+                            for (; i + 8 <= k; i += 8) xsum_batch<8>(xs + L + i, x0, sx, sxx);
+                            if (i + 4 <= k) {
+                                xsum_batch<4>(xs + L + i, x0, sx, sxx);
+                                i += 4;
+                            }
+                            for (; i < k; ++i) {
+                                const double dx = xs[L + i] - x0;
+                                sx += dx;
+                                sxx += dx * dx;
+                            }
                         }
                         const double2 a = pq[L], b = pq[L + k];
                         const double s1 = b.x - a.x, m1 = s1 / kk, mx = sx / kk, xm = x0 + mx;
@@ -634,7 +695,21 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                         const double a0 = yl[0];
                         double s1 = 0.0, s2 = 0.0, wsum = 0.0, awsum = 0.0;
                         int nexc = 0;
-                        for (int i0 = 0; i0 < k; i0 += kWinBatch) {
+                        int i0 = 0;
+                        if (pa.kind == SD_ANALOG_WEIGHT && !pa.has_thresh) {  // (weight_batch: straight-line batches of 8, 4, 2)
+                            const double* xw = xs + L;
+                            for (; i0 + 8 <= k; i0 += 8) weight_batch<8>(yl + i0, xw + i0, qj, a0, s1, s2, wsum, awsum);
+                            if (i0 + 4 <= k) {
+                                weight_batch<4>(yl + i0, xw + i0, qj, a0, s1, s2, wsum, awsum);
+                                i0 += 4;
+                            }
+                            if (i0 + 2 <= k) {
+                                weight_batch<2>(yl + i0, xw + i0, qj, a0, s1, s2, wsum, awsum);
+                                i0 += 2;
+                            }
+                            nexc = i0;  // (no threshold: every analog counts, gard.py:307; an odd last one takes the generic loop)
+                        }
+                        for (; i0 < k; i0 += kWinBatch) {
                             // two analog values per load (a lane's window is contiguous; the texture path is the limit of
                             // this branch: half the load instructions, half the line requests)
                             double ab[kWinBatch];
