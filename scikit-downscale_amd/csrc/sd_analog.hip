@@ -191,9 +191,12 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
             SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&analog_f1_mean3_kernel<20>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mean3));
         }
+        // AnalogRegression with a short window sums it directly (reg_batch: no prefix arrays to build or to read); the default
+        // n_analogs = 200 keeps the prefix differences (two 16-byte loads instead of 200 values per query)
+        const bool reg_direct = mean_only && mode == 1 && k <= kRegDirectK && sd_dev_env("SD_ANALOG_REG_PREFIX") == nullptr;
         // (the prefix sums serve the regression and the plain mean; weights and thresholds read the analog values themselves)
-        if (mean_only && !phases && (mode == 1 || (kind == SD_ANALOG_MEAN && !has_thresh && k > 1))) SD_TRY(ensure_prefix_sums(ctx, st));
-        if (mean_only && mode == 1 && st->rx == nullptr) {
+        if (mean_only && !phases && !reg_direct && (mode == 1 || (kind == SD_ANALOG_MEAN && !has_thresh && k > 1))) SD_TRY(ensure_prefix_sums(ctx, st));
+        if (mean_only && mode == 1 && !reg_direct && st->rx == nullptr) {
             // first regression on this state: the cross-term prefix sums (calls on a context are serialised)
             sd_analog_state* ms = const_cast<sd_analog_state*>(st);
             SD_HIP(sd_pool_malloc(ctx, (void**)&ms->rx, sizeof(double) * (size_t)(T + 1) * C));
@@ -221,7 +224,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
             if ((int64_t)nbc > ((cc + 7) / 8) * 8) nbc = (int)(((cc + 7) / 8) * 8);
             // workgroups per cell in the single-pass kernel (see its qsplit): only when every XCD still gets whole groups
             const char* eqs = sd_dev_env("SD_ANALOG_QSPLIT");
-            int qs = eqs ? atoi(eqs) : (mode == 1 ? 2 : 1);  // measured (ms per 16 384 cells), 1/2/4/8: regression 10.8/8.5/8.7/11.0, mean 5.5/5.7/6.4/8.3
+            int qs = eqs ? atoi(eqs) : (mode == 1 && !reg_direct ? 2 : 1);  // measured (ms per 16 384 cells), 1/2/4/8: regression 10.8/8.5/8.7/11.0, mean 5.5/5.7/6.4/8.3
             if (qs < 1 || nbc % (8 * qs) != 0 || cc < (int64_t)nbc || Tq < 4096) qs = 1;
             if (phases) {
                 const int per = (int)((T + nthr - 1) / nthr);
@@ -259,7 +262,7 @@ int predict_common(int mode, sd_ctx* ctx, const sd_analog_state* st, const doubl
                           (const double*)st->rx + cb * (T + 1), (const double*)st->xbar + cb, (const double*)st->yx + cb * T,
                           (const double*)st->X + cb * T,
                           (const double*)st->y + cb * T, (const int32_t*)st->status + cb, status_p.as<int32_t>() + cb,
-                          sc_d.as<double>(), sc_i.as<int32_t>(), pw, qs);
+                          sc_d.as<double>(), sc_i.as<int32_t>(), pw, qs, reg_direct ? 1 : 0);
             } else {
                 SD_LAUNCH(ctx, "analog_f1_window_kernel", analog_f1_window_kernel, dim3(nbc), dim3(nthr), lds, mode,
                           (const double*)qc.p, Tq, Tq, T, cc, npass, (const double*)st->xs + cb * T, (const int32_t*)st->xi + cb * T,

@@ -494,6 +494,32 @@ __device__ __forceinline__ void weight_batch(const double* __restrict__ yl, cons
         awsum += ab[b] * rw[b];
     }
 }
+// B analogs of a regression window, everything the one-feature OLS needs in one pass: sums of dx = x - x0, dx^2, e = y - a0, e^2, dx e
+// (centred on the window's own first pair: no cancellation against the cell's spread), loads of the batch issued together
+template <int B>
+__device__ __forceinline__ void reg_batch(const double* __restrict__ yl, const double* xw, double x0, double a0, double& sx, double& sxx,
+                                          double& t1, double& t2, double& txy) {
+    static_assert(B % 2 == 0, "pairs of analog values per load");
+    double ab[B], xv[B];
+#pragma unroll
+    for (int b = 0; b < B; b += 2) {
+        const f64x2_a8 v = *reinterpret_cast<const f64x2_a8*>(yl + b);
+        ab[b] = v.x;
+        ab[b + 1] = v.y;
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) xv[b] = xw[b];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const double dx = xv[b] - x0, e = ab[b] - a0;
+        sx += dx;
+        sxx += dx * dx;
+        t1 += e;
+        t2 += e * e;
+        txy += dx * e;
+    }
+}
 // B training values of a regression window: sums of x - x0 and of its square, the LDS reads of the batch issued together
 template <int B>
 __device__ __forceinline__ void xsum_batch(const double* xw, double x0, double& sx, double& sxx) {
@@ -512,6 +538,7 @@ __device__ __forceinline__ void xsum_batch(const double* xw, double x0, double& 
 #ifndef SD_MEANQ
 #define SD_MEANQ 2
 #endif
+constexpr int kRegDirectK = 64;  // AnalogRegression windows up to this long are summed directly (reg_batch); longer ones take the prefix sums
 constexpr int kMeanQ = SD_MEANQ;  // queries a thread of analog_f1_mean_kernel searches together (independent bisection chains)
 // F == 1, single pass over the queries with only the sorted training values LDS-resident.  'mean_analogs' without a
 // threshold, a single analog and AnalogRegression (mode 1, k >= 3) take the window statistics from the prefix sums
@@ -528,7 +555,8 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                                                               const double* __restrict__ yx_all, const double* __restrict__ Xc,
                                                               const double* __restrict__ yc,
                                                               const int32_t* __restrict__ fit_status, int32_t* status,
-                                                              double* scratch_d, int32_t* scratch_i, PredictArgs pa, int qsplit) {
+                                                              double* scratch_d, int32_t* scratch_i, PredictArgs pa, int qsplit,
+                                                              int reg_direct /* mode 1: window sums by direct summation (pq / rx unused) */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* xs = reinterpret_cast<double*>(smem_raw);  // n sorted values + one +inf sentinel
     const int nthr = blockDim.x, tid = threadIdx.x;
@@ -562,10 +590,10 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
         const double2* pq = reinterpret_cast<const double2*>(pq_all) + c * (T + 1);
         const double ybar = ybar_all[c];
         const double* rx = rx_all + c * (T + 1);
-        const double xbar = mode == 1 ? xbar_all[c] : 0.0;
+        const double xbar = mode == 1 && !reg_direct ? xbar_all[c] : 0.0;
         // AnalogRegression: residual sums below this are left to direct summation (the prefix differences carry an
         // absolute error of ~1e-16 of the cell total)
-        const double ss_floor = mode == 1 ? 1e-4 * kk * (pq[n].y / (double)n) : 0.0;
+        const double ss_floor = mode == 1 && !reg_direct ? 1e-4 * kk * (pq[n].y / (double)n) : 0.0;
         __syncthreads();
         if (active)
             for (int i = tid; i < n; i += nthr) xs[i] = xg[i];
@@ -625,7 +653,54 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                         f1_walk_query(mode, pa, n, T, c, tq, qj, xg, xi_all + c * T, Xc + c * T, yc + c * T, sd, si, nthr);
                         continue;
                     }
-                    if (mode == 1) {
+                    if (mode == 1 && reg_direct) {
+                        // one-feature OLS on the k analogs (gard.py:194-224) from ONE pass over the window (short windows: k <= kRegDirectK):
+                        // every sum centred on the window's first pair, so the residual sum ss = vyy - slope vxy carries a relative error
+                        // of ~ eps vyy / ss -- far below the 1e-6 of the parity contract unless the fit is (nearly) exact, and then the
+                        // residuals are summed directly in a second pass, as in the prefix form.  No prefix arrays: analog_prefix_kernel
+                        // and analog_rx_kernel (21 of 110 ms per 100 000 cells at k = 30) and their 24 bytes per sample are not needed.
+                        const double x0 = xs[L];
+                        const double* yl = yx_all + c * T + L;
+                        const double a0 = yl[0];
+                        double sx = 0.0, sxx = 0.0, t1 = 0.0, t2 = 0.0, txy = 0.0;
+                        {
+                            int i = 0;
+                            for (; i + 8 <= k; i += 8) reg_batch<8>(yl + i, xs + L + i, x0, a0, sx, sxx, t1, t2, txy);
+                            if (i + 4 <= k) {
+                                reg_batch<4>(yl + i, xs + L + i, x0, a0, sx, sxx, t1, t2, txy);
+                                i += 4;
+                            }
+                            if (i + 2 <= k) {
+                                reg_batch<2>(yl + i, xs + L + i, x0, a0, sx, sxx, t1, t2, txy);
+                                i += 2;
+                            }
+                            if (i < k) {
+                                const double dx = xs[L + i] - x0, e = yl[i] - a0;
+                                sx += dx;
+                                sxx += dx * dx;
+                                t1 += e;
+                                t2 += e * e;
+                                txy += dx * e;
+                            }
+                        }
+                        const double mx = sx / kk, xm = x0 + mx, n1 = t1 / kk;
+                        const double vxx = sxx - kk * mx * mx, vyy = t2 - kk * n1 * n1, wxy = txy - kk * mx * n1;
+                        const double slope = vxx > 0.0 ? wxy / vxx : 0.0;
+                        double ss = vyy - slope * wxy;
+                        pred = (a0 + n1) + (qj - xm) * slope;
+                        if (!(ss > 1e-7 * vyy)) {
+                            // (nearly) exact fit or constant analogs: the residuals themselves
+                            const double icpt = (a0 + n1) - xm * slope;
+                            pred = icpt + qj * slope;
+                            ss = 0.0;
+                            for (int i = 0; i < k; ++i) {
+                                const double r = yl[i] - (icpt + xs[L + i] * slope);
+                                ss += r * r;
+                            }
+                        }
+                        prob = 1.0;
+                        err = sqrt(ss / kk);  // root_mean_squared_error (gard.py:218-219)
+                    } else if (mode == 1) {
                         // one-feature OLS on the k analogs (gard.py:194-224), slope 0 when all x are equal.  The x sums
                         // come from the LDS window, the y and cross sums from the prefix differences:
                         //   sum (x - xm)(y - ym) = [rx] + (xbar - xm) [p],  sum (y - ym)^2 = [q] - k m1^2
