@@ -494,6 +494,45 @@ __device__ __forceinline__ void weight_batch(const double* __restrict__ yl, cons
         awsum += ab[b] * rw[b];
     }
 }
+// the same with a threshold (gard.py:307: the analogs above it are counted; the sums run over all of them, a masked window answers NaN
+// further down), with or without the weights
+template <int B, bool WEIGHT>
+__device__ __forceinline__ void thresh_batch(const double* __restrict__ yl, const double* xw, double qj, double a0, double thresh, double& s1,
+                                             double& s2, double& wsum, double& awsum, int& nexc) {
+    static_assert(B % 2 == 0, "pairs of analog values per load");
+    double ab[B], xv[B], rw[B];
+#pragma unroll
+    for (int b = 0; b < B; b += 2) {
+        const f64x2_a8 v = *reinterpret_cast<const f64x2_a8*>(yl + b);
+        ab[b] = v.x;
+        ab[b + 1] = v.y;
+    }
+    if constexpr (WEIGHT) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) xv[b] = xw[b];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            double d = __builtin_fabs(qj - xv[b]);
+            d = d == 0.0 ? 1e-20 : d;
+            double r = __builtin_amdgcn_rcp(d);
+            r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+            r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+            rw[b] = r;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const double e = ab[b] - a0;
+        s1 += e;
+        s2 += e * e;
+        nexc += ab[b] > thresh ? 1 : 0;
+        if constexpr (WEIGHT) {
+            wsum += rw[b];
+            awsum += ab[b] * rw[b];
+        }
+    }
+}
 // B analogs of a regression window, everything the one-feature OLS needs in one pass: sums of dx = x - x0, dx^2, e = y - a0, e^2, dx e
 // (centred on the window's own first pair: no cancellation against the cell's spread), loads of the batch issued together
 template <int B>
@@ -783,6 +822,22 @@ __global__ void __launch_bounds__(1024) analog_f1_mean_kernel(int mode, const do
                                 i0 += 2;
                             }
                             nexc = i0;  // (no threshold: every analog counts, gard.py:307; an odd last one takes the generic loop)
+                        } else if (pa.has_thresh) {  // (thresh_batch: the same batches with the exceedance count)
+                            const double* xw = xs + L;
+                            const double th = pa.thresh;
+                            if (pa.kind == SD_ANALOG_WEIGHT) {
+                                for (; i0 + 8 <= k; i0 += 8) thresh_batch<8, true>(yl + i0, xw + i0, qj, a0, th, s1, s2, wsum, awsum, nexc);
+                                if (i0 + 4 <= k) {
+                                    thresh_batch<4, true>(yl + i0, xw + i0, qj, a0, th, s1, s2, wsum, awsum, nexc);
+                                    i0 += 4;
+                                }
+                            } else {
+                                for (; i0 + 8 <= k; i0 += 8) thresh_batch<8, false>(yl + i0, xw + i0, qj, a0, th, s1, s2, wsum, awsum, nexc);
+                                if (i0 + 4 <= k) {
+                                    thresh_batch<4, false>(yl + i0, xw + i0, qj, a0, th, s1, s2, wsum, awsum, nexc);
+                                    i0 += 4;
+                                }
+                            }
                         }
                         for (; i0 < k; i0 += kWinBatch) {
                             // two analog values per load (a lane's window is contiguous; the texture path is the limit of
