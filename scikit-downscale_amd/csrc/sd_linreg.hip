@@ -33,6 +33,7 @@ namespace {
 
 constexpr int kMaxF = sdlsq::kMaxF;
 constexpr int kCells = 64, kSlices = 8;
+constexpr int kFitUnroll = 4;  // time steps of a thread whose loads are in flight together in the fit pass
 
 __device__ __forceinline__ bool lr_finite(double v) { return (__double_as_longlong(v) & 0x7ff0000000000000ll) != 0x7ff0000000000000ll; }
 
@@ -55,12 +56,13 @@ __global__ void __launch_bounds__(kCells * kSlices) linreg_fit_kernel(const doub
                                                                       int32_t* __restrict__ thresh_off) {
     __shared__ double part[kSlices * kCells];
     __shared__ double model[(F + 1) * kCells];  // coefficients and intercept of the tile's cells
+    __shared__ double rss1[kCells];             // residual sum of squares from the sums of pass 1, or -1: the cell takes pass 2
     const int cx = threadIdx.x % kCells, ty = threadIdx.x / kCells;
     const int64_t c = (int64_t)blockIdx.x * kCells + cx;
     const bool live = c < C;
     // pass 1: sums and cross products of the data shifted by the cell's first sample (one pass; the shift keeps the
     // centring subtraction below benign), plus the mask / finite bookkeeping of core.py:35-37, base.py:18-20
-    double x0[F], sx[F], S[F][F], b[F], sy = 0.0;
+    double x0[F], sx[F], S[F][F], b[F], sy = 0.0, syy = 0.0;
     bool bad = false;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
@@ -73,27 +75,42 @@ __global__ void __launch_bounds__(kCells * kSlices) linreg_fit_kernel(const doub
     const double y0 = live ? y[c] : 0.0;
     double cnt = 0.0;  // samples entering the linear model: all, or those above the threshold (gard.py:439)
     if (live)
-        for (int64_t t = ty; t < T; t += kSlices) {
-            double d[F];
-            const double w = y[t * ld + c];
-            bad |= !lr_finite(w);
-            const bool in = !has_thresh || w > thresh;
+        for (int64_t t0 = ty; t0 < T; t0 += kSlices * kFitUnroll) {
+            // (the loads of kFitUnroll time steps are requested together; the sums run in time order as before)
+            double wv[kFitUnroll], xv[kFitUnroll][F];
 #pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const double v = X[(t * F + f) * ld + c];
-                bad |= !lr_finite(v);
-                d[f] = v - x0[f];
+            for (int u = 0; u < kFitUnroll; ++u) {
+                const int64_t t = t0 + (int64_t)u * kSlices;
+                const bool ok = t < T;
+                wv[u] = ok ? y[t * ld + c] : y0;
+#pragma unroll
+                for (int f = 0; f < F; ++f) xv[u][f] = ok ? X[(t * F + f) * ld + c] : x0[f];
             }
-            if (!in) continue;
-            cnt += 1.0;
-            const double e = w - y0;
-            sy += e;
 #pragma unroll
-            for (int f = 0; f < F; ++f) {
-                sx[f] += d[f];
-                b[f] += d[f] * e;
+            for (int u = 0; u < kFitUnroll; ++u) {
+                if (t0 + (int64_t)u * kSlices >= T) break;
+                double d[F];
+                const double w = wv[u];
+                bad |= !lr_finite(w);
+                const bool in = !has_thresh || w > thresh;
 #pragma unroll
-                for (int g = f; g < F; ++g) S[f][g] += d[f] * d[g];
+                for (int f = 0; f < F; ++f) {
+                    const double v = xv[u][f];
+                    bad |= !lr_finite(v);
+                    d[f] = v - x0[f];
+                }
+                if (!in) continue;
+                cnt += 1.0;
+                const double e = w - y0;
+                sy += e;
+                syy += e * e;
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    sx[f] += d[f];
+                    b[f] += d[f] * e;
+#pragma unroll
+                    for (int g = f; g < F; ++g) S[f][g] += d[f] * d[g];
+                }
             }
         }
     if (live && ty == 0 && x0[0] != x0[0]) atomicOr(&status[c], SDI_MASKED);
@@ -110,6 +127,7 @@ __global__ void __launch_bounds__(kCells * kSlices) linreg_fit_kernel(const doub
         xm[f] = x0[f] + dm[f];
     }
     const double em = slice_sum(sy, part, cx, ty) / n, ym = y0 + em;
+    const double Syy = slice_sum(syy, part, cx, ty) - n * em * em;  // centred: sum e^2 - n mean(e)^2
     double A[kMaxF][kMaxF + 1];
 #pragma unroll
     for (int f = 0; f < F; ++f) {
@@ -122,7 +140,9 @@ __global__ void __launch_bounds__(kCells * kSlices) linreg_fit_kernel(const doub
         }
     }
     if (ty == 0) {
-        double coef[kMaxF];
+        double coef[kMaxF], sxy[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) sxy[f] = A[f][F];  // (the solver works in place)
         sdlsq::minnorm_solve(F, A, coef);
         double icpt = ym;
 #pragma unroll
@@ -131,15 +151,26 @@ __global__ void __launch_bounds__(kCells * kSlices) linreg_fit_kernel(const doub
             model[f * kCells + cx] = coef[f];
         }
         model[F * kCells + cx] = icpt;
+        // residual sum of squares of the least-squares solution from the sums of pass 1: Syy - coef . Sxy (the normal equations).
+        // Its relative error is ~ eps Syy / rss: far inside the parity contract unless the fit is (nearly) exact -- such a cell,
+        // and every cell with a threshold (subset fit: kept as it was), sums its residuals in a second pass.  The decision is
+        // per cell: a cell's result does not depend on the cells that share its tile.
+        double rss = Syy;
+#pragma unroll
+        for (int f = 0; f < F; ++f) rss -= coef[f] * sxy[f];
+        const bool second = has_thresh || !(rss > 1e-9 * Syy);
+        rss1[cx] = second ? -1.0 : rss;
     }
     __syncthreads();
-    // pass 2: residuals of the fit (root_mean_squared_error, gard.py:441-442)
+    // pass 2 (cells that need it): residuals of the fit (root_mean_squared_error, gard.py:441-442)
     double cf[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) cf[f] = model[f * kCells + cx];
     const double icpt = model[F * kCells + cx];
+    const double rss_sums = rss1[cx];
+    const bool second = rss_sums < 0.0;
     double ss = 0.0;
-    if (live)
+    if (live && second)
         for (int64_t t = ty; t < T; t += kSlices) {
             const double w = y[t * ld + c];
             if (has_thresh && !(w > thresh)) continue;
@@ -154,7 +185,7 @@ __global__ void __launch_bounds__(kCells * kSlices) linreg_fit_kernel(const doub
 #pragma unroll
         for (int f = 0; f < F; ++f) coef_out[(int64_t)f * C + c] = cf[f];
         icpt_out[c] = icpt;
-        rmse_out[c] = sqrt(ss / n);
+        rmse_out[c] = sqrt((second ? ss : rss_sums) / n);
     }
 }
 
