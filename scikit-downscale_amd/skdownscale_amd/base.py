@@ -77,3 +77,29 @@ class TimeSynchronousDownscaler(BaseEstimator):
         if reset_features:
             self.n_features_in_ = X2.shape[1]
         return X2, index
+
+# sklearn keyword arguments the reference forwards to LinearRegression / LogisticRegression (gard.py:136-150, 257-271, 389-402;
+# trend.py:40-42).  The engine computes ONE model -- ordinary least squares with an intercept; the exact minimiser of the
+# L2-penalised logistic objective with C = 1 --, so a value that asks for that model, or an option that does not change the
+# fitted model (threads, copies, verbosity, solver, stopping rule: the engine's minimiser is the converged one), is accepted
+# and anything else refused.
+LINEAR_NEUTRAL = {"fit_intercept": (True,), "positive": (False,), "copy_X": None, "n_jobs": None, "tol": None}
+LOGISTIC_NEUTRAL = {"penalty": ("l2",), "C": (1, 1.0), "fit_intercept": (True,), "dual": (False,), "intercept_scaling": (1, 1.0),
+                    "class_weight": (None,), "l1_ratio": (None,), "multi_class": ("auto", "deprecated"), "solver": None, "tol": None,
+                    "max_iter": None, "n_jobs": None, "verbose": None, "warm_start": None, "random_state": None}
+
+
+def _same_value(v, a):
+    if a is None or isinstance(a, (bool, str)):
+        return v is a or (isinstance(a, str) and isinstance(v, str) and v == a)
+    return isinstance(v, (int, float)) and not isinstance(v, bool) and v == a  # (C=1 and C=1.0 are the same request)
+
+
+def check_sklearn_kwargs(kwargs, neutral, what, model):
+    """raise NotImplementedError for the first entry of ``kwargs`` that would change the fitted model"""
+    for k, v in (kwargs or {}).items():
+        if k not in neutral:
+            raise NotImplementedError(f"{what}={{{k!r}: {v!r}}} is not supported on the HIP engine ({model})")
+        allowed = neutral[k]
+        if allowed is not None and not any(_same_value(v, a) for a in allowed):
+            raise NotImplementedError(f"{what}={{{k!r}: {v!r}}} is not supported on the HIP engine ({model})")

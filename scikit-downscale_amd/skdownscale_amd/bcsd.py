@@ -18,7 +18,7 @@ import pandas as pd
 from sklearn.exceptions import NotFittedError
 
 from . import _lib
-from .base import TimeSynchronousDownscaler
+from .base import LINEAR_NEUTRAL, TimeSynchronousDownscaler, check_sklearn_kwargs
 from .engine import DeviceArray, default_context
 from .groupers import DAY_GROUPER, MONTH_GROUPER, PaddedDOYGrouper, group_keys, padded_doy_table
 from .trend import FittedLine, FittedTrend
@@ -57,8 +57,9 @@ def check_supported(model):
     extra = set(qm) - {"detrend", "lt_kwargs", "qt_kwargs"}
     if extra:
         raise TypeError(f"QuantileMapper.__init__() got an unexpected keyword argument {sorted(extra)[0]!r}")
-    if qm.get("detrend", False) and (qm.get("lt_kwargs") or {}).get("lr_kwargs"):
-        raise NotImplementedError("LinearTrendTransformer(lr_kwargs=...): only the LinearRegression defaults run on the HIP engine")
+    if qm.get("detrend", False):
+        check_sklearn_kwargs((qm.get("lt_kwargs") or {}).get("lr_kwargs"), LINEAR_NEUTRAL, "LinearTrendTransformer(lr_kwargs)",
+                             "only the LinearRegression defaults run")
     qt_settings(model)
 
 

@@ -15,7 +15,7 @@ from sklearn.base import BaseEstimator, RegressorMixin
 from sklearn.exceptions import NotFittedError
 
 from . import _lib
-from .base import _finite_error
+from .base import LINEAR_NEUTRAL, LOGISTIC_NEUTRAL, _finite_error, check_sklearn_kwargs
 from .engine import default_context
 
 KIND_CODES = {"best_analog": _lib.ANALOG_BEST, "sample_analogs": _lib.ANALOG_SAMPLE,
@@ -158,10 +158,8 @@ class AnalogRegression(AnalogBase):
         self.lr_kwargs = lr_kwargs
 
     def _check(self):
-        if self.lr_kwargs:
-            raise NotImplementedError("lr_kwargs are not supported on the HIP engine (plain OLS with intercept)")
-        if self.logistic_kwargs:
-            raise NotImplementedError("logistic_kwargs are not supported on the HIP engine (LogisticRegression defaults: L2, C=1)")
+        check_sklearn_kwargs(self.lr_kwargs, LINEAR_NEUTRAL, "lr_kwargs", "plain OLS with intercept")
+        check_sklearn_kwargs(self.logistic_kwargs, LOGISTIC_NEUTRAL, "logistic_kwargs", "LogisticRegression defaults: L2, C=1")
         check_tree_kwargs(self)
 
     def predict(self, X):
@@ -258,10 +256,8 @@ class PureRegression(RegressorMixin, BaseEstimator):
         self.linear_kwargs = linear_kwargs
 
     def _check(self):
-        if self.linear_kwargs:
-            raise NotImplementedError("linear_kwargs are not supported on the HIP engine (plain OLS with intercept)")
-        if self.logistic_kwargs:
-            raise NotImplementedError("logistic_kwargs are not supported on the HIP engine (LogisticRegression defaults: L2, C=1)")
+        check_sklearn_kwargs(self.linear_kwargs, LINEAR_NEUTRAL, "linear_kwargs", "plain OLS with intercept")
+        check_sklearn_kwargs(self.logistic_kwargs, LOGISTIC_NEUTRAL, "logistic_kwargs", "LogisticRegression defaults: L2, C=1")
 
     def _adopt(self, e, c):
         """fitted attributes of cell ``c`` of an exported state (gard.py:420-443)"""

@@ -17,6 +17,7 @@ from sklearn.exceptions import NotFittedError
 from sklearn.utils import check_array
 
 from . import _lib
+from .base import LINEAR_NEUTRAL, check_sklearn_kwargs
 from .engine import default_context
 from .trend import FittedLine, FittedTrend
 
@@ -62,7 +63,11 @@ class QuantileMapper(TransformerMixin, BaseEstimator):
 
     def _check(self):
         if self.detrend and self.lt_kwargs:
-            raise NotImplementedError("QuantileMapper(lt_kwargs=...): only the LinearTrendTransformer defaults run on the HIP engine")
+            extra = set(self.lt_kwargs) - {"lr_kwargs"}
+            if extra:  # (LinearTrendTransformer takes lr_kwargs only: trend.py:40)
+                raise TypeError(f"LinearTrendTransformer.__init__() got an unexpected keyword argument {sorted(extra)[0]!r}")
+            check_sklearn_kwargs(self.lt_kwargs.get("lr_kwargs"), LINEAR_NEUTRAL, "QuantileMapper(lt_kwargs={'lr_kwargs': ...})",
+                                 "only the LinearRegression defaults run")
         self._tails()
 
     def _tails(self):

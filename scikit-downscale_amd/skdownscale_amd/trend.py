@@ -13,6 +13,7 @@ from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.exceptions import NotFittedError
 from sklearn.utils import check_array
 
+from .base import LINEAR_NEUTRAL, check_sklearn_kwargs
 from .engine import default_context
 
 FittedLine = collections.namedtuple("FittedLine", ["coef_", "intercept_"])  # the lr_model_ attributes trend.py:50-51 leaves behind
@@ -40,8 +41,7 @@ class LinearTrendTransformer(TransformerMixin, BaseEstimator):
         self.lr_kwargs = lr_kwargs
 
     def fit(self, X, y=None):
-        if self.lr_kwargs:
-            raise NotImplementedError("LinearTrendTransformer(lr_kwargs=...): only the LinearRegression defaults run on the HIP engine")
+        check_sklearn_kwargs(self.lr_kwargs, LINEAR_NEUTRAL, "LinearTrendTransformer(lr_kwargs)", "only the LinearRegression defaults run")
         X = check_array(X, dtype="numeric", ensure_2d=True)
         Xv = np.asarray(X, dtype=np.float64)
         n, cells = Xv.shape

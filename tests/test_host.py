@@ -79,6 +79,7 @@ def test_unsupported_configurations_raise():
 
     check_supported(BcsdTemperature(climate_trend=DAY_GROUPER))
     check_supported(BcsdTemperature(qm_kwargs={"detrend": True}))
+    check_supported(BcsdTemperature(qm_kwargs={"detrend": True, "lt_kwargs": {"lr_kwargs": {"fit_intercept": True, "n_jobs": 2}}}))
     for bad in (BcsdTemperature(time_grouper="M"), BcsdTemperature(qm_kwargs={"detrend": True, "lt_kwargs": {"lr_kwargs": {"fit_intercept": False}}}),
                 BcsdTemperature(qm_kwargs={"qt_kwargs": {"n_endpoints": 0}})):
         with pytest.raises(NotImplementedError):
@@ -363,8 +364,13 @@ def test_quantile_mapper_qt_kwargs_are_validated_like_the_reference():
     for bad in (0, -3, 2.5, None):
         with pytest.raises(NotImplementedError, match="n_endpoints"):
             QuantileMapper(qt_kwargs={"n_endpoints": bad}).fit(np.arange(10.0).reshape(-1, 1))
-    with pytest.raises(NotImplementedError, match="lt_kwargs"):
+    # lt_kwargs go to LinearTrendTransformer(**lt_kwargs) (quantile.py:96-97), which takes `lr_kwargs` only (trend.py:31): anything else is
+    # the reference's TypeError; lr_kwargs that would change the fitted line are refused, result-neutral ones accepted
+    with pytest.raises(TypeError, match="unexpected keyword argument 'fit_intercept'"):
         QuantileMapper(detrend=True, lt_kwargs={"fit_intercept": False}).fit(np.arange(10.0).reshape(-1, 1))
+    with pytest.raises(NotImplementedError, match="lt_kwargs"):
+        QuantileMapper(detrend=True, lt_kwargs={"lr_kwargs": {"fit_intercept": False}}).fit(np.arange(10.0).reshape(-1, 1))
+    QuantileMapper(detrend=True, lt_kwargs={"lr_kwargs": {"fit_intercept": True, "copy_X": False}})._check()
 
 
 def test_pure_regression_argument_checks():
@@ -382,6 +388,18 @@ def test_pure_regression_argument_checks():
         PureRegression(thresh=1.0, logistic_kwargs={"C": 10.0}).fit(X, y)
     with pytest.raises(NotImplementedError, match="linear_kwargs"):
         PureRegression(linear_kwargs={"fit_intercept": False}).fit(X, y)
+    # keyword values that ask for the model the engine computes, or that do not change the fitted model, pass the check
+    # (gard.py:389-402 forwards them to sklearn); anything that would change it is refused
+    from skdownscale_amd.base import LINEAR_NEUTRAL, LOGISTIC_NEUTRAL, check_sklearn_kwargs
+
+    for kw, table in ((None, LINEAR_NEUTRAL), ({"fit_intercept": True, "n_jobs": 4, "copy_X": False, "positive": False}, LINEAR_NEUTRAL),
+                      ({"C": 1, "penalty": "l2", "tol": 1e-12, "max_iter": 1000, "solver": "newton-cg", "class_weight": None}, LOGISTIC_NEUTRAL)):
+        check_sklearn_kwargs(kw, table, "kw", "model")
+    PureRegression(thresh=1.0, logistic_kwargs={"C": 1.0, "max_iter": 500}, linear_kwargs={"n_jobs": 2})._check()
+    for kw, table in (({"positive": True}, LINEAR_NEUTRAL), ({"fit_intercept": 1}, LINEAR_NEUTRAL), ({"unknown": 0}, LINEAR_NEUTRAL),
+                      ({"penalty": "l1"}, LOGISTIC_NEUTRAL), ({"class_weight": "balanced"}, LOGISTIC_NEUTRAL), ({"C": True}, LOGISTIC_NEUTRAL)):
+        with pytest.raises(NotImplementedError, match="not supported on the HIP engine"):
+            check_sklearn_kwargs(kw, table, "kw", "model")
     with pytest.raises(NotFittedError):
         m.predict(X)
     with pytest.raises(ValueError, match="NaN"):
