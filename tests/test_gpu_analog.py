@@ -637,3 +637,35 @@ def test_tile_shaped_fit_stage_is_bit_identical(ctx, dev_ctx, monkeypatch, T):
     for c in (0, 12, 18):
         d, i = ao.knn(X[:, :, c], Xq[:, :, c], k)
         assert np.array_equal(ia[:, :, c], i) and np.array_equal(da[:, :, c], d)
+
+
+@pytest.mark.parametrize("k", [5, 30, 64])
+def test_regression_direct_window_sums_against_prefix_differences(ctx, dev_ctx, monkeypatch, k):
+    """One-feature AnalogRegression with a window of k <= 64 analogs sums the window directly (reg_batch in analog_f1_mean_kernel); the
+    development library's SD_ANALOG_REG_PREFIX keeps the form it replaces (prefix differences, what n_analogs > 64 still takes).
+    Both are restatements of the same least squares: they agree to rounding on continuous data -- long query series (value-ordered
+    runs) and short ones, a masked cell, a cell with a non-finite sample --, and both agree with the oracle's lstsq per query.
+    (The straight-line batches of 'weight_analogs' need no such pair: same operations in the same order, covered bit for bit by every
+    weight_analogs case of this file.)"""
+    rng = np.random.default_rng(100 + k)
+    T, C = 6000, 7
+    X = rng.standard_normal((T, 1, C))
+    y = 0.8 * X[:, 0, :] + 0.5 * rng.standard_normal((T, C))
+    X[0, 0, 2] = np.nan
+    y[17, 5] = np.inf
+    st = ctx.analog_fit(X, y)
+    monkeypatch.setenv("SD_ANALOG_REG_PREFIX", "1")
+    st0 = dev_ctx.analog_fit(X, y)
+    for Tq in (300, 5000):
+        Xq = 1.1 * rng.standard_normal((Tq, 1, C))
+        monkeypatch.delenv("SD_ANALOG_REG_PREFIX", raising=False)
+        a, sa = ctx.analogreg_predict(st, Xq, k)
+        monkeypatch.setenv("SD_ANALOG_REG_PREFIX", "1")
+        b, sb = dev_ctx.analogreg_predict(st0, Xq, k)
+        assert sa.tolist() == sb.tolist() and sa[2] == 1 and sa[5] == 2
+        # (the prefix differences carry an absolute error of ~1e-16 of the cell totals: ~1e-8 of a five-analog window's residual sum)
+        assert_close(a, b, rtol=1e-7, what=f"direct vs prefix k={k} Tq={Tq}")
+        sel = np.arange(0, Tq, max(1, Tq // 150))
+        exp = ao.pointwise_analog(X[:, :, [0, 6]], y[:, [0, 6]], Xq[sel][:, :, [0, 6]], k, ao.KIND_MEAN, regression=True)
+        assert_close(a[sel][:, :, [0, 6]], exp, what=f"direct vs oracle k={k} Tq={Tq}")
+    monkeypatch.delenv("SD_ANALOG_REG_PREFIX", raising=False)
